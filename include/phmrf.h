@@ -1,0 +1,160 @@
+/* libphmrf -- MI355X (gfx950) E-step of Phylo-HMRF behind a plain C ABI.
+ *
+ * One `phmrf_block_t` is one syntenic block (an independent MRF; reference: one OS process per
+ * block, base.py:357-362) resident on ONE GPU: observations X[n,S], the neighbour graph, the
+ * emission log-likelihoods logprob[n,K] and the labels stay in HBM across EM iterations.  Per
+ * iteration the host sends K*(S+S*S) doubles (means_, _covars_) and receives K*(1+S+S*S)+4
+ * doubles (sufficient statistics + cost numerators).
+ *
+ * Every entry point returns a status int (PHMRF_OK == 0); nothing throws across the boundary
+ * (the reference's native layer signals by GCException, gco_source/GCoptimization.cpp:1072-1076;
+ * here it is a status + phmrf_last_error()).  Host arrays are plain C-order arrays owned by the
+ * caller (NumPy-compatible), float64 / int32 / int64 as the reference passes them.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   b1  phyloHMRF._compute_log_likelihood            phylo_hmrf.py:266-268  -> phmrf_emission
+ *   b2  pygco.cut_general_graph(... 'swap' ...)      phylo_hmrf.py:496-498  -> phmrf_mrf_solve
+ *       (gco handle API it sits on: GCoptimization.h:551-597)                  phmrf_block_set_graph
+ *   b3  phyloHMRF._compute_posteriors_graph + stats  phylo_hmrf.py:334-355, :311-314
+ *                                                                           -> phmrf_posterior_stats
+ *   a-E judged energy                                      -> phmrf_mrf_energy
+ */
+#ifndef PHMRF_H_
+#define PHMRF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHMRF_API __attribute__((visibility("default")))
+
+/* ---- status codes --------------------------------------------------------------------------- */
+#define PHMRF_OK 0
+#define PHMRF_ERR_INVALID 1      /* bad argument (shape, range, NULL)                              */
+#define PHMRF_ERR_HIP 2          /* a HIP runtime call failed (see phmrf_last_error)               */
+#define PHMRF_ERR_NO_DEVICE 3    /* no gfx950 device visible                                       */
+#define PHMRF_ERR_UNSUPPORTED 4  /* valid request outside what the kernels cover (K>64, deg>64...) */
+#define PHMRF_ERR_STATE 5        /* call order: e.g. solve before the graph or logprob was set     */
+#define PHMRF_ERR_NOT_PD 6       /* a state covariance is not positive definite (sklearn raises
+                                    ValueError at the same point)                                  */
+
+typedef struct phmrf_block* phmrf_block_t;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+PHMRF_API int phmrf_version(void);
+PHMRF_API const char* phmrf_last_error(void);
+PHMRF_API const char* phmrf_status_string(int status);
+PHMRF_API int phmrf_device_count(int* count);
+PHMRF_API int phmrf_set_device(int device);
+
+/* ---- block lifetime --------------------------------------------------------------------------- */
+/* n nodes (Hi-C bin pairs), S species (leaves), K states.  K <= 64, S <= 16. */
+PHMRF_API int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out);
+PHMRF_API int phmrf_block_destroy(phmrf_block_t b);
+/* Run this block's kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
+ * block's own stream. */
+PHMRF_API int phmrf_block_set_stream(phmrf_block_t b, void* hip_stream);
+PHMRF_API int phmrf_block_sync(phmrf_block_t b);
+
+/* X: host float64 [n,S] C-order (reference `samples[s1:s2]`, phylo_hmrf.py:303); stored as f32. */
+PHMRF_API int phmrf_block_set_observations(phmrf_block_t b, const double* X);
+/* Same from a device f32 [n,S] buffer (device-to-device copy on the block's stream). */
+PHMRF_API int phmrf_block_set_observations_dev(phmrf_block_t b, const float* X_dev);
+
+/* Undirected graph as the reference hands it to pygco (phylo_hmrf.py:496): edges int64 [E,2]
+ * (one row per unordered pair, any order, no self loops, no duplicates), w float64 [E] >= 0
+ * (= exp(-beta1*d), phylo_hmrf.py:585).  Builds the device adjacency once; the graph is constant
+ * across EM iterations (phylo_hmrf.py:101). */
+PHMRF_API int phmrf_block_set_graph(phmrf_block_t b, int64_t E, const int64_t* edges, const double* w);
+/* Optional geometry of the block (len_vec fields 3,4,8: H, W, type):
+ * diagonal=1: H==W, nodes are the upper triangle row-major; diagonal=0: full H x W row-major.
+ * num_neighbor 8 or 4 (utility.py:1898-1905).  Checked against the edge list (every edge must join
+ * grid neighbours); enables the 1-D chain moves (rows / columns / diagonals). */
+PHMRF_API int phmrf_block_set_grid(phmrf_block_t b, int H, int W, int diagonal, int num_neighbor);
+
+/* labels: host int32 [n], each in [0,K).  (reference: init_labels = labels_local[id1:id2],
+ * phylo_hmrf.py:479; float input is cast by the Python layer.) */
+PHMRF_API int phmrf_block_set_labels(phmrf_block_t b, const int32_t* labels);
+PHMRF_API int phmrf_block_get_labels(phmrf_block_t b, int32_t* labels);
+/* Device-side label snapshots (slot 0..3), e.g. labels_local / t_labels (base.py:419, :426) without a
+ * host round trip. */
+PHMRF_API int phmrf_block_save_labels(phmrf_block_t b, int slot);
+PHMRF_API int phmrf_block_restore_labels(phmrf_block_t b, int slot);
+PHMRF_API int phmrf_block_get_saved_labels(phmrf_block_t b, int slot, int32_t* labels);
+
+/* ---- b1: emission ---------------------------------------------------------------------------- */
+/* logprob[i,k] = log N(x_i; means[k], covars[k]) for all nodes of the block, left resident in HBM.
+ * means float64 [K,S], covars float64 [K,S,S].  Cholesky (with sklearn's +1e-7*I retry) and
+ * L^-1 are done in float64 on the host, the per-node arithmetic in float32 on the device. */
+PHMRF_API int phmrf_emission(phmrf_block_t b, const double* means, const double* covars);
+PHMRF_API int phmrf_block_get_logprob(phmrf_block_t b, double* logprob /* [n,K] */);
+/* Install externally computed log-likelihoods (drop-in cut_general_graph: unary = -logprob). */
+PHMRF_API int phmrf_block_set_logprob(phmrf_block_t b, const double* logprob /* [n,K] */);
+
+/* Stateless device-pointer form of b1 (all pointers are device memory, f32):
+ * packed = phmrf_emission_pack() output copied to the device. */
+PHMRF_API int phmrf_emission_pack_size(int S, int K, int64_t* n_floats);
+PHMRF_API int phmrf_emission_pack(int S, int K, const double* means, const double* covars, float* packed_host);
+PHMRF_API int phmrf_emission_dev(const float* X_dev, int64_t n, int S, int K, const float* packed_dev,
+                                 float* logprob_dev, void* hip_stream);
+
+/* ---- b2: MRF labelling ------------------------------------------------------------------------ */
+typedef struct phmrf_solve_opts {
+  int max_rounds;      /* <=0: default 64.  One round = chain moves (if grid set) + component moves + ICM sweep */
+  int use_chains;      /* 1: exact 1-D chain moves when geometry is known                                      */
+  int use_components;  /* 1: whole-component relabel moves                                                     */
+  int init_mode;       /* 0: start from the block's current labels (reference warm start, phylo_hmrf.py:479)
+                          1: start from argmax_k logprob                                                        */
+  int reserved[4];
+} phmrf_solve_opts;
+
+typedef struct phmrf_solve_result {
+  double energy;        /* E_float = sum_i -logprob[i,l_i] + beta * sum_(i,j) w_ij [l_i != l_j]  */
+  double energy_unary;
+  double energy_pair;
+  double energy_init;   /* same for the starting labels */
+  int rounds;           /* rounds executed */
+  int converged;        /* 1 if the last round changed no label */
+  int64_t changed;      /* total label changes applied */
+} phmrf_solve_result;
+
+/* Minimise E_float by energy-non-increasing moves from the current labels; labels stay on the device
+ * (phmrf_block_get_labels to fetch).  opts NULL = defaults, res may be NULL. */
+PHMRF_API int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res);
+/* One colour-ordered ICM sweep / one sweep of one chain family / one component-move pass (exposed
+ * for move-level parity tests against oracle/mrf_moves.py).  family: 0 rows, 1 columns,
+ * 2 diagonals, 3 anti-diagonals. */
+PHMRF_API int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed);
+PHMRF_API int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* changed);
+PHMRF_API int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed);
+PHMRF_API int phmrf_mrf_energy(phmrf_block_t b, double beta, double* e_total, double* e_unary, double* e_pair);
+
+/* ---- b3: posteriors, costs, sufficient statistics ------------------------------------------- */
+/* stats_out: host float64 [K + K*S + K*S*S] = post | obs | obs*obs.T (phylo_hmrf.py:311-314).
+ * costs_out: host float64 [4] = UN-normalised sums over the block's nodes of
+ *   [0] sum_i sum_{e in inc(i)} V[l_other,l_i]*w'_e      (n * pairwise_cost,            :438-447)
+ *   [1] sum_i -log(ppn[i,l_i] + 1e-16)                   (n * pairwise_cost_normalize,  :386,:392)
+ *   [2] sum_i -logprob[i,l_i]                            (n * unary_cost,               :385-390)
+ *   [3] [1] + [2]                                        (n * cost1,                    :394)
+ * w'_e = w_e when estimate_type == 3 else 1 (:431-434, :460-462).
+ * posteriors_out: optional host float64 [n,K] (NULL to skip the download). */
+PHMRF_API int phmrf_posterior_stats(phmrf_block_t b, double beta, int estimate_type, double* stats_out,
+                                    double* costs_out, double* posteriors_out);
+/* Same, results left in device memory (float64 [K+K*S+K*S*S+4], stats then costs) for an RCCL
+ * all-reduce on the caller's stream; no host synchronisation. */
+PHMRF_API int phmrf_posterior_stats_dev(phmrf_block_t b, double beta, int estimate_type, double* out_dev);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
+ * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats. */
+#define PHMRF_NUM_KERNEL_CLASSES 6
+PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
+PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[6]*/, int64_t* launches /*[6]*/);
+PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHMRF_H_ */

@@ -1,0 +1,130 @@
+"""ctypes binding of libphmrf.so (include/phmrf.h).  No CPU fallback: if the HIP library is missing or
+no GPU is visible, the product path raises."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphmrf.so")
+
+OK = 0
+NUM_KERNEL_CLASSES = 6
+KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats")
+
+
+class PhmrfError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "libphmrf status %d: %s" % (status, message))
+        self.status = status
+
+
+class SolveOpts(ctypes.Structure):
+    _fields_ = [("max_rounds", ctypes.c_int), ("use_chains", ctypes.c_int), ("use_components", ctypes.c_int),
+                ("init_mode", ctypes.c_int), ("reserved", ctypes.c_int * 4)]
+
+
+class SolveResult(ctypes.Structure):
+    _fields_ = [("energy", ctypes.c_double), ("energy_unary", ctypes.c_double), ("energy_pair", ctypes.c_double),
+                ("energy_init", ctypes.c_double), ("rounds", ctypes.c_int), ("converged", ctypes.c_int),
+                ("changed", ctypes.c_int64)]
+
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_d = ctypes.c_double
+_dp = ctypes.POINTER(ctypes.c_double)
+_fp = ctypes.POINTER(ctypes.c_float)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_lp = ctypes.POINTER(ctypes.c_int64)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "phmrf_version": [],
+    "phmrf_last_error": [],
+    "phmrf_status_string": [_i],
+    "phmrf_device_count": [ctypes.POINTER(_i)],
+    "phmrf_set_device": [_i],
+    "phmrf_block_create": [_i64, _i, _i, ctypes.POINTER(_vp)],
+    "phmrf_block_destroy": [_vp],
+    "phmrf_block_set_stream": [_vp, _vp],
+    "phmrf_block_sync": [_vp],
+    "phmrf_block_set_observations": [_vp, _dp],
+    "phmrf_block_set_observations_dev": [_vp, _vp],
+    "phmrf_block_set_graph": [_vp, _i64, _lp, _dp],
+    "phmrf_block_set_grid": [_vp, _i, _i, _i, _i],
+    "phmrf_block_set_labels": [_vp, _ip],
+    "phmrf_block_get_labels": [_vp, _ip],
+    "phmrf_block_save_labels": [_vp, _i],
+    "phmrf_block_restore_labels": [_vp, _i],
+    "phmrf_block_get_saved_labels": [_vp, _i, _ip],
+    "phmrf_emission": [_vp, _dp, _dp],
+    "phmrf_block_get_logprob": [_vp, _dp],
+    "phmrf_block_set_logprob": [_vp, _dp],
+    "phmrf_emission_pack_size": [_i, _i, _lp],
+    "phmrf_emission_pack": [_i, _i, _dp, _dp, _fp],
+    "phmrf_emission_dev": [_vp, _i64, _i, _i, _vp, _vp, _vp],
+    "phmrf_mrf_solve": [_vp, _d, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveResult)],
+    "phmrf_mrf_icm_sweep": [_vp, _d, _lp],
+    "phmrf_mrf_chain_sweep": [_vp, _d, _i, _lp],
+    "phmrf_mrf_component_pass": [_vp, _d, _lp],
+    "phmrf_mrf_energy": [_vp, _d, _dp, _dp, _dp],
+    "phmrf_posterior_stats": [_vp, _d, _i, _dp, _dp, _dp],
+    "phmrf_posterior_stats_dev": [_vp, _d, _i, _vp],
+    "phmrf_block_enable_timing": [_vp, _i],
+    "phmrf_block_get_timing": [_vp, _dp, _lp],
+    "phmrf_block_reset_timing": [_vp],
+}
+_RESTYPES = {"phmrf_last_error": ctypes.c_char_p, "phmrf_status_string": ctypes.c_char_p}
+
+
+def load():
+    """Load libphmrf.so and declare every entry point.  Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C phylo_hmrf_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        raise PhmrfError(status, load().phmrf_last_error().decode())
+
+
+def device_count():
+    c = ctypes.c_int(0)
+    st = load().phmrf_device_count(ctypes.byref(c))
+    return c.value if st == OK else 0
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise RuntimeError("phylo_hmrf_amd needs an MI355X (gfx950) GPU: no HIP device is visible and there is "
+                           "no CPU fallback")
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr_d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def ptr_i32(a):
+    return a.ctypes.data_as(_ip)
+
+
+def ptr_i64(a):
+    return a.ctypes.data_as(_lp)

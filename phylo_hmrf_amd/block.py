@@ -1,0 +1,168 @@
+"""`Block`: one syntenic block resident on one MI355X, a thin object wrapper over the C ABI."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import SolveOpts, SolveResult, as_f64, check, ptr_d, ptr_i32, ptr_i64
+
+
+class Block(object):
+    """Device-resident state of one syntenic block (reference: one forked process per block,
+    base.py:357-362).  X, the neighbour graph, logprob[n,K] and the labels live in HBM."""
+
+    def __init__(self, n, S, K):
+        _lib.require_gpu()
+        self._L = _lib.load()
+        self.n, self.S, self.K = int(n), int(S), int(K)
+        h = ctypes.c_void_p()
+        check(self._L.phmrf_block_create(self.n, self.S, self.K, ctypes.byref(h)))
+        self._h = h
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.phmrf_block_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._L.phmrf_block_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        check(self._L.phmrf_block_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    # -- inputs -----------------------------------------------------------------------------------
+    def set_observations(self, X):
+        X = as_f64(X)
+        assert X.shape == (self.n, self.S), (X.shape, self.n, self.S)
+        check(self._L.phmrf_block_set_observations(self._h, ptr_d(X)))
+
+    def set_observations_dev(self, dev_ptr):
+        check(self._L.phmrf_block_set_observations_dev(self._h, ctypes.c_void_p(dev_ptr)))
+
+    def set_graph(self, edges, w):
+        edges = np.ascontiguousarray(np.asarray(edges)[:, 0:2], dtype=np.int64)
+        w = as_f64(w)
+        assert edges.shape[0] == w.shape[0]
+        check(self._L.phmrf_block_set_graph(self._h, edges.shape[0], ptr_i64(edges), ptr_d(w)))
+
+    def set_grid(self, H, W, diagonal, num_neighbor=8):
+        check(self._L.phmrf_block_set_grid(self._h, int(H), int(W), int(bool(diagonal)), int(num_neighbor)))
+
+    def set_labels(self, labels):
+        lab = np.ascontiguousarray(np.asarray(labels), dtype=np.int32)   # float labels are cast (base.py:381,394)
+        assert lab.shape == (self.n,)
+        check(self._L.phmrf_block_set_labels(self._h, ptr_i32(lab)))
+
+    def get_labels(self):
+        out = np.empty(self.n, dtype=np.int32)
+        check(self._L.phmrf_block_get_labels(self._h, ptr_i32(out)))
+        return out
+
+    def save_labels(self, slot):
+        check(self._L.phmrf_block_save_labels(self._h, slot))
+
+    def restore_labels(self, slot):
+        check(self._L.phmrf_block_restore_labels(self._h, slot))
+
+    def get_saved_labels(self, slot):
+        out = np.empty(self.n, dtype=np.int32)
+        check(self._L.phmrf_block_get_saved_labels(self._h, slot, ptr_i32(out)))
+        return out
+
+    # -- b1 ---------------------------------------------------------------------------------------
+    def emission(self, means, covars):
+        means, covars = as_f64(means), as_f64(covars)
+        assert means.shape == (self.K, self.S) and covars.shape == (self.K, self.S, self.S)
+        check(self._L.phmrf_emission(self._h, ptr_d(means), ptr_d(covars)))
+
+    def get_logprob(self):
+        out = np.empty((self.n, self.K), dtype=np.float64)
+        check(self._L.phmrf_block_get_logprob(self._h, ptr_d(out)))
+        return out
+
+    def set_logprob(self, logprob):
+        lp = as_f64(logprob)
+        assert lp.shape == (self.n, self.K)
+        check(self._L.phmrf_block_set_logprob(self._h, ptr_d(lp)))
+
+    # -- b2 ---------------------------------------------------------------------------------------
+    def solve(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0):
+        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode))
+        r = SolveResult()
+        check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), ctypes.byref(r)))
+        return dict(energy=r.energy, energy_unary=r.energy_unary, energy_pair=r.energy_pair,
+                    energy_init=r.energy_init, rounds=r.rounds, converged=bool(r.converged), changed=r.changed)
+
+    def solve_fast(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0):
+        """Same without the two energy evaluations."""
+        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode))
+        check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), None))
+
+    def icm_sweep(self, beta):
+        c = ctypes.c_int64(0)
+        check(self._L.phmrf_mrf_icm_sweep(self._h, float(beta), ctypes.byref(c)))
+        return c.value
+
+    def chain_sweep(self, beta, family):
+        c = ctypes.c_int64(0)
+        check(self._L.phmrf_mrf_chain_sweep(self._h, float(beta), int(family), ctypes.byref(c)))
+        return c.value
+
+    def component_pass(self, beta):
+        c = ctypes.c_int64(0)
+        check(self._L.phmrf_mrf_component_pass(self._h, float(beta), ctypes.byref(c)))
+        return c.value
+
+    def energy(self, beta):
+        e, eu, ep = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        check(self._L.phmrf_mrf_energy(self._h, float(beta), ctypes.byref(e), ctypes.byref(eu), ctypes.byref(ep)))
+        return e.value, eu.value, ep.value
+
+    # -- b3 ---------------------------------------------------------------------------------------
+    def n_stats(self):
+        return self.K * (1 + self.S + self.S * self.S)
+
+    def posterior_stats(self, beta, estimate_type, want_posteriors=False):
+        """-> (stats dict with the reference's keys, costs[4] un-normalised sums, posteriors or None)."""
+        K, S = self.K, self.S
+        st = np.zeros(self.n_stats(), dtype=np.float64)
+        costs = np.zeros(4, dtype=np.float64)
+        post = np.empty((self.n, K), dtype=np.float64) if want_posteriors else None
+        check(self._L.phmrf_posterior_stats(self._h, float(beta), int(estimate_type), ptr_d(st), ptr_d(costs),
+                                            ptr_d(post) if want_posteriors else None))
+        return unpack_stats(st, K, S), costs, post
+
+    def posterior_stats_dev(self, beta, estimate_type, out_dev_ptr):
+        check(self._L.phmrf_posterior_stats_dev(self._h, float(beta), int(estimate_type), ctypes.c_void_p(out_dev_ptr)))
+
+    # -- timing -----------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        check(self._L.phmrf_block_enable_timing(self._h, int(on)))
+
+    def reset_timing(self):
+        check(self._L.phmrf_block_reset_timing(self._h))
+
+    def timing(self):
+        ms = (ctypes.c_double * _lib.NUM_KERNEL_CLASSES)()
+        ln = (ctypes.c_int64 * _lib.NUM_KERNEL_CLASSES)()
+        check(self._L.phmrf_block_get_timing(self._h, ms, ln))
+        return {name: (ms[i], ln[i]) for i, name in enumerate(_lib.KERNEL_CLASSES)}
+
+
+def unpack_stats(vec, K, S):
+    """flat [K + K*S + K*S*S] -> the reference's stats dict (phylo_hmrf.py:311-314)."""
+    vec = np.asarray(vec, dtype=np.float64)
+    return {"post": vec[:K].copy(),
+            "obs": vec[K:K + K * S].reshape(K, S).copy(),
+            "obs*obs.T": vec[K + K * S:K + K * S + K * S * S].reshape(K, S, S).copy()}
+
+
+def pack_stats(stats):
+    return np.concatenate([np.ravel(stats["post"]), np.ravel(stats["obs"]), np.ravel(stats["obs*obs.T"])])

@@ -1,0 +1,822 @@
+// C ABI of libphmrf (include/phmrf.h): host-side orchestration around the gfx950 kernels.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "common.h"
+
+namespace phmrf {
+
+static thread_local std::string g_error;
+
+void set_error(const std::string& msg) { g_error = msg; }
+
+int fail(int status, const std::string& msg) {
+  g_error = msg;
+  return status;
+}
+
+void tic(phmrf_block* b) {
+  if (b->timing) (void)hipEventRecord(b->ev0, b->stream);
+}
+
+void toc(phmrf_block* b, int kclass, int n_launches) {
+  b->launches[kclass] += n_launches;
+  if (!b->timing) return;
+  (void)hipEventRecord(b->ev1, b->stream);
+  (void)hipEventSynchronize(b->ev1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
+  b->ms[kclass] += ms;
+}
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  return PHMRF_OK;
+}
+
+template <typename T>
+void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+int upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  PHMRF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+  PHMRF_HIP(hipStreamSynchronize(st));
+  return PHMRF_OK;
+}
+
+int download(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  PHMRF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+  PHMRF_HIP(hipStreamSynchronize(st));
+  return PHMRF_OK;
+}
+
+int zero_accum(phmrf_block* b, size_t first, size_t count) {
+  PHMRF_HIP(hipMemsetAsync(b->accum + first, 0, count * sizeof(double), b->stream));
+  return PHMRF_OK;
+}
+
+int n_stats(const phmrf_block* b) { return b->K * (1 + b->S + b->S * b->S); }
+
+void free_family(ChainFamily& f) {
+  dev_free(f.nodes);
+  for (int p = 0; p < 2; ++p)
+    for (int c = 0; c < 3; ++c) {
+      dev_free(f.seg_start[p][c]);
+      dev_free(f.seg_len[p][c]);
+    }
+}
+
+// (row, col) of node id under the block geometry
+struct Geometry {
+  int H, W, diagonal;
+  std::vector<int64_t> row_start;  // diagonal: first node id of each row
+  explicit Geometry(int H_, int W_, int diag) : H(H_), W(W_), diagonal(diag) {
+    if (diagonal) {
+      row_start.resize(H + 1);
+      int64_t s = 0;
+      for (int i = 0; i < H; ++i) {
+        row_start[i] = s;
+        s += W - i;
+      }
+      row_start[H] = s;
+    }
+  }
+  int64_t count() const { return diagonal ? row_start[H] : (int64_t)H * W; }
+  void coords(int64_t id, int* i, int* j) const {
+    if (!diagonal) {
+      *i = (int)(id / W);
+      *j = (int)(id % W);
+    } else {
+      int r = (int)(std::upper_bound(row_start.begin(), row_start.end(), id) - row_start.begin()) - 1;
+      *i = r;
+      *j = r + (int)(id - row_start[r]);
+    }
+  }
+  int64_t id(int i, int j) const { return diagonal ? row_start[i] + (j - i) : (int64_t)i * W + j; }
+  bool valid(int i, int j) const { return i >= 0 && i < H && j >= 0 && j < W && (!diagonal || i <= j); }
+};
+
+}  // namespace
+}  // namespace phmrf
+
+using namespace phmrf;
+
+extern "C" {
+
+// ---- library ------------------------------------------------------------------------------------
+int phmrf_version(void) { return 100; }
+
+const char* phmrf_last_error(void) { return g_error.c_str(); }
+
+const char* phmrf_status_string(int status) {
+  switch (status) {
+    case PHMRF_OK: return "ok";
+    case PHMRF_ERR_INVALID: return "invalid argument";
+    case PHMRF_ERR_HIP: return "HIP runtime error";
+    case PHMRF_ERR_NO_DEVICE: return "no GPU device";
+    case PHMRF_ERR_UNSUPPORTED: return "unsupported configuration";
+    case PHMRF_ERR_STATE: return "call order / missing input";
+    case PHMRF_ERR_NOT_PD: return "covariance not positive definite";
+  }
+  return "unknown status";
+}
+
+int phmrf_device_count(int* count) {
+  PHMRF_CHECK(count, PHMRF_ERR_INVALID, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(PHMRF_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = c;
+  return PHMRF_OK;
+}
+
+int phmrf_set_device(int device) {
+  PHMRF_HIP(hipSetDevice(device));
+  return PHMRF_OK;
+}
+
+// ---- block lifetime -----------------------------------------------------------------------------
+int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
+  PHMRF_CHECK(out, PHMRF_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  PHMRF_CHECK(n > 0 && n < ((int64_t)1 << 31) - 64, PHMRF_ERR_INVALID, "n must be in [1, 2^31)");
+  PHMRF_CHECK(S >= 1 && S <= 16, PHMRF_ERR_UNSUPPORTED, "S must be in [1,16]");
+  PHMRF_CHECK(K >= 1 && K <= 64, PHMRF_ERR_UNSUPPORTED, "K must be in [1,64]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PHMRF_ERR_NO_DEVICE, "no HIP device visible");
+  phmrf_block* b = new phmrf_block();
+  b->n = n;
+  b->S = S;
+  b->K = K;
+  int st = PHMRF_OK;
+  auto guard = [&](int s) {
+    if (s != PHMRF_OK && st == PHMRF_OK) st = s;
+  };
+  if (hipGetDevice(&b->device) != hipSuccess) guard(fail(PHMRF_ERR_HIP, "hipGetDevice failed"));
+  if (st == PHMRF_OK && hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess)
+    guard(fail(PHMRF_ERR_HIP, "hipStreamCreate failed"));
+  b->stream = b->own_stream;
+  if (st == PHMRF_OK) guard(dev_alloc(&b->X, (size_t)n * S));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->logprob, (size_t)n * K));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->labels, (size_t)n));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->labels_tmp, (size_t)n));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->accum, (size_t)ACCUM_DOUBLES));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->counters, (size_t)8));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->emis_params, (size_t)K * (S + S * (S + 1) / 2 + 1)));
+  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->accum_host), ACCUM_DOUBLES * sizeof(double)) != hipSuccess)
+    guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
+  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->counters_host), 8 * sizeof(unsigned long long)) != hipSuccess)
+    guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
+  if (st == PHMRF_OK && (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess))
+    guard(fail(PHMRF_ERR_HIP, "hipEventCreate failed"));
+  if (st == PHMRF_OK && hipMemsetAsync(b->labels, 0, (size_t)n, b->stream) != hipSuccess)
+    guard(fail(PHMRF_ERR_HIP, "hipMemset failed"));
+  if (st != PHMRF_OK) {
+    std::string keep = g_error;
+    phmrf_block_destroy(b);
+    g_error = keep;
+    return st;
+  }
+  *out = b;
+  return PHMRF_OK;
+}
+
+int phmrf_block_destroy(phmrf_block_t b) {
+  if (!b) return PHMRF_OK;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  dev_free(b->X);
+  dev_free(b->logprob);
+  dev_free(b->labels);
+  dev_free(b->labels_tmp);
+  for (int s = 0; s < 4; ++s) dev_free(b->saved[s]);
+  dev_free(b->nbr);
+  dev_free(b->wgt);
+  dev_free(b->colour_nodes);
+  for (auto& f : b->families) free_family(f);
+  dev_free(b->comp);
+  dev_free(b->comp_tab);
+  dev_free(b->comp_best);
+  dev_free(b->comp_gain);
+  dev_free(b->comp_move);
+  dev_free(b->emis_params);
+  dev_free(b->posteriors);
+  dev_free(b->accum);
+  dev_free(b->counters);
+  if (b->accum_host) (void)hipHostFree(b->accum_host);
+  if (b->counters_host) (void)hipHostFree(b->counters_host);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+  delete b;
+  return PHMRF_OK;
+}
+
+int phmrf_block_set_stream(phmrf_block_t b, void* hip_stream) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  b->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : b->own_stream;
+  return PHMRF_OK;
+}
+
+int phmrf_block_sync(phmrf_block_t b) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  return PHMRF_OK;
+}
+
+int phmrf_block_set_observations(phmrf_block_t b, const double* X) {
+  PHMRF_CHECK(b && X, PHMRF_ERR_INVALID, "NULL argument");
+  const size_t cnt = (size_t)b->n * b->S;
+  std::vector<float> tmp(cnt);
+  for (size_t i = 0; i < cnt; ++i) tmp[i] = (float)X[i];
+  PHMRF_TRY(upload(b->X, tmp.data(), cnt * sizeof(float), b->stream));
+  b->has_X = true;
+  return PHMRF_OK;
+}
+
+int phmrf_block_set_observations_dev(phmrf_block_t b, const float* X_dev) {
+  PHMRF_CHECK(b && X_dev, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_HIP(hipMemcpyAsync(b->X, X_dev, (size_t)b->n * b->S * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+  b->has_X = true;
+  return PHMRF_OK;
+}
+
+// ---- graph --------------------------------------------------------------------------------------
+int phmrf_block_set_graph(phmrf_block_t b, int64_t E, const int64_t* edges, const double* w) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(E >= 0 && (E == 0 || (edges && w)), PHMRF_ERR_INVALID, "edges / w is NULL");
+  const int64_t n = b->n;
+  std::vector<int32_t> deg(n, 0);
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t a = edges[2 * e], c = edges[2 * e + 1];
+    PHMRF_CHECK(a >= 0 && a < n && c >= 0 && c < n, PHMRF_ERR_INVALID, "edge endpoint out of range");
+    PHMRF_CHECK(a != c, PHMRF_ERR_INVALID, "self loop in edge list");
+    PHMRF_CHECK(w[e] >= 0.0 && std::isfinite(w[e]), PHMRF_ERR_INVALID, "edge weights must be finite and >= 0");
+    ++deg[a];
+    ++deg[c];
+  }
+  int maxdeg = 0;
+  for (int64_t i = 0; i < n; ++i) maxdeg = std::max(maxdeg, deg[i]);
+  PHMRF_CHECK(maxdeg <= 64, PHMRF_ERR_UNSUPPORTED, "node degree > 64 is not supported");
+  const int D = std::max(4, (maxdeg + 3) / 4 * 4);
+  std::vector<int32_t> nbr((size_t)n * D, -1);
+  std::vector<float> wgt((size_t)n * D, 0.f);
+  std::fill(deg.begin(), deg.end(), 0);
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t a = edges[2 * e], c = edges[2 * e + 1];
+    nbr[(size_t)a * D + deg[a]] = (int32_t)c;
+    wgt[(size_t)a * D + deg[a]++] = (float)w[e];
+    nbr[(size_t)c * D + deg[c]] = (int32_t)a;
+    wgt[(size_t)c * D + deg[c]++] = (float)w[e];
+  }
+  // neighbours ascending (deterministic summation order == oracle/mrf_moves.Graph); rows are short
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t* c = &nbr[(size_t)i * D];
+    float* ww = &wgt[(size_t)i * D];
+    for (int x = 1; x < deg[i]; ++x) {
+      const int32_t cv = c[x];
+      const float wv = ww[x];
+      int y = x - 1;
+      while (y >= 0 && c[y] > cv) {
+        c[y + 1] = c[y];
+        ww[y + 1] = ww[y];
+        --y;
+      }
+      c[y + 1] = cv;
+      ww[y + 1] = wv;
+    }
+    for (int x = 1; x < deg[i]; ++x)
+      PHMRF_CHECK(c[x] != c[x - 1], PHMRF_ERR_INVALID, "duplicate edge in edge list");
+  }
+  // greedy colouring in index order (replaced by the parity colouring when a grid is declared)
+  std::vector<int32_t> colour(n, -1);
+  int ncol = 0;
+  {
+    std::vector<int> mark(66, -1);
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t* c = &nbr[(size_t)i * D];
+      for (int x = 0; x < deg[i]; ++x)
+        if (colour[c[x]] >= 0) mark[colour[c[x]]] = (int)(i & 0x7fffffff);
+      int col = 0;
+      while (mark[col] == (int)(i & 0x7fffffff)) ++col;
+      colour[i] = col;
+      ncol = std::max(ncol, col + 1);
+    }
+  }
+  std::vector<int64_t> cptr(ncol + 1, 0);
+  for (int64_t i = 0; i < n; ++i) ++cptr[colour[i] + 1];
+  for (int c = 0; c < ncol; ++c) cptr[c + 1] += cptr[c];
+  std::vector<int32_t> cnodes(n);
+  {
+    std::vector<int64_t> pos(cptr.begin(), cptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) cnodes[pos[colour[i]]++] = (int32_t)i;
+  }
+  dev_free(b->nbr);
+  dev_free(b->wgt);
+  dev_free(b->colour_nodes);
+  PHMRF_TRY(dev_alloc(&b->nbr, (size_t)n * D));
+  PHMRF_TRY(dev_alloc(&b->wgt, (size_t)n * D));
+  PHMRF_TRY(dev_alloc(&b->colour_nodes, (size_t)n));
+  PHMRF_TRY(upload(b->nbr, nbr.data(), nbr.size() * sizeof(int32_t), b->stream));
+  PHMRF_TRY(upload(b->wgt, wgt.data(), wgt.size() * sizeof(float), b->stream));
+  PHMRF_TRY(upload(b->colour_nodes, cnodes.data(), cnodes.size() * sizeof(int32_t), b->stream));
+  b->D = D;
+  b->E = E;
+  b->n_colours = ncol;
+  b->colour_ptr = cptr;
+  b->has_graph = true;
+  b->has_grid = false;
+  for (auto& f : b->families) free_family(f);
+  b->families.clear();
+  return PHMRF_OK;
+}
+
+int phmrf_block_set_grid(phmrf_block_t b, int H, int W, int diagonal, int num_neighbor) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(b->has_graph, PHMRF_ERR_STATE, "set_graph must precede set_grid");
+  PHMRF_CHECK(H >= 1 && W >= 1, PHMRF_ERR_INVALID, "H, W must be >= 1");
+  PHMRF_CHECK(num_neighbor == 8 || num_neighbor == 4, PHMRF_ERR_INVALID, "num_neighbor must be 8 or 4");
+  PHMRF_CHECK(!diagonal || H == W, PHMRF_ERR_INVALID, "a diagonal block must be square");
+  Geometry g(H, W, diagonal);
+  PHMRF_CHECK(g.count() == b->n, PHMRF_ERR_INVALID, "H, W, diagonal do not match the node count");
+  const int64_t n = b->n;
+  const int D = b->D;
+  std::vector<int32_t> nbr((size_t)n * D);
+  std::vector<float> wgt((size_t)n * D);
+  PHMRF_TRY(download(nbr.data(), b->nbr, nbr.size() * sizeof(int32_t), b->stream));
+  PHMRF_TRY(download(wgt.data(), b->wgt, wgt.size() * sizeof(float), b->stream));
+  std::vector<int32_t> ci(n), cj(n);
+  for (int64_t v = 0; v < n; ++v) {
+    int i, j;
+    g.coords(v, &i, &j);
+    ci[v] = i;
+    cj[v] = j;
+  }
+  for (int64_t v = 0; v < n; ++v)
+    for (int x = 0; x < D; ++x) {
+      const int32_t u = nbr[(size_t)v * D + x];
+      if (u < 0) continue;
+      const int di = std::abs(ci[u] - ci[v]), dj = std::abs(cj[u] - cj[v]);
+      PHMRF_CHECK(di <= 1 && dj <= 1 && (di + dj) > 0, PHMRF_ERR_INVALID, "edge list joins nodes that are not grid neighbours");
+      PHMRF_CHECK(num_neighbor == 8 || (di + dj) == 1, PHMRF_ERR_INVALID, "diagonal edge in a 4-neighbour block");
+    }
+  // ICM colours: 2x2 parity classes (oracle/mrf_moves.icm_colours)
+  {
+    std::vector<int64_t> cptr(5, 0);
+    for (int64_t v = 0; v < n; ++v) ++cptr[(ci[v] % 2) * 2 + (cj[v] % 2) + 1];
+    for (int c = 0; c < 4; ++c) cptr[c + 1] += cptr[c];
+    std::vector<int64_t> pos(cptr.begin(), cptr.end() - 1);
+    std::vector<int32_t> cnodes(n);
+    for (int64_t v = 0; v < n; ++v) cnodes[pos[(ci[v] % 2) * 2 + (cj[v] % 2)]++] = (int32_t)v;
+    PHMRF_TRY(upload(b->colour_nodes, cnodes.data(), cnodes.size() * sizeof(int32_t), b->stream));
+    b->n_colours = 4;
+    b->colour_ptr = cptr;
+  }
+  // chain families: 0 rows, 1 columns, 2 diagonals (y-x), 3 anti-diagonals (x+y)
+  for (auto& f : b->families) free_family(f);
+  b->families.clear();
+  const int nfam = num_neighbor == 8 ? 4 : 2;
+  for (int fam = 0; fam < nfam; ++fam) {
+    // key_chain, key_pos per node
+    std::vector<int64_t> key(n);
+    int ncol = fam < 2 ? 2 : 3;
+    for (int64_t v = 0; v < n; ++v) {
+      int kc, kp;
+      switch (fam) {
+        case 0: kc = ci[v]; kp = cj[v]; break;
+        case 1: kc = cj[v]; kp = ci[v]; break;
+        case 2: kc = cj[v] - ci[v] + H; kp = ci[v]; break;   // +H keeps the key non-negative
+        default: kc = ci[v] + cj[v]; kp = ci[v]; break;
+      }
+      key[v] = ((int64_t)kc << 32) | (uint32_t)kp;
+    }
+    std::vector<int32_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t c) { return key[a] < key[c]; });
+    std::vector<int32_t> chain_ptr;
+    std::vector<int> chain_colour;
+    int max_len = 0;
+    for (int64_t p = 0; p < n; ++p) {
+      const int64_t kc = key[order[p]] >> 32;
+      if (p == 0 || kc != (key[order[p - 1]] >> 32)) {
+        chain_ptr.push_back((int32_t)p);
+        int raw = (int)kc;
+        if (fam == 2) raw -= H;  // colour by (y - x) mod 3 like the oracle (python % is non-negative)
+        chain_colour.push_back(((raw % ncol) + ncol) % ncol);
+      }
+    }
+    chain_ptr.push_back((int32_t)n);
+    const int C = (int)chain_ptr.size() - 1;
+    for (int c = 0; c < C; ++c) max_len = std::max(max_len, chain_ptr[c + 1] - chain_ptr[c]);
+    ChainFamily f;
+    f.n_chains = C;
+    f.n_colours = ncol;
+    f.max_len = max_len;
+    PHMRF_TRY(dev_alloc(&f.nodes, (size_t)n));
+    PHMRF_TRY(upload(f.nodes, order.data(), (size_t)n * sizeof(int32_t), b->stream));
+    for (int phase = 0; phase < 2; ++phase)
+      for (int col = 0; col < ncol; ++col) {
+        std::vector<int32_t> ss, sl;
+        for (int c = 0; c < C; ++c) {
+          if (chain_colour[c] != col) continue;
+          const int32_t p0 = chain_ptr[c], L = chain_ptr[c + 1] - chain_ptr[c];
+          // separators (fixed nodes) sit at chain positions 63, 127, ... (phase 0) or 31, 95, ... (phase 1)
+          int32_t start = 0;
+          int32_t sep = phase ? 31 : 63;
+          while (start < L) {
+            const int32_t end = std::min<int32_t>(sep, L);
+            if (end > start) {
+              ss.push_back(p0 + start);
+              sl.push_back(end - start);
+            }
+            start = sep + 1;
+            sep += 64;
+          }
+        }
+        f.nseg[phase][col] = (int)ss.size();
+        PHMRF_TRY(dev_alloc(&f.seg_start[phase][col], ss.size()));
+        PHMRF_TRY(dev_alloc(&f.seg_len[phase][col], sl.size()));
+        if (!ss.empty()) {
+          PHMRF_TRY(upload(f.seg_start[phase][col], ss.data(), ss.size() * sizeof(int32_t), b->stream));
+          PHMRF_TRY(upload(f.seg_len[phase][col], sl.data(), sl.size() * sizeof(int32_t), b->stream));
+        }
+      }
+    b->families.push_back(f);
+  }
+  b->H = H;
+  b->W = W;
+  b->diagonal = diagonal;
+  b->num_neighbor = num_neighbor;
+  b->has_grid = true;
+  return PHMRF_OK;
+}
+
+// ---- labels -------------------------------------------------------------------------------------
+int phmrf_block_set_labels(phmrf_block_t b, const int32_t* labels) {
+  PHMRF_CHECK(b && labels, PHMRF_ERR_INVALID, "NULL argument");
+  std::vector<uint8_t> tmp(b->n);
+  for (int64_t i = 0; i < b->n; ++i) {
+    PHMRF_CHECK(labels[i] >= 0 && labels[i] < b->K, PHMRF_ERR_INVALID, "label out of range [0,K)");
+    tmp[i] = (uint8_t)labels[i];
+  }
+  PHMRF_TRY(upload(b->labels, tmp.data(), (size_t)b->n, b->stream));
+  b->has_labels = true;
+  return PHMRF_OK;
+}
+
+static int fetch_labels(phmrf_block_t b, const uint8_t* src, int32_t* labels) {
+  std::vector<uint8_t> tmp(b->n);
+  PHMRF_TRY(download(tmp.data(), src, (size_t)b->n, b->stream));
+  for (int64_t i = 0; i < b->n; ++i) labels[i] = tmp[i];
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_labels(phmrf_block_t b, int32_t* labels) {
+  PHMRF_CHECK(b && labels, PHMRF_ERR_INVALID, "NULL argument");
+  return fetch_labels(b, b->labels, labels);
+}
+
+int phmrf_block_save_labels(phmrf_block_t b, int slot) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(slot >= 0 && slot < 4, PHMRF_ERR_INVALID, "slot must be in [0,4)");
+  if (!b->saved[slot]) PHMRF_TRY(dev_alloc(&b->saved[slot], (size_t)b->n));
+  PHMRF_HIP(hipMemcpyAsync(b->saved[slot], b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
+  return PHMRF_OK;
+}
+
+int phmrf_block_restore_labels(phmrf_block_t b, int slot) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(slot >= 0 && slot < 4 && b->saved[slot], PHMRF_ERR_STATE, "label slot is empty");
+  PHMRF_HIP(hipMemcpyAsync(b->labels, b->saved[slot], (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
+  b->has_labels = true;
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_saved_labels(phmrf_block_t b, int slot, int32_t* labels) {
+  PHMRF_CHECK(b && labels, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(slot >= 0 && slot < 4 && b->saved[slot], PHMRF_ERR_STATE, "label slot is empty");
+  return fetch_labels(b, b->saved[slot], labels);
+}
+
+// ---- b1 emission --------------------------------------------------------------------------------
+int phmrf_emission_pack_size(int S, int K, int64_t* n_floats) {
+  PHMRF_CHECK(n_floats && S >= 1 && S <= 16 && K >= 1, PHMRF_ERR_INVALID, "bad S/K");
+  *n_floats = (int64_t)K * (S + S * (S + 1) / 2 + 1);
+  return PHMRF_OK;
+}
+
+int phmrf_emission_pack(int S, int K, const double* means, const double* covars, float* packed) {
+  PHMRF_CHECK(means && covars && packed, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(S >= 1 && S <= 16 && K >= 1, PHMRF_ERR_INVALID, "bad S/K");
+  const int PS = S + S * (S + 1) / 2 + 1;
+  std::vector<double> L(S * S), Li(S * S);
+  for (int k = 0; k < K; ++k) {
+    const double* cv = covars + (size_t)k * S * S;
+    bool ok = false;
+    for (int attempt = 0; attempt < 2 && !ok; ++attempt) {  // sklearn 0.18: retry once with +1e-7*I
+      const double jitter = attempt ? 1e-7 : 0.0;
+      ok = true;
+      std::fill(L.begin(), L.end(), 0.0);
+      for (int i = 0; i < S && ok; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double s = cv[i * S + j] + (i == j ? jitter : 0.0);
+          for (int t = 0; t < j; ++t) s -= L[i * S + t] * L[j * S + t];
+          if (i == j) {
+            if (!(s > 0.0) || !std::isfinite(s)) { ok = false; break; }
+            L[i * S + i] = std::sqrt(s);
+          } else {
+            L[i * S + j] = s / L[j * S + j];
+          }
+        }
+    }
+    if (!ok) return fail(PHMRF_ERR_NOT_PD, "'covars' must be symmetric, positive-definite (state " + std::to_string(k) + ")");
+    // Li = L^-1 (lower) by forward substitution; logdet = 2 sum log diag(L)
+    std::fill(Li.begin(), Li.end(), 0.0);
+    double logdet = 0.0;
+    for (int i = 0; i < S; ++i) logdet += 2.0 * std::log(L[i * S + i]);
+    for (int c = 0; c < S; ++c)
+      for (int i = c; i < S; ++i) {
+        double s = (i == c) ? 1.0 : 0.0;
+        for (int t = c; t < i; ++t) s -= L[i * S + t] * Li[t * S + c];
+        Li[i * S + c] = s / L[i * S + i];
+      }
+    float* p = packed + (size_t)k * PS;
+    for (int s = 0; s < S; ++s) p[s] = (float)means[(size_t)k * S + s];
+    int idx = S;
+    for (int i = 0; i < S; ++i)
+      for (int c = 0; c <= i; ++c) p[idx++] = (float)Li[i * S + c];
+    p[idx] = (float)(-0.5 * (S * std::log(2.0 * M_PI) + logdet));
+  }
+  return PHMRF_OK;
+}
+
+int phmrf_emission_dev(const float* X_dev, int64_t n, int S, int K, const float* packed_dev, float* logprob_dev,
+                       void* hip_stream) {
+  PHMRF_CHECK(X_dev && packed_dev && logprob_dev, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(n > 0 && K >= 1 && K <= 64, PHMRF_ERR_INVALID, "bad n/K");
+  return launch_emission(X_dev, n, S, K, packed_dev, logprob_dev, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int phmrf_emission(phmrf_block_t b, const double* means, const double* covars) {
+  PHMRF_CHECK(b && means && covars, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(b->has_X, PHMRF_ERR_STATE, "observations not set");
+  const int PS = b->S + b->S * (b->S + 1) / 2 + 1;
+  std::vector<float> packed((size_t)b->K * PS);
+  PHMRF_TRY(phmrf_emission_pack(b->S, b->K, means, covars, packed.data()));
+  PHMRF_TRY(upload(b->emis_params, packed.data(), packed.size() * sizeof(float), b->stream));
+  tic(b);
+  PHMRF_TRY(launch_emission(b->X, b->n, b->S, b->K, b->emis_params, b->logprob, b->stream));
+  toc(b, KC_EMISSION, 1);
+  b->has_logprob = true;
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_logprob(phmrf_block_t b, double* logprob) {
+  PHMRF_CHECK(b && logprob, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(b->has_logprob, PHMRF_ERR_STATE, "logprob not computed");
+  const size_t cnt = (size_t)b->n * b->K;
+  std::vector<float> tmp(cnt);
+  PHMRF_TRY(download(tmp.data(), b->logprob, cnt * sizeof(float), b->stream));
+  for (size_t i = 0; i < cnt; ++i) logprob[i] = tmp[i];
+  return PHMRF_OK;
+}
+
+int phmrf_block_set_logprob(phmrf_block_t b, const double* logprob) {
+  PHMRF_CHECK(b && logprob, PHMRF_ERR_INVALID, "NULL argument");
+  const size_t cnt = (size_t)b->n * b->K;
+  std::vector<float> tmp(cnt);
+  for (size_t i = 0; i < cnt; ++i) tmp[i] = (float)logprob[i];
+  PHMRF_TRY(upload(b->logprob, tmp.data(), cnt * sizeof(float), b->stream));
+  b->has_logprob = true;
+  return PHMRF_OK;
+}
+
+// ---- b2 MRF -------------------------------------------------------------------------------------
+static int read_counter(phmrf_block_t b, int64_t* v) {
+  PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  *v = (int64_t)b->counters_host[0];
+  return PHMRF_OK;
+}
+
+static int zero_counter(phmrf_block_t b) {
+  PHMRF_HIP(hipMemsetAsync(b->counters, 0, 8 * sizeof(unsigned long long), b->stream));
+  return PHMRF_OK;
+}
+
+static int check_solvable(phmrf_block_t b) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(b->has_graph, PHMRF_ERR_STATE, "graph not set");
+  PHMRF_CHECK(b->has_logprob, PHMRF_ERR_STATE, "logprob not set (run phmrf_emission or phmrf_block_set_logprob)");
+  return PHMRF_OK;
+}
+
+static int icm_sweep_nocount(phmrf_block_t b, float beta) {
+  tic(b);
+  for (int c = 0; c < b->n_colours; ++c) PHMRF_TRY(launch_icm_colour(b, beta, c));
+  toc(b, KC_ICM, b->n_colours);
+  return PHMRF_OK;
+}
+
+static int chain_sweep_nocount(phmrf_block_t b, float beta, int family, int phase) {
+  const ChainFamily& f = b->families[family];
+  tic(b);
+  for (int c = 0; c < f.n_colours; ++c) PHMRF_TRY(launch_chain_colour(b, beta, family, c, phase));
+  toc(b, KC_CHAIN, f.n_colours);
+  return PHMRF_OK;
+}
+
+static int energy_now(phmrf_block_t b, double beta, double* eu, double* ep) {
+  PHMRF_TRY(zero_accum(b, 4, 2));
+  tic(b);
+  PHMRF_TRY(launch_energy(b, (float)beta));
+  toc(b, KC_ENERGY, 1);
+  PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  *eu = b->accum_host[4];
+  *ep = beta * b->accum_host[5];
+  return PHMRF_OK;
+}
+
+int phmrf_mrf_energy(phmrf_block_t b, double beta, double* e_total, double* e_unary, double* e_pair) {
+  PHMRF_TRY(check_solvable(b));
+  double eu, ep;
+  PHMRF_TRY(energy_now(b, beta, &eu, &ep));
+  if (e_total) *e_total = eu + ep;
+  if (e_unary) *e_unary = eu;
+  if (e_pair) *e_pair = ep;
+  return PHMRF_OK;
+}
+
+int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_TRY(zero_counter(b));
+  PHMRF_TRY(icm_sweep_nocount(b, (float)beta));
+  int64_t ch = 0;
+  PHMRF_TRY(read_counter(b, &ch));
+  if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
+int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* changed) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "chain moves need phmrf_block_set_grid");
+  PHMRF_CHECK(family >= 0 && family < (int)b->families.size(), PHMRF_ERR_INVALID, "no such chain family");
+  PHMRF_TRY(zero_counter(b));
+  PHMRF_TRY(chain_sweep_nocount(b, (float)beta, family, 0));
+  PHMRF_TRY(chain_sweep_nocount(b, (float)beta, family, 1));
+  int64_t ch = 0;
+  PHMRF_TRY(read_counter(b, &ch));
+  if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
+int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_TRY(zero_counter(b));
+  tic(b);
+  PHMRF_TRY(launch_component_pass(b, (float)beta));
+  toc(b, KC_COMPONENT, 1);
+  int64_t ch = 0;
+  PHMRF_TRY(read_counter(b, &ch));
+  if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
+int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res) {
+  PHMRF_TRY(check_solvable(b));
+  phmrf_solve_opts o;
+  std::memset(&o, 0, sizeof(o));
+  o.max_rounds = 64;
+  o.use_chains = 1;
+  o.use_components = 1;
+  if (opts) {
+    o = *opts;
+    if (o.max_rounds <= 0) o.max_rounds = 64;
+  }
+  const float bf = (float)beta;
+  if (o.init_mode == 1) {
+    PHMRF_TRY(launch_argmax_labels(b));
+    b->has_labels = true;
+  }
+  double eu0 = 0, ep0 = 0;
+  if (res) PHMRF_TRY(energy_now(b, beta, &eu0, &ep0));
+  int64_t total = 0;
+  int rounds = 0, converged = 0;
+  const bool chains = o.use_chains && b->has_grid;
+  for (int r = 0; r < o.max_rounds; ++r) {
+    PHMRF_TRY(zero_counter(b));
+    if (chains)
+      for (int f = 0; f < (int)b->families.size(); ++f) PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1));
+    PHMRF_TRY(icm_sweep_nocount(b, bf));
+    if (o.use_components) {
+      tic(b);
+      PHMRF_TRY(launch_component_pass(b, bf));
+      toc(b, KC_COMPONENT, 1);
+    }
+    int64_t ch = 0;
+    PHMRF_TRY(read_counter(b, &ch));
+    total += ch;
+    ++rounds;
+    if (ch == 0) {
+      converged = 1;
+      break;
+    }
+  }
+  b->has_labels = true;
+  if (res) {
+    double eu = 0, ep = 0;
+    PHMRF_TRY(energy_now(b, beta, &eu, &ep));
+    res->energy = eu + ep;
+    res->energy_unary = eu;
+    res->energy_pair = ep;
+    res->energy_init = eu0 + ep0;
+    res->rounds = rounds;
+    res->converged = converged;
+    res->changed = total;
+  }
+  return PHMRF_OK;
+}
+
+// ---- b3 posterior / stats -----------------------------------------------------------------------
+static int posterior_launch(phmrf_block_t b, double beta, int estimate_type, bool write_post) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(b->has_X, PHMRF_ERR_STATE, "observations not set");
+  const int ns = n_stats(b);
+  PHMRF_CHECK(8 + ns <= ACCUM_DOUBLES, PHMRF_ERR_UNSUPPORTED, "K*(1+S+S*S) too large");
+  if (write_post && !b->posteriors) PHMRF_TRY(dev_alloc(&b->posteriors, (size_t)b->n * b->K));
+  PHMRF_TRY(zero_accum(b, 0, 4));
+  PHMRF_TRY(zero_accum(b, 8, ns));
+  tic(b);
+  PHMRF_TRY(launch_posterior_stats(b, (float)beta, estimate_type, write_post));
+  toc(b, KC_POSTERIOR, 1);
+  return PHMRF_OK;
+}
+
+int phmrf_posterior_stats(phmrf_block_t b, double beta, int estimate_type, double* stats_out, double* costs_out,
+                          double* posteriors_out) {
+  PHMRF_CHECK(b && stats_out && costs_out, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_TRY(posterior_launch(b, beta, estimate_type, posteriors_out != nullptr));
+  const int ns = n_stats(b);
+  PHMRF_HIP(hipMemcpyAsync(b->accum_host, b->accum, (8 + ns) * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  std::memcpy(costs_out, b->accum_host, 4 * sizeof(double));
+  std::memcpy(stats_out, b->accum_host + 8, ns * sizeof(double));
+  if (posteriors_out) {
+    const size_t cnt = (size_t)b->n * b->K;
+    std::vector<float> tmp(cnt);
+    PHMRF_TRY(download(tmp.data(), b->posteriors, cnt * sizeof(float), b->stream));
+    for (size_t i = 0; i < cnt; ++i) posteriors_out[i] = tmp[i];
+  }
+  return PHMRF_OK;
+}
+
+int phmrf_posterior_stats_dev(phmrf_block_t b, double beta, int estimate_type, double* out_dev) {
+  PHMRF_CHECK(b && out_dev, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_TRY(posterior_launch(b, beta, estimate_type, false));
+  const int ns = n_stats(b);
+  PHMRF_HIP(hipMemcpyAsync(out_dev, b->accum + 8, ns * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+  PHMRF_HIP(hipMemcpyAsync(out_dev + ns, b->accum, 4 * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+  return PHMRF_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------
+int phmrf_block_enable_timing(phmrf_block_t b, int enable) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  b->timing = enable != 0;
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_timing(phmrf_block_t b, double* ms, int64_t* launches) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES; ++i) {
+    if (ms) ms[i] = b->ms[i];
+    if (launches) launches[i] = b->launches[i];
+  }
+  return PHMRF_OK;
+}
+
+int phmrf_block_reset_timing(phmrf_block_t b) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES; ++i) {
+    b->ms[i] = 0;
+    b->launches[i] = 0;
+  }
+  return PHMRF_OK;
+}
+
+}  // extern "C"

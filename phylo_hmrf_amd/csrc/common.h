@@ -1,0 +1,130 @@
+// Shared declarations of libphmrf (gfx950 only; no portability layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/phmrf.h"
+
+namespace phmrf {
+
+// ---- error plumbing: status int + thread-local message, nothing throws across the C ABI ---------
+void set_error(const std::string& msg);
+int fail(int status, const std::string& msg);
+
+#define PHMRF_HIP(expr)                                                                     \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return ::phmrf::fail(PHMRF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define PHMRF_CHECK(cond, status, msg) \
+  do {                                 \
+    if (!(cond)) return ::phmrf::fail((status), (msg)); \
+  } while (0)
+
+#define PHMRF_TRY(expr)          \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != PHMRF_OK) return _s; \
+  } while (0)
+
+// ---- kernel classes for the built-in timers (phmrf.h) -------------------------------------------
+enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5 };
+
+// A chain family (grid rows / columns / diagonals / anti-diagonals): `nodes` lists node ids chain after
+// chain in chain order.  Chains of one colour share no edge.  Every chain is cut into SEGMENTS of at most
+// 63 consecutive nodes separated by single nodes that stay fixed during the sweep (so simultaneous segment
+// moves never share an edge); two phases shift the cut points by 32 so every node gets optimised.
+struct ChainFamily {
+  int32_t* nodes = nullptr;            // device [n]
+  int32_t* seg_start[2][3] = {};       // device [nseg]: position in `nodes` of the segment's first node
+  int32_t* seg_len[2][3] = {};         // device [nseg]: 1..63
+  int nseg[2][3] = {};
+  int n_chains = 0;
+  int n_colours = 0;
+  int max_len = 0;
+};
+
+}  // namespace phmrf
+
+// One syntenic block resident on one GPU.  Layout in HBM (all row-major, contiguous):
+//   X        f32 [n, S]        observations (species contact vectors)
+//   logprob  f32 [n, K]        emission log-likelihoods (unary cost = -logprob)
+//   labels   u8  [n]           current labelling
+//   nbr      i32 [n, D]        ELL adjacency, neighbours ascending, -1 padded; D = max degree rounded up to 4
+//   wgt      f32 [n, D]        edge weights w_ij (0 in padding)
+struct phmrf_block {
+  int64_t n = 0;
+  int S = 0, K = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+
+  float* X = nullptr;
+  float* logprob = nullptr;
+  uint8_t* labels = nullptr;
+  uint8_t* labels_tmp = nullptr;
+  uint8_t* saved[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool has_X = false, has_logprob = false, has_labels = false, has_graph = false, has_grid = false;
+
+  int D = 0;
+  int64_t E = 0;
+  int32_t* nbr = nullptr;
+  float* wgt = nullptr;
+
+  // ICM colour classes: node ids grouped by colour
+  int n_colours = 0;
+  int32_t* colour_nodes = nullptr;          // device [n]
+  std::vector<int64_t> colour_ptr;          // host [n_colours+1]
+
+  // grid geometry (optional) and chain families
+  int H = 0, W = 0, diagonal = 0, num_neighbor = 0;
+  std::vector<phmrf::ChainFamily> families;
+
+  // component-move scratch
+  int32_t* comp = nullptr;                  // device [n] component root per node
+  float* comp_tab = nullptr;                // device [n, K] per-root sums
+  int32_t* comp_best = nullptr;             // device [n]
+  float* comp_gain = nullptr;               // device [n]
+  uint8_t* comp_move = nullptr;             // device [n]
+
+  float* emis_params = nullptr;             // device packed emission parameters
+  float* posteriors = nullptr;              // device [n, K], allocated on demand
+  double* accum = nullptr;                  // device small f64 accumulator area
+  double* accum_host = nullptr;             // pinned mirror
+  unsigned long long* counters = nullptr;   // device [8]
+  unsigned long long* counters_host = nullptr;
+
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double ms[PHMRF_NUM_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+  int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace phmrf {
+
+constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every supported (K,S)
+
+// RAII-free helpers for the timers: call tic before the launches of one class, toc after.
+void tic(phmrf_block* b);
+void toc(phmrf_block* b, int kclass, int n_launches);
+
+inline int tile_threads(int K) { return K <= 40 ? 256 : 128; }
+inline int padded_k(int K) { return (K % 2 == 0) ? K + 1 : K; }  // odd LDS row stride: conflict-free row-per-lane access
+
+// kernels (defined in the .hip files) -------------------------------------------------------------
+int launch_emission(const float* X, int64_t n, int S, int K, const float* packed, float* logprob, hipStream_t st);
+int launch_argmax_labels(const phmrf_block* b);
+int launch_icm_colour(const phmrf_block* b, float beta, int colour);
+int launch_energy(const phmrf_block* b, float beta);  // -> accum[0]=unary, accum[1]=pair (caller zeroes)
+int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors);
+int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase);
+int launch_component_pass(phmrf_block* b, float beta);  // adds relabelled nodes to counters[0]
+
+}  // namespace phmrf

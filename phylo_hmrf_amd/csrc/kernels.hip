@@ -1,0 +1,525 @@
+// gfx950 kernels of the E-step: emission, argmax init, colour-ordered ICM, energy, posterior + statistics.
+//
+// Common shape ("node tile"): a workgroup of TB threads owns TB nodes.  The K-wide row of each node
+// (logprob[i, 0:K]) is brought into LDS with coalesced 16-byte loads (K/4 lanes per row), laid out
+// with an ODD row stride Kp so that "lane r reads word k of row r" is bank-conflict free; afterwards
+// each lane works on its own node with plain dynamic LDS indexing (neighbour-label histogram,
+// argmin / softmax over k).  All of these kernels are HBM-bound (<= 20 flop/B); no MFMA.
+
+#include "common.h"
+
+namespace phmrf {
+
+namespace {
+
+constexpr int ACC_COST = 0;    // accum[0..3]  cost numerators
+constexpr int ACC_ENERGY = 4;  // accum[4..5]  unary, pair
+constexpr int ACC_STATS = 8;   // accum[8..]   post | obs | obs*obs.T
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over the workgroup, result valid in thread 0.  red: LDS scratch of >= 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];
+  }
+  return t;
+}
+
+// Cooperative load of `rows` K-wide rows into the LDS tile: tile[r*Kp + c] = scale * src_row(r)[c] + add*tile.
+// VEC floats per lane per access (VEC | K): consecutive lanes read consecutive 4*VEC-byte pieces of a row.
+template <int VEC, bool ACCUM>
+__device__ __forceinline__ void rows_to_tile(const float* __restrict__ mat, const int32_t* __restrict__ nodes,
+                                             int64_t base, int rows, int K, int Kp, float* tile, float scale,
+                                             float tile_scale) {
+  const int KV = K / VEC;
+  const int total = rows * KV;
+  for (int q = threadIdx.x; q < total; q += blockDim.x) {
+    const int r = q / KV;
+    const int c = (q - r * KV) * VEC;
+    const int64_t node = nodes ? (int64_t)nodes[base + r] : base + r;
+    const float* src = mat + node * K + c;
+    float v[VEC];
+    if (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(src);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if (VEC == 2) {
+      const float2 t = *reinterpret_cast<const float2*>(src);
+      v[0] = t.x; v[1] = t.y;
+    } else {
+      v[0] = src[0];
+    }
+    float* dst = tile + r * Kp + c;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dst[j] = ACCUM ? fmaf(tile_scale, dst[j], scale * v[j]) : scale * v[j];
+  }
+}
+
+// Cooperative store of a contiguous [rows, K] chunk from the LDS tile.
+template <int VEC>
+__device__ __forceinline__ void tile_to_rows(float* __restrict__ out, int rows, int K, int Kp, const float* tile) {
+  const int KV = K / VEC;
+  const int total = rows * KV;
+  for (int q = threadIdx.x; q < total; q += blockDim.x) {
+    const int r = q / KV;
+    const int c = (q - r * KV) * VEC;
+    const float* s = tile + r * Kp + c;
+    float* d = out + (int64_t)r * K + c;
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(d) = make_float4(s[0], s[1], s[2], s[3]);
+    } else if (VEC == 2) {
+      *reinterpret_cast<float2*>(d) = make_float2(s[0], s[1]);
+    } else {
+      d[0] = s[0];
+    }
+  }
+}
+
+inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
+
+inline int grid_for(int64_t work_items, int tb, int max_blocks = 256 * 16) {
+  int64_t g = (work_items + tb - 1) / tb;
+  if (g > max_blocks) g = max_blocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// -------------------------------------------------------------------------------------------------
+// b1 emission: logprob[i,k] = c_k - 0.5 * || Linv_k (x_i - mu_k) ||^2
+// (phylo_hmrf.py:266-268; sklearn-0.18 log_multivariate_normal_density 'full': Cholesky + triangular solve.
+//  The solve is replaced by a product with the host-inverted factor, S(S+1)/2 FMAs per state.)
+// packed per state: mu[S] | Linv lower triangle row-major [S(S+1)/2] | c
+// -------------------------------------------------------------------------------------------------
+template <int S, int VEC>
+__global__ __launch_bounds__(256) void emission_kernel(const float* __restrict__ X, int64_t n, int K, int Kp,
+                                                       const float* __restrict__ P, float* __restrict__ out) {
+  extern __shared__ float tile[];
+  constexpr int PS = S + S * (S + 1) / 2 + 1;
+  const int TB = blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t i = base + threadIdx.x;
+    if (i < n) {
+      float x[S];
+      if (S % 4 == 0) {
+#pragma unroll
+        for (int s = 0; s < S; s += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(X + i * S + s);
+          x[s] = t.x; x[s + 1] = t.y; x[s + 2] = t.z; x[s + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < S; ++s) x[s] = X[i * S + s];
+      }
+      float* row = tile + threadIdx.x * Kp;
+      for (int k = 0; k < K; ++k) {
+        const float* p = P + k * PS;  // wave-uniform address: scalar loads
+        float d[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) d[s] = x[s] - p[s];
+        float q = 0.f;
+        int idx = S;
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+          float y = 0.f;
+#pragma unroll
+          for (int c = 0; c <= r; ++c) y = fmaf(p[idx++], d[c], y);
+          q = fmaf(y, y, q);
+        }
+        row[k] = fmaf(-0.5f, q, p[idx]);
+      }
+    }
+    __syncthreads();
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    tile_to_rows<VEC>(out + base * K, rows, K, Kp, tile);
+    __syncthreads();
+  }
+}
+
+template <int S>
+int launch_emission_s(const float* X, int64_t n, int K, const float* packed, float* logprob, hipStream_t st) {
+  const int TB = tile_threads(K), Kp = padded_k(K);
+  const size_t lds = (size_t)TB * Kp * sizeof(float);
+  const int grid = grid_for(n, TB);
+  switch (vec_of(K)) {
+    case 4: hipLaunchKernelGGL((emission_kernel<S, 4>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob); break;
+    case 2: hipLaunchKernelGGL((emission_kernel<S, 2>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob); break;
+    default: hipLaunchKernelGGL((emission_kernel<S, 1>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob); break;
+  }
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// argmax_k logprob -> labels (init_mode 1)
+// -------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp,
+                                                     uint8_t* __restrict__ labels) {
+  extern __shared__ float tile[];
+  const int TB = blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    rows_to_tile<VEC, false>(logprob, nullptr, base, rows, K, Kp, tile, 1.f, 0.f);
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+      const float* row = tile + threadIdx.x * Kp;
+      float best = row[0];
+      int bk = 0;
+      for (int k = 1; k < K; ++k) {
+        const float v = row[k];
+        if (v > best) { best = v; bk = k; }
+      }
+      labels[base + threadIdx.x] = (uint8_t)bk;
+    }
+    __syncthreads();
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// ICM, one colour class: every node of the class minimises
+//     cost_k = -logprob[i,k] - beta * sum_{j in N(i), l_j == k} w_ij      (+ const)
+// over k, neighbours fixed (no two nodes of a class are adjacent).  Strict improvement only; lowest
+// label wins ties (same rule as oracle/mrf_moves.icm_sweep).
+// -------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void icm_kernel(const float* __restrict__ logprob, const int32_t* __restrict__ nodes,
+                                                  int64_t count, int K, int Kp, int D,
+                                                  const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
+                                                  uint8_t* __restrict__ labels, float beta,
+                                                  unsigned long long* __restrict__ changed) {
+  extern __shared__ float tile[];
+  const int TB = blockDim.x;
+  unsigned int my_changed = 0;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < count; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = count - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    rows_to_tile<VEC, false>(logprob, nodes, base, rows, K, Kp, tile, -1.f, 0.f);
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+      const int64_t node = nodes ? (int64_t)nodes[base + threadIdx.x] : base + threadIdx.x;
+      float* row = tile + threadIdx.x * Kp;
+      const int32_t* nb = nbr + node * D;
+      const float* wg = wgt + node * D;
+      for (int j = 0; j < D; j += 4) {
+        const int4 c = *reinterpret_cast<const int4*>(nb + j);
+        const float4 w = *reinterpret_cast<const float4*>(wg + j);
+        if (c.x >= 0) row[labels[c.x]] -= beta * w.x;
+        if (c.y >= 0) row[labels[c.y]] -= beta * w.y;
+        if (c.z >= 0) row[labels[c.z]] -= beta * w.z;
+        if (c.w >= 0) row[labels[c.w]] -= beta * w.w;
+      }
+      const int cur = labels[node];
+      float best = row[cur];
+      int bk = cur;
+      for (int k = 0; k < K; ++k) {
+        const float v = row[k];
+        if (v < best) { best = v; bk = k; }
+      }
+      if (bk != cur) {
+        labels[node] = (uint8_t)bk;
+        ++my_changed;
+      }
+    }
+    __syncthreads();
+  }
+  // one atomic per wave
+  unsigned int s = my_changed;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(changed, (unsigned long long)s);
+}
+
+// -------------------------------------------------------------------------------------------------
+// a-E energy: unary = sum_i -logprob[i,l_i];  pair = 0.5 * sum_i sum_{j in N(i)} w_ij [l_i != l_j]
+// (beta applied by the host).  f64 accumulation.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ logprob, int64_t n, int K, int D,
+                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
+                                                     const uint8_t* __restrict__ labels, double* __restrict__ accum) {
+  __shared__ double red[8];
+  double eu = 0.0, ep = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = labels[i];
+    eu -= (double)logprob[i * K + l];
+    const int32_t* nb = nbr + i * D;
+    const float* wg = wgt + i * D;
+    float s = 0.f;
+    for (int j = 0; j < D; j += 4) {
+      const int4 c = *reinterpret_cast<const int4*>(nb + j);
+      const float4 w = *reinterpret_cast<const float4*>(wg + j);
+      if (c.x >= 0 && labels[c.x] != l) s += w.x;
+      if (c.y >= 0 && labels[c.y] != l) s += w.y;
+      if (c.z >= 0 && labels[c.z] != l) s += w.z;
+      if (c.w >= 0 && labels[c.w] != l) s += w.w;
+    }
+    ep += (double)s;
+  }
+  const double tu = block_sum(eu, red);
+  const double tp = block_sum(ep, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(accum + ACC_ENERGY, tu);
+    atomicAdd(accum + ACC_ENERGY + 1, 0.5 * tp);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// b3 posteriors + costs + sufficient statistics, fused (phylo_hmrf.py:334-355, :374-396, :311-314).
+//   pp[i,k]   = beta * sum_{e in inc(i)} w'_e [l_other != k]          (w' = w if estimate_type==3 else 1)
+//             = beta * (Wtot' - h[i,k]);   isolated node: beta*[k != l_i]            (:421-423)
+//   post[i,k] = softmax_k(logprob - pp)   (max-shifted; the reference does not shift, :342-345)
+//   ppn[i,k]  = softmax_k(-pp)
+//   costs     : see phmrf.h
+//   stats     : post | obs | obs*obs.T = Gamma^T [1 | x | x (x) x], accumulated in f64 across tiles,
+//               one atomic flush per workgroup at the end (grid is capped, blocks stride over tiles)
+// -------------------------------------------------------------------------------------------------
+constexpr int MAXO = 18;  // outputs per thread; needs K*(1+S+S*S) <= MAXO*TB
+
+template <int S, int VEC, bool WRITE_POST>
+__global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ X, const float* __restrict__ logprob,
+                                                        int64_t n, int K, int Kp, int D,
+                                                        const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
+                                                        const uint8_t* __restrict__ labels, float beta, int use_w,
+                                                        float* __restrict__ post_out, double* __restrict__ accum) {
+  extern __shared__ float lds[];
+  constexpr int M = 1 + S + S * S;
+  constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
+  const int TB = blockDim.x;
+  float* tile = lds;            // [TB][Kp]
+  float* feat = lds + TB * Kp;  // [TB][Mp]
+  __shared__ double red[8];
+
+  const int KM = K * M;
+  int ok[MAXO], om[MAXO];
+  double acc[MAXO];
+#pragma unroll
+  for (int p = 0; p < MAXO; ++p) {
+    const int o = threadIdx.x + p * TB;
+    ok[p] = o < KM ? o / M : -1;
+    om[p] = o < KM ? o - (o / M) * M : 0;
+    acc[p] = 0.0;
+  }
+  double c_pair = 0.0, c_pcn = 0.0, c_un = 0.0;
+
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    const int64_t i = base + threadIdx.x;
+    const bool live = (int)threadIdx.x < rows;
+    float* row = tile + threadIdx.x * Kp;
+    float wtot = 0.f;
+    int li = 0;
+    // phase 1: neighbour-label histogram h[k] in the node's own LDS row; pairwise / ppn / unary costs
+    if (live) {
+      li = labels[i];
+      for (int k = 0; k < K; ++k) row[k] = 0.f;
+      const int32_t* nb = nbr + i * D;
+      const float* wg = wgt + i * D;
+      float diff = 0.f;
+      int deg = 0;
+      for (int j = 0; j < D; j += 4) {
+        const int4 c = *reinterpret_cast<const int4*>(nb + j);
+        const float4 wv = *reinterpret_cast<const float4*>(wg + j);
+        const int cc[4] = {c.x, c.y, c.z, c.w};
+        const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (cc[t] >= 0) {
+            const float w = use_w ? ww[t] : 1.f;
+            const int l = labels[cc[t]];
+            row[l] += w;
+            wtot += w;
+            if (l != li) diff += w;
+            ++deg;
+          }
+        }
+      }
+      c_pair += (double)(beta * diff);
+      if (!deg) {  // isolated (:421-423): pp = V[l_i,:]  <=>  h = onehot(l_i), Wtot = 1
+        row[li] = 1.f;
+        wtot = 1.f;
+      }
+      // -pp_k = beta*(h_k - wtot) <= 0 with max 0 reached only if some h_k == wtot; shift by the max anyway
+      float mb = -3.0e38f;
+      for (int k = 0; k < K; ++k) mb = fmaxf(mb, beta * (row[k] - wtot));
+      float s2 = 0.f;
+      for (int k = 0; k < K; ++k) s2 += __expf(beta * (row[k] - wtot) - mb);
+      const float ppn = __expf(beta * (row[li] - wtot) - mb) / s2;
+      c_pcn -= (double)logf(ppn + 1e-16f);
+      c_un -= (double)logprob[i * K + li];
+    }
+    __syncthreads();
+    // phase 2: tile = logprob + beta*h   (coalesced row loads, K/VEC lanes per row)
+    rows_to_tile<VEC, true>(logprob, nullptr, base, rows, K, Kp, tile, 1.f, beta);
+    __syncthreads();
+    // phase 3: posteriors = softmax_k(tile_k - beta*wtot) in place; per-node features [1 | x | x x^T]
+    if (live) {
+      float m = -3.0e38f;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, row[k]);
+      float s1 = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float e = __expf(row[k] - m);
+        row[k] = e;
+        s1 += e;
+      }
+      const float inv = 1.f / s1;
+      for (int k = 0; k < K; ++k) row[k] *= inv;
+      float x[S];
+      if (S % 4 == 0) {
+#pragma unroll
+        for (int s = 0; s < S; s += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(X + i * S + s);
+          x[s] = t.x; x[s + 1] = t.y; x[s + 2] = t.z; x[s + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < S; ++s) x[s] = X[i * S + s];
+      }
+      float* f = feat + threadIdx.x * Mp;
+      f[0] = 1.f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) f[1 + s] = x[s];
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < S; ++t) f[1 + S + s * S + t] = x[s] * x[t];
+    }
+    __syncthreads();
+    if (WRITE_POST) tile_to_rows<VEC>(post_out + base * K, rows, K, Kp, tile);
+    // phase 4: stats[k][m] += sum_r gamma[r][k] * feat[r][m]; thread owns outputs o = tid + p*TB
+#pragma unroll
+    for (int p = 0; p < MAXO; ++p) {
+      if (ok[p] >= 0) {
+        const float* g = tile + ok[p];
+        const float* f = feat + om[p];
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a = fmaf(g[r * Kp], f[r * Mp], a);
+        acc[p] += (double)a;
+      }
+    }
+    __syncthreads();
+  }
+  // flush: statistics (layout post[K] | obs[K,S] | obsobsT[K,S,S]) and the three cost numerators
+#pragma unroll
+  for (int p = 0; p < MAXO; ++p) {
+    if (ok[p] >= 0) {
+      const int k = ok[p], m = om[p];
+      int dst;
+      if (m == 0) dst = k;
+      else if (m <= S) dst = K + k * S + (m - 1);
+      else dst = K + K * S + k * S * S + (m - 1 - S);
+      atomicAdd(accum + ACC_STATS + dst, acc[p]);
+    }
+  }
+  const double t0 = block_sum(c_pair, red);
+  const double t1 = block_sum(c_pcn, red);
+  const double t2 = block_sum(c_un, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(accum + ACC_COST + 0, t0);
+    atomicAdd(accum + ACC_COST + 1, t1);
+    atomicAdd(accum + ACC_COST + 2, t2);
+    atomicAdd(accum + ACC_COST + 3, t1 + t2);
+  }
+}
+
+template <int S>
+int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool write_post) {
+  constexpr int M = 1 + S + S * S;
+  constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
+  const int K = b->K, Kp = padded_k(K);
+  int TB = 256;
+  while (TB > 64 && (size_t)TB * (Kp + Mp) * sizeof(float) > 64 * 1024 - 256) TB >>= 1;
+  PHMRF_CHECK((size_t)TB * (Kp + Mp) * sizeof(float) <= 64 * 1024 - 256, PHMRF_ERR_UNSUPPORTED,
+              "posterior_stats: K and S too large for the LDS tile");
+  PHMRF_CHECK(K * M <= MAXO * TB, PHMRF_ERR_UNSUPPORTED, "posterior_stats: K*(1+S+S*S) exceeds the per-workgroup output capacity");
+  const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float);
+  const int grid = grid_for(b->n, TB, 256 * 8);
+  const int use_w = estimate_type == 3 ? 1 : 0;
+#define PHMRF_LAUNCH_POST(VEC_, WP_)                                                                                \
+  hipLaunchKernelGGL((posterior_kernel<S, VEC_, WP_>), dim3(grid), dim3(TB), lds, b->stream, b->X, b->logprob, b->n, \
+                     K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, use_w, b->posteriors, b->accum)
+  const int v = vec_of(K);
+  if (write_post) {
+    if (v == 4) PHMRF_LAUNCH_POST(4, true); else if (v == 2) PHMRF_LAUNCH_POST(2, true); else PHMRF_LAUNCH_POST(1, true);
+  } else {
+    if (v == 4) PHMRF_LAUNCH_POST(4, false); else if (v == 2) PHMRF_LAUNCH_POST(2, false); else PHMRF_LAUNCH_POST(1, false);
+  }
+#undef PHMRF_LAUNCH_POST
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+}  // namespace
+
+// ---- launchers --------------------------------------------------------------------------------------
+int launch_emission(const float* X, int64_t n, int S, int K, const float* packed, float* logprob, hipStream_t st) {
+  switch (S) {
+#define PHMRF_CASE(S_) case S_: return launch_emission_s<S_>(X, n, K, packed, logprob, st);
+    PHMRF_CASE(1) PHMRF_CASE(2) PHMRF_CASE(3) PHMRF_CASE(4) PHMRF_CASE(5) PHMRF_CASE(6) PHMRF_CASE(7) PHMRF_CASE(8)
+    PHMRF_CASE(9) PHMRF_CASE(10) PHMRF_CASE(11) PHMRF_CASE(12) PHMRF_CASE(13) PHMRF_CASE(14) PHMRF_CASE(15) PHMRF_CASE(16)
+#undef PHMRF_CASE
+  }
+  return fail(PHMRF_ERR_UNSUPPORTED, "emission: S must be in [1,16]");
+}
+
+int launch_argmax_labels(const phmrf_block* b) {
+  const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
+  const size_t lds = (size_t)TB * Kp * sizeof(float);
+  const int grid = grid_for(b->n, TB);
+  switch (vec_of(K)) {
+    case 4: hipLaunchKernelGGL((argmax_kernel<4>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->labels); break;
+    case 2: hipLaunchKernelGGL((argmax_kernel<2>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->labels); break;
+    default: hipLaunchKernelGGL((argmax_kernel<1>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->labels); break;
+  }
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+int launch_icm_colour(const phmrf_block* b, float beta, int colour) {
+  const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
+  const int64_t lo = b->colour_ptr[colour], hi = b->colour_ptr[colour + 1];
+  const int64_t count = hi - lo;
+  if (count <= 0) return PHMRF_OK;
+  const size_t lds = (size_t)TB * Kp * sizeof(float);
+  const int grid = grid_for(count, TB);
+  const int32_t* nodes = b->colour_nodes + lo;
+  switch (vec_of(K)) {
+    case 4: hipLaunchKernelGGL((icm_kernel<4>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters); break;
+    case 2: hipLaunchKernelGGL((icm_kernel<2>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters); break;
+    default: hipLaunchKernelGGL((icm_kernel<1>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters); break;
+  }
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+int launch_energy(const phmrf_block* b, float beta) {
+  (void)beta;
+  const int grid = grid_for(b->n, 256, 256 * 8);
+  hipLaunchKernelGGL(energy_kernel, dim3(grid), dim3(256), 0, b->stream, b->logprob, b->n, b->K, b->D, b->nbr, b->wgt,
+                     b->labels, b->accum);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors) {
+  switch (b->S) {
+#define PHMRF_CASE(S_) case S_: return launch_posterior_s<S_>(b, beta, estimate_type, write_posteriors);
+    PHMRF_CASE(1) PHMRF_CASE(2) PHMRF_CASE(3) PHMRF_CASE(4) PHMRF_CASE(5) PHMRF_CASE(6) PHMRF_CASE(7) PHMRF_CASE(8)
+#undef PHMRF_CASE
+  }
+  return fail(PHMRF_ERR_UNSUPPORTED, "posterior_stats: S must be in [1,8]");
+}
+
+}  // namespace phmrf

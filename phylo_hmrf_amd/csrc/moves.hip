@@ -1,0 +1,413 @@
+// gfx950 kernels of the label solver's block moves (replacing gco's alpha-beta swap, phylo_hmrf.py:496-498):
+//
+//  chain_kernel      exact minimisation over ALL labellings of a 1-D segment (<= 63 consecutive nodes of a grid
+//                    row / column / diagonal), every other node fixed: Viterbi with the Potts min-trick,
+//                      m_t[k] = theta_t[k] + min(m_{t-1}[k], min_j m_{t-1}[j] + beta*w_{t-1,t}).
+//                    One wavefront per segment.  Phase 1 maps lane <-> node (theta rows built in LDS exactly
+//                    like the ICM tile), phase 2 maps lane <-> label: the min over labels is a DPP wave
+//                    reduction, argmin / jump decisions are 64-bit ballots kept one step per lane
+//                    (one v_cndmask per value), and the backtrack runs on scalars (v_readlane).
+//  component pass    connected components of equal label (hook + pointer-jumping label propagation), then for
+//                    every component C and label k the exact energy change of relabelling all of C to k,
+//                      dE = sum_{i in C} (u_i(k) - u_i(cur)) - beta * sum_{boundary edges to label k} w,
+//                    and the best strictly-improving move of every component that beats all adjacent candidates.
+//
+// Both are energy non-increasing by construction (simultaneous moves never share an edge).
+
+#include "common.h"
+
+namespace phmrf {
+namespace {
+
+inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
+
+// ---- wave-wide min over 64 lanes with DPP; result broadcast through an SGPR -------------------------
+#define PHMRF_DPP_MIN(v, ctrl, rmask)                                                                              \
+  v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),                   \
+                                                                     __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false)))
+
+__device__ __forceinline__ float wave_min_f32(float v) {
+  PHMRF_DPP_MIN(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+  PHMRF_DPP_MIN(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+  PHMRF_DPP_MIN(v, 0x141, 0xf);  // row_half_mirror
+  PHMRF_DPP_MIN(v, 0x140, 0xf);  // row_mirror          -> every 16-lane row holds its min
+  PHMRF_DPP_MIN(v, 0x142, 0xa);  // row_bcast15 into rows 1,3
+  PHMRF_DPP_MIN(v, 0x143, 0xc);  // row_bcast31 into rows 2,3 -> lane 63 holds the wave min
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+constexpr float BIG = 3.0e38f;
+
+// -------------------------------------------------------------------------------------------------
+// chain segments
+// -------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ logprob, const int32_t* __restrict__ order,
+                                                    const int32_t* __restrict__ seg_start,
+                                                    const int32_t* __restrict__ seg_len, int nseg, int K, int Kp, int D,
+                                                    const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
+                                                    uint8_t* __restrict__ labels, float beta,
+                                                    unsigned long long* __restrict__ changed) {
+  extern __shared__ float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int WPB = blockDim.x >> 6;
+  float* tile = lds + wave * 64 * Kp;  // [64][Kp], private to this wave
+  unsigned int my_changed = 0;
+  const int KV = K / VEC;
+
+  for (int seg0 = blockIdx.x * WPB; seg0 < nseg; seg0 += gridDim.x * WPB) {  // uniform trip count per block
+    const int seg = seg0 + wave;
+    const bool active = seg < nseg;
+    const int p0 = active ? seg_start[seg] : 0;
+    const int len = active ? seg_len[seg] : 0;
+    // phase 1a: theta rows <- -logprob rows (K/VEC lanes per row, coalesced)
+    for (int q = lane; q < len * KV; q += 64) {
+      const int r = q / KV;
+      const int c = (q - r * KV) * VEC;
+      const float* src = logprob + (int64_t)order[p0 + r] * K + c;
+      float* dst = tile + r * Kp + c;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        dst[0] = -t.x; dst[1] = -t.y; dst[2] = -t.z; dst[3] = -t.w;
+      } else if (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        dst[0] = -t.x; dst[1] = -t.y;
+      } else {
+        dst[0] = -src[0];
+      }
+    }
+    __syncthreads();
+    // phase 1b: lane t subtracts beta*w for every neighbour outside the segment-chain (fixed labels);
+    //           the edge to the chain successor becomes the link weight
+    const int node = lane < len ? order[p0 + lane] : -1;
+    int pv = __shfl_up(node, 1, 64);
+    int nx = __shfl_down(node, 1, 64);
+    if (lane == 0) pv = -1;
+    if (lane >= len - 1) nx = -1;
+    float link = 0.f;
+    int old = 0;
+    if (lane < len) {
+      float* row = tile + lane * Kp;
+      const int32_t* nb = nbr + (int64_t)node * D;
+      const float* wg = wgt + (int64_t)node * D;
+      for (int j = 0; j < D; ++j) {
+        const int c = nb[j];
+        if (c < 0) continue;
+        const float w = wg[j];
+        if (c == nx) { link = w; continue; }
+        if (c == pv) continue;
+        row[labels[c]] -= beta * w;
+      }
+      old = labels[node];
+    }
+    __syncthreads();
+    // phase 2: forward pass, lane <-> label
+    float m = (lane < K && len > 0) ? tile[lane] : BIG;
+    unsigned int jm_lo = 0, jm_hi = 0, am_v = 0;  // lane t holds the decisions of step t
+    for (int t = 1; t < len; ++t) {
+      const float th = lane < K ? tile[t * Kp + lane] : 0.f;
+      const float mmin = wave_min_f32(m);
+      const unsigned long long eq = __ballot(m == mmin);
+      const int am = __ffsll((long long)eq) - 1;
+      const float lk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, link), t - 1));
+      const float alt = mmin + beta * lk;
+      const bool jp = (lane < K) && (alt < m);
+      const unsigned long long jm = __ballot(jp);
+      m = lane < K ? th + (jp ? alt : m) : BIG;
+      if (lane == t) {  // "write lane t": uniform value into one lane
+        jm_lo = (unsigned int)(jm & 0xffffffffu);
+        jm_hi = (unsigned int)(jm >> 32);
+        am_v = (unsigned int)am;
+      }
+    }
+    // backtrack on scalars
+    int newl = 0;
+    if (len > 0) {
+      const float mmin = wave_min_f32(m);
+      int cur = __ffsll((long long)__ballot(m == mmin)) - 1;
+      for (int t = len - 1; t >= 1; --t) {
+        if (lane == t) newl = cur;
+        const unsigned long long jm = ((unsigned long long)__builtin_amdgcn_readlane(jm_hi, t) << 32) |
+                                      (unsigned long long)__builtin_amdgcn_readlane(jm_lo, t);
+        if ((jm >> cur) & 1ull) cur = (int)__builtin_amdgcn_readlane(am_v, t);
+      }
+      if (lane == 0) newl = cur;
+    }
+    if (lane < len && newl != old) {
+      labels[node] = (uint8_t)newl;
+      ++my_changed;
+    }
+    __syncthreads();
+  }
+  unsigned int s = my_changed;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
+}
+
+// -------------------------------------------------------------------------------------------------
+// connected components of equal label
+// -------------------------------------------------------------------------------------------------
+__global__ void cc_init_kernel(int32_t* __restrict__ comp, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    comp[i] = (int32_t)i;
+}
+
+// hook: the root of i's tree is attached below the smallest root id seen among same-label neighbours
+__global__ void cc_hook_kernel(int32_t* __restrict__ comp, int64_t n, int D, const int32_t* __restrict__ nbr,
+                               const uint8_t* __restrict__ labels, unsigned long long* __restrict__ flag) {
+  bool any = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = labels[i];
+    const int ci = comp[i];
+    int m = ci;
+    const int32_t* nb = nbr + i * D;
+    for (int j = 0; j < D; ++j) {
+      const int c = nb[j];
+      if (c >= 0 && labels[c] == l) {
+        const int cc = comp[c];
+        m = cc < m ? cc : m;
+      }
+    }
+    if (m < ci) {
+      atomicMin(comp + ci, m);
+      any = true;
+    }
+  }
+  if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag + 1, 1ull);
+}
+
+// pointer jumping to the root
+__global__ void cc_compress_kernel(int32_t* __restrict__ comp, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = comp[i];
+    int p = comp[c];
+    while (p != c) {
+      c = p;
+      p = comp[c];
+    }
+    comp[i] = c;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// per-component move table: tab[root,k] = sum_{i in C} -logprob[i,k] - beta * sum_{boundary edges to label k} w
+// Node tile like ICM; the tile rows are then summed over runs of equal root (consecutive node ids mostly
+// share a component) before the atomics, so a large component receives one add per run, not per node.
+// -------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void comp_table_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp, int D,
+                                                         const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
+                                                         const uint8_t* __restrict__ labels,
+                                                         const int32_t* __restrict__ comp, float beta,
+                                                         float* __restrict__ tab) {
+  extern __shared__ float lds[];
+  const int TB = blockDim.x;
+  float* tile = lds;                                          // [TB][Kp]
+  int32_t* roots = reinterpret_cast<int32_t*>(lds + TB * Kp);  // [TB]
+  const int KV = K / VEC;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    for (int q = threadIdx.x; q < rows * KV; q += TB) {
+      const int r = q / KV;
+      const int c = (q - r * KV) * VEC;
+      const float* src = logprob + (base + r) * K + c;
+      float* dst = tile + r * Kp + c;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        dst[0] = -t.x; dst[1] = -t.y; dst[2] = -t.z; dst[3] = -t.w;
+      } else if (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        dst[0] = -t.x; dst[1] = -t.y;
+      } else {
+        dst[0] = -src[0];
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+      const int64_t i = base + threadIdx.x;
+      const int ci = comp[i];
+      roots[threadIdx.x] = ci;
+      float* row = tile + threadIdx.x * Kp;
+      const int32_t* nb = nbr + i * D;
+      const float* wg = wgt + i * D;
+      for (int j = 0; j < D; ++j) {
+        const int c = nb[j];
+        if (c >= 0 && comp[c] != ci) row[labels[c]] -= beta * wg[j];
+      }
+    }
+    __syncthreads();
+    // column k, row slice s: walk the slice, flush one atomic per run of equal root
+    const int nslice = TB / K;
+    const int k = threadIdx.x % K, s = threadIdx.x / K;
+    if (s < nslice) {
+      const int per = (rows + nslice - 1) / nslice;
+      const int r0 = s * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+      if (r0 < r1) {
+        int root = roots[r0];
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+          const int rr = roots[r];
+          if (rr != root) {
+            atomicAdd(tab + (int64_t)root * K + k, acc);
+            acc = 0.f;
+            root = rr;
+          }
+          acc += tile[r * Kp + k];
+        }
+        atomicAdd(tab + (int64_t)root * K + k, acc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// best strictly-improving label per component (computed at the root node); gain = dE < 0 or 0
+__global__ void comp_decide_kernel(const float* __restrict__ tab, int64_t n, int K, const uint8_t* __restrict__ labels,
+                                   const int32_t* __restrict__ comp, int32_t* __restrict__ best,
+                                   float* __restrict__ gain) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = 0.f;
+    int bk = -1;
+    if (comp[i] == (int32_t)i) {
+      const float* row = tab + i * K;
+      const int cur = labels[i];
+      const float tc = row[cur];
+      float bv = tc;
+      for (int k = 0; k < K; ++k) {
+        const float v = row[k];
+        if (v < bv) { bv = v; bk = k; }
+      }
+      // float atomics sum in arbitrary order: demand a margin well above their rounding noise
+      const float margin = 1e-5f * fabsf(tc) + 1e-6f;
+      if (bk >= 0 && bv < tc - margin) g = bv - tc; else bk = -1;
+    }
+    best[i] = bk;
+    gain[i] = g;
+  }
+}
+
+// a candidate component is blocked when an adjacent candidate has a better (more negative) gain; ties by root id
+__global__ void comp_block_kernel(int64_t n, int D, const int32_t* __restrict__ nbr, const int32_t* __restrict__ comp,
+                                  const float* __restrict__ gain, uint8_t* __restrict__ blocked) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = comp[i];
+    const float gi = gain[ci];
+    if (gi >= 0.f) continue;
+    const int32_t* nb = nbr + i * D;
+    for (int j = 0; j < D; ++j) {
+      const int c = nb[j];
+      if (c < 0) continue;
+      const int cj = comp[c];
+      if (cj == ci) continue;
+      const float gj = gain[cj];
+      if (gj < gi || (gj == gi && cj < ci)) blocked[ci] = 1;
+    }
+  }
+}
+
+__global__ void comp_apply_kernel(int64_t n, const int32_t* __restrict__ comp, const int32_t* __restrict__ best,
+                                  const uint8_t* __restrict__ blocked, uint8_t* __restrict__ labels,
+                                  unsigned long long* __restrict__ changed) {
+  unsigned int mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = comp[i];
+    const int bk = best[ci];
+    if (bk >= 0 && !blocked[ci]) {
+      labels[i] = (uint8_t)bk;
+      ++mine;
+    }
+  }
+  unsigned int s = mine;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(changed, (unsigned long long)s);
+}
+
+inline int grid1d(int64_t n, int tb = 256, int cap = 256 * 16) {
+  int64_t g = (n + tb - 1) / tb;
+  if (g > cap) g = cap;
+  return g < 1 ? 1 : (int)g;
+}
+
+template <typename T>
+int ensure(T** p, size_t count) {
+  if (*p) return PHMRF_OK;
+  PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  return PHMRF_OK;
+}
+
+}  // namespace
+
+int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase) {
+  const ChainFamily& f = b->families[family];
+  const int nseg = f.nseg[phase][colour];
+  if (nseg <= 0) return PHMRF_OK;
+  const int K = b->K, Kp = padded_k(K);
+  const int TB = 256, WPB = TB / 64;
+  const size_t lds = (size_t)WPB * 64 * Kp * sizeof(float);
+  int grid = (nseg + WPB - 1) / WPB;
+  if (grid > 256 * 16) grid = 256 * 16;
+#define PHMRF_LAUNCH_CHAIN(VEC_)                                                                                      \
+  hipLaunchKernelGGL((chain_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, f.nodes,                  \
+                     f.seg_start[phase][colour], f.seg_len[phase][colour], nseg, K, Kp, b->D, b->nbr, b->wgt, b->labels, \
+                     beta, b->counters)
+  switch (vec_of(K)) {
+    case 4: PHMRF_LAUNCH_CHAIN(4); break;
+    case 2: PHMRF_LAUNCH_CHAIN(2); break;
+    default: PHMRF_LAUNCH_CHAIN(1); break;
+  }
+#undef PHMRF_LAUNCH_CHAIN
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+int launch_component_pass(phmrf_block* b, float beta) {
+  const int64_t n = b->n;
+  const int K = b->K, Kp = padded_k(K), D = b->D;
+  PHMRF_TRY(ensure(&b->comp, (size_t)n));
+  PHMRF_TRY(ensure(&b->comp_tab, (size_t)n * K));
+  PHMRF_TRY(ensure(&b->comp_best, (size_t)n));
+  PHMRF_TRY(ensure(&b->comp_gain, (size_t)n));
+  PHMRF_TRY(ensure(&b->comp_move, (size_t)n));
+  hipStream_t st = b->stream;
+  const int g = grid1d(n);
+  hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n);
+  // hook + compress until a hook pass finds nothing to attach (flag = counters[1])
+  for (int it = 0; it < 256; ++it) {
+    PHMRF_HIP(hipMemsetAsync(b->counters + 1, 0, sizeof(unsigned long long), st));
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(cc_hook_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->counters);
+      hipLaunchKernelGGL(cc_compress_kernel, dim3(g), dim3(256), 0, st, b->comp, n);
+    }
+    PHMRF_HIP(hipMemcpyAsync(b->counters_host + 1, b->counters + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PHMRF_HIP(hipStreamSynchronize(st));
+    if (b->counters_host[1] == 0) break;
+  }
+  PHMRF_HIP(hipMemsetAsync(b->comp_tab, 0, (size_t)n * K * sizeof(float), st));
+  PHMRF_HIP(hipMemsetAsync(b->comp_move, 0, (size_t)n, st));
+  {
+    const int TB = tile_threads(K);
+    const size_t lds = (size_t)TB * Kp * sizeof(float) + (size_t)TB * sizeof(int32_t);
+    const int grid = grid1d(n, TB);
+#define PHMRF_LAUNCH_TAB(VEC_)                                                                                       \
+  hipLaunchKernelGGL((comp_table_kernel<VEC_>), dim3(grid), dim3(TB), lds, st, b->logprob, n, K, Kp, D, b->nbr, b->wgt, \
+                     b->labels, b->comp, beta, b->comp_tab)
+    switch (vec_of(K)) {
+      case 4: PHMRF_LAUNCH_TAB(4); break;
+      case 2: PHMRF_LAUNCH_TAB(2); break;
+      default: PHMRF_LAUNCH_TAB(1); break;
+    }
+#undef PHMRF_LAUNCH_TAB
+  }
+  hipLaunchKernelGGL(comp_decide_kernel, dim3(g), dim3(256), 0, st, b->comp_tab, n, K, b->labels, b->comp, b->comp_best,
+                     b->comp_gain);
+  hipLaunchKernelGGL(comp_block_kernel, dim3(g), dim3(256), 0, st, n, D, b->nbr, b->comp, b->comp_gain, b->comp_move);
+  hipLaunchKernelGGL(comp_apply_kernel, dim3(g), dim3(256), 0, st, n, b->comp, b->comp_best, b->comp_move, b->labels,
+                     b->counters);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+}  // namespace phmrf

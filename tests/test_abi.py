@@ -1,0 +1,80 @@
+"""CPU: libphmrf.so loads without a GPU and exports every symbol include/phmrf.h declares; the ctypes table in
+phylo_hmrf_amd/_lib.py covers exactly that set.  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "phmrf.h")
+LIB = os.path.join(ROOT, "phylo_hmrf_amd", "libphmrf.so")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"PHMRF_API\s+[\w\s\*]+?\b(phmrf_\w+)\s*\(", txt)))
+
+
+def test_header_declares_the_hot_path_entry_points():
+    syms = declared_symbols()
+    for must in ("phmrf_emission", "phmrf_mrf_solve", "phmrf_posterior_stats", "phmrf_mrf_energy",
+                 "phmrf_block_create", "phmrf_block_set_graph", "phmrf_block_destroy"):
+        assert must in syms
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libphmrf.so not built (run __graft_entry__.build())")
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(LIB)
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libphmrf.so not built")
+def test_ctypes_table_matches_header():
+    from phylo_hmrf_amd import _lib
+    assert sorted(_lib.SIGNATURES.keys()) == declared_symbols()
+    L = _lib.load()
+    assert L.phmrf_version() >= 100
+    assert L.phmrf_status_string(0).decode() == "ok"
+    assert L.phmrf_status_string(6).decode().startswith("covariance")
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libphmrf.so not built")
+def test_product_path_fails_loudly_without_a_gpu():
+    from phylo_hmrf_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        from phylo_hmrf_amd import Block
+        Block(10, 4, 5)
+
+
+def test_emission_pack_is_host_only_and_matches_oracle():
+    """phmrf_emission_pack is pure host code (Cholesky, inverse factor, log-det): check it without a GPU."""
+    if not os.path.exists(LIB):
+        pytest.skip("libphmrf.so not built")
+    import numpy as np
+    from phylo_hmrf_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    S, K = 4, 3
+    A = rng.standard_normal((K, S, S))
+    cov = np.einsum("kij,klj->kil", A, A) + 2e-3 * np.eye(S)
+    mu = rng.uniform(0, 3, (K, S))
+    nf = ctypes.c_int64(0)
+    assert L.phmrf_emission_pack_size(S, K, ctypes.byref(nf)) == 0
+    PS = S + S * (S + 1) // 2 + 1
+    assert nf.value == K * PS
+    out = np.zeros(nf.value, dtype=np.float32)
+    assert L.phmrf_emission_pack(S, K, _lib.ptr_d(mu), _lib.ptr_d(cov), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) == 0
+    for k in range(K):
+        p = out[k * PS:(k + 1) * PS]
+        Lc = np.linalg.cholesky(cov[k])
+        Li = np.linalg.inv(Lc)
+        np.testing.assert_allclose(p[:S], mu[k], rtol=1e-6)
+        np.testing.assert_allclose(p[S:-1], Li[np.tril_indices(S)], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(p[-1], -0.5 * (S * np.log(2 * np.pi) + 2 * np.log(np.diag(Lc)).sum()), rtol=1e-6)
+    bad = cov.copy()
+    bad[1] = -np.eye(S)
+    assert L.phmrf_emission_pack(S, K, _lib.ptr_d(mu), _lib.ptr_d(bad), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) == 6
