@@ -102,12 +102,14 @@ PHMRF_API int phmrf_emission_dev(const float* X_dev, int64_t n, int S, int K, co
 
 /* ---- b2: MRF labelling ------------------------------------------------------------------------ */
 typedef struct phmrf_solve_opts {
-  int max_rounds;      /* <=0: default 64.  One round = chain moves (if grid set) + component moves + ICM sweep */
+  int max_rounds;      /* <=0: default 64.  One round = chain moves + ICM sweep + component moves + strip moves */
   int use_chains;      /* 1: exact 1-D chain moves when geometry is known                                      */
   int use_components;  /* 1: whole-component relabel moves                                                     */
   int init_mode;       /* 0: start from the block's current labels (reference warm start, phylo_hmrf.py:479)
                           1: start from argmax_k logprob                                                        */
-  int reserved[4];
+  int use_strips;      /* 1: exact 5-row strip fusion moves (needs the grid)                                   */
+  int use_expansion;   /* 1: additionally one strip alpha-expansion per label and orientation every round      */
+  int reserved[2];
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {
@@ -129,6 +131,11 @@ PHMRF_API int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_op
 PHMRF_API int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed);
 PHMRF_API int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* changed);
 PHMRF_API int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed);
+/* One pass of exact strip fusion moves.  orient 0: strips of 5 grid rows, 1: of 5 grid columns; shift_r in [0,5],
+ * shift_c in [0,63] move the fixed separator rows/columns; alpha >= 0: every node may keep its label or take
+ * alpha (strip alpha-expansion); alpha < 0: every node may keep its label or take its best alternative label. */
+PHMRF_API int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, int alpha,
+                                   int64_t* changed);
 PHMRF_API int phmrf_mrf_energy(phmrf_block_t b, double beta, double* e_total, double* e_unary, double* e_pair);
 
 /* ---- b3: posteriors, costs, sufficient statistics ------------------------------------------- */
@@ -148,10 +155,10 @@ PHMRF_API int phmrf_posterior_stats_dev(phmrf_block_t b, double beta, int estima
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
- * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats. */
-#define PHMRF_NUM_KERNEL_CLASSES 6
+ * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip. */
+#define PHMRF_NUM_KERNEL_CLASSES 7
 PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
-PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[6]*/, int64_t* launches /*[6]*/);
+PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[7]*/, int64_t* launches /*[7]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
 
 #ifdef __cplusplus

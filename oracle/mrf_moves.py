@@ -218,3 +218,176 @@ def solve(g, unary, init, beta, H=None, W=None, diagonal=None, num_neighbor=8, m
         if ch == 0:
             break
     return labels
+
+
+# ------------------------------------------------------------------------------------------------
+# connected-component relabel moves (model of csrc/moves.hip: component pass)
+# ------------------------------------------------------------------------------------------------
+def component_pass(g, unary, labels, beta, margin=True):
+    """Relabel whole connected components of equal label: for every component C and label k the exact
+    dE = sum_{i in C}(u_i(k) - u_i(cur)) - beta * sum_{boundary edges to label k} w; a component moves to its
+    best strictly-improving label unless an adjacent candidate component has a better gain (ties: lower
+    root id).  In place; returns the number of relabelled nodes."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    K = unary.shape[1]
+    a, b = g.edge_ids[:, 0], g.edge_ids[:, 1]
+    same = labels[a] == labels[b]
+    A = sp.coo_matrix((np.ones(int(same.sum())), (a[same], b[same])), shape=(g.n, g.n))
+    nc, comp0 = connected_components(A, directed=False)
+    # root id = smallest node id of the component (what the device's min-propagation converges to)
+    root_of = np.full(nc, g.n, dtype=np.int64)
+    np.minimum.at(root_of, comp0, np.arange(g.n))
+    U = np.zeros((nc, K))
+    np.add.at(U, comp0, unary)
+    cs, cd = comp0[g.src], comp0[g.col]
+    bd = cs != cd
+    np.add.at(U, (cs[bd], labels[g.col[bd]]), -beta * g.wgt[bd])
+    cur = np.zeros(nc, dtype=np.int64)
+    cur[comp0] = labels
+    tc = U[np.arange(nc), cur]
+    best = np.argmin(U, axis=1)
+    bv = U[np.arange(nc), best]
+    mar = (1e-5 * np.abs(tc) + 1e-6) if margin else 0.0
+    cand = bv < tc - mar
+    gain = np.where(cand, bv - tc, 0.0)
+    blocked = np.zeros(nc, dtype=bool)
+    ci, cj = cs[bd], cd[bd]
+    worse = cand[ci] & ((gain[cj] < gain[ci]) | ((gain[cj] == gain[ci]) & (root_of[cj] < root_of[ci]) & cand[cj]))
+    blocked[ci[worse]] = True
+    move = cand & ~blocked
+    mv = move[comp0]
+    labels[mv] = best[comp0[mv]]
+    return int(mv.sum())
+
+
+# ------------------------------------------------------------------------------------------------
+# strip fusion moves (model of csrc/strip.hip)
+# ------------------------------------------------------------------------------------------------
+STRIP_H = 5          # rows per strip: profile of H+1 = 6 binary cells = 64 states = one wavefront
+STRIP_L = 63         # columns per strip segment
+
+
+def best_alternative(g, unary, labels, beta):
+    """proposal p_i = argmin_{k != l_i} (u_i(k) - beta * sum_{j in N(i), l_j == k} w_ij), lowest k on ties."""
+    K = unary.shape[1]
+    cost = unary - beta * neighbour_hist(g, labels, K)
+    cost[np.arange(g.n), labels] = np.inf
+    return np.argmin(cost, axis=1)
+
+
+def strip_node_table(H, W, diagonal, orient, shift_r, shift_c):
+    """-> nodes[NS, STRIP_L*STRIP_H] (column-major cells, -1 missing), ncols[NS].  Geometry (shared with the
+    kernel): orient 0: strip rows = grid rows; orient 1: strip rows = grid columns.  Bands of STRIP_H strip-rows
+    start at b*(STRIP_H+1) - shift_r and are separated by one fixed strip-row; segments of STRIP_L strip-columns
+    start at s*64 - shift_c and are separated by one fixed strip-column."""
+    h, L = STRIP_H, STRIP_L
+    if diagonal:
+        idmap = -np.ones((H, W), dtype=np.int64)
+        ii, jj = np.triu_indices(H)
+        idmap[ii, jj] = np.arange(ii.shape[0])
+    else:
+        idmap = np.arange(H * W).reshape(H, W)
+    mp = idmap if orient == 0 else idmap.T
+    Hs, Ws = mp.shape
+    nb = -(-(Hs + shift_r) // (h + 1))
+    ns = -(-(Ws + shift_c) // 64)
+    out, ncols = [], []
+    for b in range(nb):
+        rs0 = b * (h + 1) - shift_r
+        for s in range(ns):
+            cs0 = s * 64 - shift_c
+            ca, cb = max(cs0, 0), min(cs0 + L, Ws)
+            if cb <= ca:
+                continue
+            blk = -np.ones((L, h), dtype=np.int64)
+            for rr in range(h):
+                r = rs0 + rr
+                if 0 <= r < Hs:
+                    blk[:cb - ca, rr] = mp[r, ca:cb]
+            out.append(blk.reshape(-1))
+            ncols.append(cb - ca)
+    return np.array(out), np.array(ncols)
+
+
+def strip_fusion(g, unary, labels, prop, beta, H, W, diagonal, orient, shift_r, shift_c):
+    """Exact binary fusion x_i in {keep l_i, take prop_i} over every strip simultaneously (profile DP over
+    2^(STRIP_H+1) states).  In place; returns the number of changed nodes."""
+    h = STRIP_H
+    nodes, ncols = strip_node_table(H, W, diagonal, orient, shift_r, shift_c)
+    NS, T = nodes.shape
+    n = g.n
+    valid = nodes >= 0
+    safe = np.where(valid, nodes, 0)
+    sid = -np.ones(n, dtype=np.int64)
+    ss, pp = np.nonzero(valid)
+    sid[nodes[ss, pp]] = ss
+    lab = np.asarray(labels, dtype=np.int64)
+    prop = np.asarray(prop, dtype=np.int64)
+    inside = (sid[g.src] >= 0) & (sid[g.src] == sid[g.col])
+    c0 = unary[np.arange(n), lab].copy()
+    c1 = unary[np.arange(n), prop].copy()
+    o = ~inside
+    np.add.at(c0, g.src[o], beta * g.wgt[o] * (lab[g.src[o]] != lab[g.col[o]]))
+    np.add.at(c1, g.src[o], beta * g.wgt[o] * (prop[g.src[o]] != lab[g.col[o]]))
+    keys = g.src * n + g.col
+
+    def wlook(a, b):
+        q = np.where((a >= 0) & (b >= 0), a * n + b, -1)
+        p = np.clip(np.searchsorted(keys, q.ravel()), 0, len(keys) - 1)
+        hit = keys[p] == q.ravel()
+        return np.where(hit, g.wgt[p], 0.0).reshape(q.shape)
+
+    rr = np.arange(T) % h
+
+    def shifted(off, ok):
+        res = -np.ones_like(nodes)
+        if off < T:
+            res[:, off:] = nodes[:, :T - off]
+        res[:, ~ok] = -1
+        return res
+
+    nbs = [(shifted(1, rr > 0), 0), (shifted(h + 1, rr > 0), h), (shifted(h, rr >= 0), h - 1),
+           (shifted(h - 1, rr < h - 1), h - 2)]
+    ws = [wlook(nodes, nb) for nb, _ in nbs]
+    labv = np.where(valid, lab[safe], 0)
+    prv = np.where(valid, prop[safe], 0)
+    BIG = 1e30
+    C0 = np.where(valid, c0[safe], 0.0)
+    C1 = np.where(valid & (prv != labv), c1[safe], BIG)
+    NSt = 1 << (h + 1)
+    st = np.arange(NSt)
+    bbit = st & 1
+    m = np.zeros((NS, NSt))
+    back = np.zeros((NS, T, NSt), dtype=bool)
+    ncell = ncols * h
+    s_fin = np.zeros(NS, dtype=np.int64)
+    for t in range(T):
+        def total(pred):
+            cost = np.where(bbit[None, :] == 1, C1[:, t][:, None], C0[:, t][:, None])
+            labi = np.where(bbit[None, :] == 1, prv[:, t][:, None], labv[:, t][:, None])
+            for (nb, posn), w in zip(nbs, ws):
+                nbv = nb[:, t] >= 0
+                nsafe = np.where(nbv, nb[:, t], 0)
+                bitj = (pred >> posn) & 1
+                labj = np.where(bitj[None, :] == 1, prop[nsafe][:, None], lab[nsafe][:, None])
+                cost = cost + np.where(nbv[:, None], beta * w[:, t][:, None] * (labi != labj), 0.0)
+            return m[:, pred] + cost
+        a0 = total(st >> 1)
+        a1 = total((st >> 1) | (1 << h))
+        take1 = a1 < a0
+        m = np.where(take1, a1, a0)
+        back[:, t, :] = take1
+        done = ncell == t + 1
+        s_fin[done] = np.argmin(m[done], axis=1)       # the kernel stops at the strip's own last cell
+    s = s_fin.copy()
+    x = np.zeros((NS, T), dtype=np.int64)
+    for t in range(T - 1, -1, -1):
+        live = t < ncell
+        x[:, t] = np.where(live, s & 1, 0)
+        d = back[np.arange(NS), t, s]
+        s = np.where(live, (s >> 1) | (d.astype(np.int64) << h), s)
+    newlab = np.where(x == 1, prv, labv)
+    ch = int(((newlab != labv) & valid).sum())
+    labels[nodes[valid]] = newlab[valid]
+    return ch

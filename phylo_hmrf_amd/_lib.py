@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
-NUM_KERNEL_CLASSES = 6
-KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats")
+NUM_KERNEL_CLASSES = 7
+KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip")
 
 
 class PhmrfError(RuntimeError):
@@ -21,7 +21,8 @@ class PhmrfError(RuntimeError):
 
 class SolveOpts(ctypes.Structure):
     _fields_ = [("max_rounds", ctypes.c_int), ("use_chains", ctypes.c_int), ("use_components", ctypes.c_int),
-                ("init_mode", ctypes.c_int), ("reserved", ctypes.c_int * 4)]
+                ("init_mode", ctypes.c_int), ("use_strips", ctypes.c_int), ("use_expansion", ctypes.c_int),
+                ("reserved", ctypes.c_int * 2)]
 
 
 class SolveResult(ctypes.Structure):
@@ -71,6 +72,7 @@ SIGNATURES = {
     "phmrf_mrf_icm_sweep": [_vp, _d, _lp],
     "phmrf_mrf_chain_sweep": [_vp, _d, _i, _lp],
     "phmrf_mrf_component_pass": [_vp, _d, _lp],
+    "phmrf_mrf_strip_pass": [_vp, _d, _i, _i, _i, _i, _lp],
     "phmrf_mrf_energy": [_vp, _d, _dp, _dp, _dp],
     "phmrf_posterior_stats": [_vp, _d, _i, _dp, _dp, _dp],
     "phmrf_posterior_stats_dev": [_vp, _d, _i, _vp],

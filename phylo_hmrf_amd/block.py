@@ -93,16 +93,20 @@ class Block(object):
         check(self._L.phmrf_block_set_logprob(self._h, ptr_d(lp)))
 
     # -- b2 ---------------------------------------------------------------------------------------
-    def solve(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0):
-        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode))
+    def solve(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
+              use_expansion=True):
+        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
+                      int(use_expansion))
         r = SolveResult()
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), ctypes.byref(r)))
         return dict(energy=r.energy, energy_unary=r.energy_unary, energy_pair=r.energy_pair,
                     energy_init=r.energy_init, rounds=r.rounds, converged=bool(r.converged), changed=r.changed)
 
-    def solve_fast(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0):
+    def solve_fast(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
+                   use_expansion=True):
         """Same without the two energy evaluations."""
-        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode))
+        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
+                      int(use_expansion))
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), None))
 
     def icm_sweep(self, beta):
@@ -118,6 +122,12 @@ class Block(object):
     def component_pass(self, beta):
         c = ctypes.c_int64(0)
         check(self._L.phmrf_mrf_component_pass(self._h, float(beta), ctypes.byref(c)))
+        return c.value
+
+    def strip_pass(self, beta, orient, shift_r, shift_c, alpha=-1):
+        c = ctypes.c_int64(0)
+        check(self._L.phmrf_mrf_strip_pass(self._h, float(beta), int(orient), int(shift_r), int(shift_c), int(alpha),
+                                           ctypes.byref(c)))
         return c.value
 
     def energy(self, beta):

@@ -697,6 +697,29 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   return PHMRF_OK;
 }
 
+static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha) {
+  tic(b);
+  if (alpha < 0) PHMRF_TRY(launch_propose(b, beta));
+  PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha));
+  toc(b, KC_STRIP, alpha < 0 ? 2 : 1);
+  return PHMRF_OK;
+}
+
+int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, int alpha, int64_t* changed) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "strip moves need phmrf_block_set_grid");
+  PHMRF_CHECK(b->num_neighbor == 8 || b->num_neighbor == 4, PHMRF_ERR_STATE, "bad grid");
+  PHMRF_CHECK(orient == 0 || orient == 1, PHMRF_ERR_INVALID, "orient must be 0 or 1");
+  PHMRF_CHECK(shift_r >= 0 && shift_r <= 5 && shift_c >= 0 && shift_c <= 63, PHMRF_ERR_INVALID, "shift out of range");
+  PHMRF_CHECK(alpha < b->K, PHMRF_ERR_INVALID, "alpha must be < K");
+  PHMRF_TRY(zero_counter(b));
+  PHMRF_TRY(strip_pass_nocount(b, (float)beta, orient, shift_r, shift_c, alpha));
+  int64_t ch = 0;
+  PHMRF_TRY(read_counter(b, &ch));
+  if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
 int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res) {
   PHMRF_TRY(check_solvable(b));
   phmrf_solve_opts o;
@@ -704,6 +727,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   o.max_rounds = 64;
   o.use_chains = 1;
   o.use_components = 1;
+  o.use_strips = 1;
+  o.use_expansion = 1;
   if (opts) {
     o = *opts;
     if (o.max_rounds <= 0) o.max_rounds = 64;
@@ -727,6 +752,14 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       tic(b);
       PHMRF_TRY(launch_component_pass(b, bf));
       toc(b, KC_COMPONENT, 1);
+    }
+    if (o.use_strips && b->has_grid) {
+      for (int orient = 0; orient < 2; ++orient) {
+        const int sr = (2 * r + 3 * orient) % 6, sc = (17 * r + 31 * orient) % 64;
+        PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, -1));
+        if (o.use_expansion)
+          for (int a = 0; a < b->K; ++a) PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, a));
+      }
     }
     int64_t ch = 0;
     PHMRF_TRY(read_counter(b, &ch));

@@ -34,7 +34,7 @@ int fail(int status, const std::string& msg);
   } while (0)
 
 // ---- kernel classes for the built-in timers (phmrf.h) -------------------------------------------
-enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5 };
+enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5, KC_STRIP = 6 };
 
 // A chain family (grid rows / columns / diagonals / anti-diagonals): `nodes` lists node ids chain after
 // chain in chain order.  Chains of one colour share no edge.  Every chain is cut into SEGMENTS of at most
@@ -103,8 +103,8 @@ struct phmrf_block {
   // timing
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double ms[PHMRF_NUM_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
-  int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+  double ms[PHMRF_NUM_KERNEL_CLASSES] = {};
+  int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {};
 };
 
 namespace phmrf {
@@ -125,6 +125,8 @@ int launch_icm_colour(const phmrf_block* b, float beta, int colour);
 int launch_energy(const phmrf_block* b, float beta);  // -> accum[0]=unary, accum[1]=pair (caller zeroes)
 int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors);
 int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase);
-int launch_component_pass(phmrf_block* b, float beta);  // adds relabelled nodes to counters[0]
+int launch_component_pass(phmrf_block* b, float beta);
+int launch_propose(const phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha);  // adds relabelled nodes to counters[0]
 
 }  // namespace phmrf
