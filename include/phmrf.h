@@ -74,6 +74,14 @@ PHMRF_API int phmrf_block_set_graph(phmrf_block_t b, int64_t E, const int64_t* e
  * grid neighbours); enables the 1-D chain moves (rows / columns / diagonals). */
 PHMRF_API int phmrf_block_set_grid(phmrf_block_t b, int H, int W, int diagonal, int num_neighbor);
 
+/* Build the neighbour graph of a grid block ON THE DEVICE from the resident observations, replacing the host
+ * edge list: the stencil and distances of utility.py:1871-2053 (d = |xi-xj|^2/(|xi||xj|+1e-16), diagonal-to-
+ * diagonal edges of a diagonal block halved) and w = exp(-beta1*d) (phylo_hmrf.py:585).  Implies set_grid. */
+PHMRF_API int phmrf_block_build_grid_graph(phmrf_block_t b, int H, int W, int diagonal, int num_neighbor, double beta1);
+/* Read back the device adjacency (tests): *D = row width, nbr_out int32 [n,D] (-1 padded), wgt_out f32 [n,D];
+ * either output may be NULL. */
+PHMRF_API int phmrf_block_get_adjacency(phmrf_block_t b, int* D, int32_t* nbr_out, float* wgt_out);
+
 /* labels: host int32 [n], each in [0,K).  (reference: init_labels = labels_local[id1:id2],
  * phylo_hmrf.py:479; float input is cast by the Python layer.) */
 PHMRF_API int phmrf_block_set_labels(phmrf_block_t b, const int32_t* labels);
@@ -155,10 +163,10 @@ PHMRF_API int phmrf_posterior_stats_dev(phmrf_block_t b, double beta, int estima
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
- * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip. */
-#define PHMRF_NUM_KERNEL_CLASSES 7
+ * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip, 7 propose. */
+#define PHMRF_NUM_KERNEL_CLASSES 8
 PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
-PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[7]*/, int64_t* launches /*[7]*/);
+PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[8]*/, int64_t* launches /*[8]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
 
 #ifdef __cplusplus

@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
-NUM_KERNEL_CLASSES = 7
-KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip")
+NUM_KERNEL_CLASSES = 8
+KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose")
 
 
 class PhmrfError(RuntimeError):
@@ -57,6 +57,8 @@ SIGNATURES = {
     "phmrf_block_set_observations_dev": [_vp, _vp],
     "phmrf_block_set_graph": [_vp, _i64, _lp, _dp],
     "phmrf_block_set_grid": [_vp, _i, _i, _i, _i],
+    "phmrf_block_build_grid_graph": [_vp, _i, _i, _i, _i, _d],
+    "phmrf_block_get_adjacency": [_vp, ctypes.POINTER(_i), _ip, _fp],
     "phmrf_block_set_labels": [_vp, _ip],
     "phmrf_block_get_labels": [_vp, _ip],
     "phmrf_block_save_labels": [_vp, _i],

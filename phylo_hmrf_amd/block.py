@@ -55,6 +55,20 @@ class Block(object):
     def set_grid(self, H, W, diagonal, num_neighbor=8):
         check(self._L.phmrf_block_set_grid(self._h, int(H), int(W), int(bool(diagonal)), int(num_neighbor)))
 
+    def build_grid_graph(self, H, W, diagonal, num_neighbor=8, beta1=0.5):
+        """Graph built on the device from the resident observations (no host edge list)."""
+        check(self._L.phmrf_block_build_grid_graph(self._h, int(H), int(W), int(bool(diagonal)), int(num_neighbor),
+                                                   float(beta1)))
+
+    def get_adjacency(self):
+        D = ctypes.c_int(0)
+        check(self._L.phmrf_block_get_adjacency(self._h, ctypes.byref(D), None, None))
+        nbr = np.empty((self.n, D.value), dtype=np.int32)
+        wgt = np.empty((self.n, D.value), dtype=np.float32)
+        check(self._L.phmrf_block_get_adjacency(self._h, ctypes.byref(D), ptr_i32(nbr),
+                                                wgt.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return nbr, wgt
+
     def set_labels(self, labels):
         lab = np.ascontiguousarray(np.asarray(labels), dtype=np.int32)   # float labels are cast (base.py:381,394)
         assert lab.shape == (self.n,)

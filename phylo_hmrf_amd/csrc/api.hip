@@ -19,18 +19,42 @@ int fail(int status, const std::string& msg) {
   return status;
 }
 
+static hipEvent_t take_event(phmrf_block* b) {
+  if (!b->free_events.empty()) {
+    hipEvent_t e = b->free_events.back();
+    b->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
 void tic(phmrf_block* b) {
-  if (b->timing) (void)hipEventRecord(b->ev0, b->stream);
+  if (!b->timing) return;
+  b->cur_start = take_event(b);
+  (void)hipEventRecord(b->cur_start, b->stream);
 }
 
 void toc(phmrf_block* b, int kclass, int n_launches) {
   b->launches[kclass] += n_launches;
-  if (!b->timing) return;
-  (void)hipEventRecord(b->ev1, b->stream);
-  (void)hipEventSynchronize(b->ev1);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
-  b->ms[kclass] += ms;
+  if (!b->timing || !b->cur_start) return;
+  hipEvent_t e = take_event(b);
+  (void)hipEventRecord(e, b->stream);
+  b->pending.push_back({kclass, b->cur_start, e});
+  b->cur_start = nullptr;
+}
+
+static void resolve_timing(phmrf_block* b) {
+  if (b->pending.empty()) return;
+  (void)hipStreamSynchronize(b->stream);
+  for (auto& p : b->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) b->ms[p.kclass] += ms;
+    b->free_events.push_back(p.a);
+    b->free_events.push_back(p.b);
+  }
+  b->pending.clear();
 }
 
 namespace {
@@ -106,6 +130,123 @@ struct Geometry {
   int64_t id(int i, int j) const { return diagonal ? row_start[i] + (j - i) : (int64_t)i * W + j; }
   bool valid(int i, int j) const { return i >= 0 && i < H && j >= 0 && j < W && (!diagonal || i <= j); }
 };
+
+// ICM colour classes and chain families of a grid block, by direct enumeration (O(n), no sorting).
+int setup_grid_tables(phmrf_block* b, const Geometry& g, int num_neighbor) {
+  const int64_t n = b->n;
+  const int H = g.H, W = g.W;
+  // ICM colours: 2x2 parity classes (oracle/mrf_moves.icm_colours)
+  {
+    std::vector<int64_t> cptr(5, 0);
+    for (int i = 0; i < H; ++i)
+      for (int j = g.diagonal ? i : 0; j < W; ++j) ++cptr[(i % 2) * 2 + (j % 2) + 1];
+    for (int c = 0; c < 4; ++c) cptr[c + 1] += cptr[c];
+    std::vector<int64_t> pos(cptr.begin(), cptr.end() - 1);
+    std::vector<int32_t> cnodes(n);
+    for (int i = 0; i < H; ++i)
+      for (int j = g.diagonal ? i : 0; j < W; ++j) cnodes[pos[(i % 2) * 2 + (j % 2)]++] = (int32_t)g.id(i, j);
+    PHMRF_TRY(upload(b->colour_nodes, cnodes.data(), cnodes.size() * sizeof(int32_t), b->stream));
+    b->n_colours = 4;
+    b->colour_ptr = cptr;
+  }
+  // chain families: 0 rows, 1 columns, 2 diagonals (j - i), 3 anti-diagonals (i + j)
+  for (auto& f : b->families) free_family(f);
+  b->families.clear();
+  const int nfam = num_neighbor == 8 ? 4 : 2;
+  for (int fam = 0; fam < nfam; ++fam) {
+    const int ncol = fam < 2 ? 2 : 3;
+    std::vector<int32_t> order;
+    order.reserve(n);
+    std::vector<int32_t> chain_ptr;
+    std::vector<int> chain_colour;
+    auto begin_chain = [&](int key) {
+      chain_ptr.push_back((int32_t)order.size());
+      chain_colour.push_back(((key % ncol) + ncol) % ncol);
+    };
+    if (fam == 0) {
+      for (int i = 0; i < H; ++i) {
+        const size_t before = order.size();
+        for (int j = 0; j < W; ++j)
+          if (g.valid(i, j)) {
+            if (order.size() == before) begin_chain(i);
+            order.push_back((int32_t)g.id(i, j));
+          }
+      }
+    } else if (fam == 1) {
+      for (int j = 0; j < W; ++j) {
+        const size_t before = order.size();
+        for (int i = 0; i < H; ++i)
+          if (g.valid(i, j)) {
+            if (order.size() == before) begin_chain(j);
+            order.push_back((int32_t)g.id(i, j));
+          }
+      }
+    } else if (fam == 2) {
+      for (int d = -(H - 1); d <= W - 1; ++d) {
+        const size_t before = order.size();
+        for (int i = std::max(0, -d); i < H && i + d < W; ++i)
+          if (g.valid(i, i + d)) {
+            if (order.size() == before) begin_chain(d);
+            order.push_back((int32_t)g.id(i, i + d));
+          }
+      }
+    } else {
+      for (int a = 0; a <= H + W - 2; ++a) {
+        const size_t before = order.size();
+        for (int i = std::max(0, a - (W - 1)); i < H && i <= a; ++i)
+          if (g.valid(i, a - i)) {
+            if (order.size() == before) begin_chain(a);
+            order.push_back((int32_t)g.id(i, a - i));
+          }
+      }
+    }
+    chain_ptr.push_back((int32_t)order.size());
+    PHMRF_CHECK((int64_t)order.size() == n, PHMRF_ERR_INVALID, "internal: chain enumeration does not cover the block");
+    const int C = (int)chain_ptr.size() - 1;
+    int max_len = 0;
+    for (int c = 0; c < C; ++c) max_len = std::max(max_len, chain_ptr[c + 1] - chain_ptr[c]);
+    ChainFamily f;
+    f.n_chains = C;
+    f.n_colours = ncol;
+    f.max_len = max_len;
+    PHMRF_TRY(dev_alloc(&f.nodes, (size_t)n));
+    PHMRF_TRY(upload(f.nodes, order.data(), (size_t)n * sizeof(int32_t), b->stream));
+    for (int phase = 0; phase < 2; ++phase)
+      for (int col = 0; col < ncol; ++col) {
+        std::vector<int32_t> ss, sl;
+        for (int c = 0; c < C; ++c) {
+          if (chain_colour[c] != col) continue;
+          const int32_t p0 = chain_ptr[c], L = chain_ptr[c + 1] - chain_ptr[c];
+          // separators (fixed nodes) sit at chain positions 63, 127, ... (phase 0) or 31, 95, ... (phase 1)
+          int32_t start = 0;
+          int32_t sep = phase ? 31 : 63;
+          while (start < L) {
+            const int32_t end = std::min<int32_t>(sep, L);
+            if (end > start) {
+              ss.push_back(p0 + start);
+              sl.push_back(end - start);
+            }
+            start = sep + 1;
+            sep += 64;
+          }
+        }
+        f.nseg[phase][col] = (int)ss.size();
+        PHMRF_TRY(dev_alloc(&f.seg_start[phase][col], ss.size()));
+        PHMRF_TRY(dev_alloc(&f.seg_len[phase][col], sl.size()));
+        if (!ss.empty()) {
+          PHMRF_TRY(upload(f.seg_start[phase][col], ss.data(), ss.size() * sizeof(int32_t), b->stream));
+          PHMRF_TRY(upload(f.seg_len[phase][col], sl.data(), sl.size() * sizeof(int32_t), b->stream));
+        }
+      }
+    b->families.push_back(f);
+  }
+  b->H = H;
+  b->W = W;
+  b->diagonal = g.diagonal;
+  b->num_neighbor = num_neighbor;
+  b->has_grid = true;
+  return PHMRF_OK;
+}
 
 }  // namespace
 }  // namespace phmrf
@@ -218,6 +359,12 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->counters);
   if (b->accum_host) (void)hipHostFree(b->accum_host);
   if (b->counters_host) (void)hipHostFree(b->counters_host);
+  for (auto& p : b->pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (auto e : b->free_events) (void)hipEventDestroy(e);
+  if (b->cur_start) (void)hipEventDestroy(b->cur_start);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -374,94 +521,36 @@ int phmrf_block_set_grid(phmrf_block_t b, int H, int W, int diagonal, int num_ne
       PHMRF_CHECK(di <= 1 && dj <= 1 && (di + dj) > 0, PHMRF_ERR_INVALID, "edge list joins nodes that are not grid neighbours");
       PHMRF_CHECK(num_neighbor == 8 || (di + dj) == 1, PHMRF_ERR_INVALID, "diagonal edge in a 4-neighbour block");
     }
-  // ICM colours: 2x2 parity classes (oracle/mrf_moves.icm_colours)
-  {
-    std::vector<int64_t> cptr(5, 0);
-    for (int64_t v = 0; v < n; ++v) ++cptr[(ci[v] % 2) * 2 + (cj[v] % 2) + 1];
-    for (int c = 0; c < 4; ++c) cptr[c + 1] += cptr[c];
-    std::vector<int64_t> pos(cptr.begin(), cptr.end() - 1);
-    std::vector<int32_t> cnodes(n);
-    for (int64_t v = 0; v < n; ++v) cnodes[pos[(ci[v] % 2) * 2 + (cj[v] % 2)]++] = (int32_t)v;
-    PHMRF_TRY(upload(b->colour_nodes, cnodes.data(), cnodes.size() * sizeof(int32_t), b->stream));
-    b->n_colours = 4;
-    b->colour_ptr = cptr;
-  }
-  // chain families: 0 rows, 1 columns, 2 diagonals (y-x), 3 anti-diagonals (x+y)
-  for (auto& f : b->families) free_family(f);
-  b->families.clear();
-  const int nfam = num_neighbor == 8 ? 4 : 2;
-  for (int fam = 0; fam < nfam; ++fam) {
-    // key_chain, key_pos per node
-    std::vector<int64_t> key(n);
-    int ncol = fam < 2 ? 2 : 3;
-    for (int64_t v = 0; v < n; ++v) {
-      int kc, kp;
-      switch (fam) {
-        case 0: kc = ci[v]; kp = cj[v]; break;
-        case 1: kc = cj[v]; kp = ci[v]; break;
-        case 2: kc = cj[v] - ci[v] + H; kp = ci[v]; break;   // +H keeps the key non-negative
-        default: kc = ci[v] + cj[v]; kp = ci[v]; break;
-      }
-      key[v] = ((int64_t)kc << 32) | (uint32_t)kp;
-    }
-    std::vector<int32_t> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t c) { return key[a] < key[c]; });
-    std::vector<int32_t> chain_ptr;
-    std::vector<int> chain_colour;
-    int max_len = 0;
-    for (int64_t p = 0; p < n; ++p) {
-      const int64_t kc = key[order[p]] >> 32;
-      if (p == 0 || kc != (key[order[p - 1]] >> 32)) {
-        chain_ptr.push_back((int32_t)p);
-        int raw = (int)kc;
-        if (fam == 2) raw -= H;  // colour by (y - x) mod 3 like the oracle (python % is non-negative)
-        chain_colour.push_back(((raw % ncol) + ncol) % ncol);
-      }
-    }
-    chain_ptr.push_back((int32_t)n);
-    const int C = (int)chain_ptr.size() - 1;
-    for (int c = 0; c < C; ++c) max_len = std::max(max_len, chain_ptr[c + 1] - chain_ptr[c]);
-    ChainFamily f;
-    f.n_chains = C;
-    f.n_colours = ncol;
-    f.max_len = max_len;
-    PHMRF_TRY(dev_alloc(&f.nodes, (size_t)n));
-    PHMRF_TRY(upload(f.nodes, order.data(), (size_t)n * sizeof(int32_t), b->stream));
-    for (int phase = 0; phase < 2; ++phase)
-      for (int col = 0; col < ncol; ++col) {
-        std::vector<int32_t> ss, sl;
-        for (int c = 0; c < C; ++c) {
-          if (chain_colour[c] != col) continue;
-          const int32_t p0 = chain_ptr[c], L = chain_ptr[c + 1] - chain_ptr[c];
-          // separators (fixed nodes) sit at chain positions 63, 127, ... (phase 0) or 31, 95, ... (phase 1)
-          int32_t start = 0;
-          int32_t sep = phase ? 31 : 63;
-          while (start < L) {
-            const int32_t end = std::min<int32_t>(sep, L);
-            if (end > start) {
-              ss.push_back(p0 + start);
-              sl.push_back(end - start);
-            }
-            start = sep + 1;
-            sep += 64;
-          }
-        }
-        f.nseg[phase][col] = (int)ss.size();
-        PHMRF_TRY(dev_alloc(&f.seg_start[phase][col], ss.size()));
-        PHMRF_TRY(dev_alloc(&f.seg_len[phase][col], sl.size()));
-        if (!ss.empty()) {
-          PHMRF_TRY(upload(f.seg_start[phase][col], ss.data(), ss.size() * sizeof(int32_t), b->stream));
-          PHMRF_TRY(upload(f.seg_len[phase][col], sl.data(), sl.size() * sizeof(int32_t), b->stream));
-        }
-      }
-    b->families.push_back(f);
-  }
-  b->H = H;
-  b->W = W;
-  b->diagonal = diagonal;
-  b->num_neighbor = num_neighbor;
-  b->has_grid = true;
+  return setup_grid_tables(b, g, num_neighbor);
+}
+
+int phmrf_block_build_grid_graph(phmrf_block_t b, int H, int W, int diagonal, int num_neighbor, double beta1) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(b->has_X, PHMRF_ERR_STATE, "observations must be set before the graph is built from them");
+  PHMRF_CHECK(H >= 1 && W >= 1, PHMRF_ERR_INVALID, "H, W must be >= 1");
+  PHMRF_CHECK(num_neighbor == 8 || num_neighbor == 4, PHMRF_ERR_INVALID, "num_neighbor must be 8 or 4");
+  PHMRF_CHECK(!diagonal || H == W, PHMRF_ERR_INVALID, "a diagonal block must be square");
+  PHMRF_CHECK(beta1 >= 0.0 && std::isfinite(beta1), PHMRF_ERR_INVALID, "beta1 must be finite and >= 0");
+  Geometry g(H, W, diagonal);
+  PHMRF_CHECK(g.count() == b->n, PHMRF_ERR_INVALID, "H, W, diagonal do not match the node count");
+  dev_free(b->nbr);
+  dev_free(b->wgt);
+  PHMRF_TRY(dev_alloc(&b->nbr, (size_t)b->n * 8));
+  PHMRF_TRY(dev_alloc(&b->wgt, (size_t)b->n * 8));
+  b->D = 8;
+  PHMRF_TRY(launch_grid_graph(b, H, W, diagonal, num_neighbor, beta1));
+  if (!b->colour_nodes) PHMRF_TRY(dev_alloc(&b->colour_nodes, (size_t)b->n));
+  b->has_graph = true;
+  b->E = 0;
+  return setup_grid_tables(b, g, num_neighbor);
+}
+
+int phmrf_block_get_adjacency(phmrf_block_t b, int* D, int32_t* nbr_out, float* wgt_out) {
+  PHMRF_CHECK(b && D, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(b->has_graph, PHMRF_ERR_STATE, "graph not set");
+  *D = b->D;
+  if (nbr_out) PHMRF_TRY(download(nbr_out, b->nbr, (size_t)b->n * b->D * sizeof(int32_t), b->stream));
+  if (wgt_out) PHMRF_TRY(download(wgt_out, b->wgt, (size_t)b->n * b->D * sizeof(float), b->stream));
   return PHMRF_OK;
 }
 
@@ -698,10 +787,14 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
 }
 
 static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha) {
+  if (alpha < 0) {
+    tic(b);
+    PHMRF_TRY(launch_propose(b, beta));
+    toc(b, KC_PROPOSE, 1);
+  }
   tic(b);
-  if (alpha < 0) PHMRF_TRY(launch_propose(b, beta));
   PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha));
-  toc(b, KC_STRIP, alpha < 0 ? 2 : 1);
+  toc(b, KC_STRIP, 1);
   return PHMRF_OK;
 }
 
@@ -836,6 +929,7 @@ int phmrf_block_enable_timing(phmrf_block_t b, int enable) {
 
 int phmrf_block_get_timing(phmrf_block_t b, double* ms, int64_t* launches) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  resolve_timing(b);
   for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES; ++i) {
     if (ms) ms[i] = b->ms[i];
     if (launches) launches[i] = b->launches[i];
@@ -845,6 +939,7 @@ int phmrf_block_get_timing(phmrf_block_t b, double* ms, int64_t* launches) {
 
 int phmrf_block_reset_timing(phmrf_block_t b) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  resolve_timing(b);
   for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES; ++i) {
     b->ms[i] = 0;
     b->launches[i] = 0;

@@ -34,7 +34,7 @@ int fail(int status, const std::string& msg);
   } while (0)
 
 // ---- kernel classes for the built-in timers (phmrf.h) -------------------------------------------
-enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5, KC_STRIP = 6 };
+enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5, KC_STRIP = 6, KC_PROPOSE = 7 };
 
 // A chain family (grid rows / columns / diagonals / anti-diagonals): `nodes` lists node ids chain after
 // chain in chain order.  Chains of one colour share no edge.  Every chain is cut into SEGMENTS of at most
@@ -100,9 +100,13 @@ struct phmrf_block {
   unsigned long long* counters = nullptr;   // device [8]
   unsigned long long* counters_host = nullptr;
 
-  // timing
+  // timing: event pairs recorded on the block's stream, resolved lazily (no host sync inside the measured loop)
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  struct Pending { int kclass; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  hipEvent_t cur_start = nullptr;
   double ms[PHMRF_NUM_KERNEL_CLASSES] = {};
   int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {};
 };
@@ -126,6 +130,7 @@ int launch_energy(const phmrf_block* b, float beta);  // -> accum[0]=unary, accu
 int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors);
 int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase);
 int launch_component_pass(phmrf_block* b, float beta);
+int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, double beta1);
 int launch_propose(const phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha);  // adds relabelled nodes to counters[0]
 

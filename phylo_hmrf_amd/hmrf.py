@@ -1,0 +1,267 @@
+"""`phyloHMRF` with the reference's constructor / fit / predict surface (phylo_hmrf.py:51-1528), E-step on MI355X.
+
+Per syntenic block one `Block` holds X, the neighbour graph, logprob and labels in HBM for the whole fit
+(the reference recomputes / re-pickles them per iteration, base.py:357-372).  Kept names and return shapes:
+  _compute_log_likelihood(X)                                  phylo_hmrf.py:266-268
+  predict(X, region_id) -> (state, logprob)                   :470-484
+  _estimate_state_graphcuts_gco(X, init, edges, weights)      :486-507   (GPU label solver instead of pygco/gco)
+  _compute_posteriors_graph(X, label, logprob, region_id)     :334-355
+  _predict_posteriors(X, len_vec, region_id, m_queue=None)    :297-322
+  _ou_param_varied_constraint(params_vec), _do_mstep(stats), _init(X), fit_accumulate_test(...)
+"""
+from __future__ import print_function
+
+import numpy as np
+
+from . import mstep as _mstep
+from .base import SLOT_BEST3, SLOT_LOCAL, _BaseGraph
+from .block import Block
+from .dist import Reducer, env_rank_world, lpt_assign
+from .tree import PhyloTree
+
+COVARIANCE_TYPES = frozenset(("linear", "spherical", "diag", "full", "tied"))
+
+
+class phyloHMRF(_BaseGraph):
+
+    def __init__(self, n_samples, n_features, edge_list, branch_list, cons_param, beta, beta1,
+                 initial_mode, initial_weight, initial_weight1, initial_magnitude, observation,
+                 edge_list_1, len_vec, type_id=0, max_iter=10, n_components=1, run_id=0, estimate_type=0,
+                 covariance_type="full", min_covar=1e-3, startprob_prior=1.0, transmat_prior=1.0,
+                 means_prior=0, means_weight=0, covars_prior=1e-2, covars_weight=1, algorithm="viterbi",
+                 random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
+                 learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
+                 solver_opts=None, mstep_workers=None, quiet=False, device_graph=False):
+        _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
+                            startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
+                            random_state=random_state, n_iter=n_iter, tol=tol, params=params, verbose=verbose,
+                            init_params=init_params)
+        if covariance_type not in COVARIANCE_TYPES:
+            raise ValueError("covariance_type must be one of {0}".format(COVARIANCE_TYPES))
+        self.quiet = quiet
+        self.covariance_type = covariance_type
+        self.min_covar = min_covar
+        self.max_iter = max_iter
+        self.beta = beta              # Potts coefficient (phylo_hmrf.py:84)
+        self.beta1 = beta1            # edge-weight decay w = exp(-beta1*d) (:85, :585)
+        self.type_id = type_id
+        self.observation = observation
+        self.n_samples = n_samples
+        self.n_features = n_features
+        self.learning_rate = learning_rate
+        self.edge_list_vec = edge_list_1
+        self.len_vec = [list(map(int, lv)) for lv in np.asarray(len_vec).tolist()]
+        self.num_neighbor = num_neighbor
+        self.edge_potential = self._pairwise_potential()
+        self.rng = np.random.default_rng(random_state)
+        self.solver_opts = dict(max_rounds=64, use_chains=True, use_components=True, use_strips=True, use_expansion=True)
+        if solver_opts:
+            self.solver_opts.update(solver_opts)
+        self.mstep_workers = mstep_workers
+
+        # species tree tables (phylo_hmrf.py:103-143)
+        self.tree = PhyloTree(edge_list)
+        self.node_num = self.tree.node_num
+        self.branch_params = branch_list
+        self.branch_dim = self.tree.branch_dim
+        self.n_params = self.tree.n_params
+        self.leaf_vec = self.tree.leaf_vec
+        if self.tree.n_features != n_features:
+            raise ValueError("tree has %d leaves but n_features is %d" % (self.tree.n_features, n_features))
+        self.params_vec1 = self.rng.random((n_components, self.n_params))     # :109
+        self.init_ou_params = self.params_vec1.copy()
+        self.lambda_0 = cons_param                                             # :145
+        self.initial_mode, self.initial_w1, self.initial_w1a, self.initial_w2 = (
+            initial_mode, initial_weight, initial_weight1, initial_magnitude)
+        self.stats = dict()
+
+        # ranks and block ownership
+        env_rank, env_world, _ = env_rank_world()
+        self.world = env_world if world is None else world
+        self.rank = env_rank if rank is None else rank
+        self.reducer = reducer if reducer is not None else Reducer(self.world)
+        sizes = [lv[0] for lv in self.len_vec]
+        self.owner = lpt_assign(sizes, self.world)
+        self.my_regions = [r for r in range(len(self.len_vec)) if self.owner[r] == self.rank]
+
+        # device-resident blocks (the reference's _edge_weight_undirected_vec, :567-598, happens here once)
+        factory = block_factory or Block
+        self.blocks = {}
+        X = np.asarray(observation)
+        for r in self.my_regions:
+            lv = self.len_vec[r]
+            n, s1, s2, H, W = lv[0], lv[1], lv[2], lv[3], lv[4]
+            diag = bool(lv[8]) if len(lv) > 8 else (H == W and n == H * (H + 1) // 2)
+            b = factory(n, n_features, n_components)
+            b.set_observations(X[s1:s2])
+            grid_ok = (n == (H * (H + 1) // 2 if diag else H * W)) and num_neighbor in (4, 8)
+            if device_graph and grid_ok:
+                b.build_grid_graph(H, W, diag, num_neighbor, beta1)
+            else:
+                e = np.asarray(edge_list_1[r])
+                w = np.exp(-beta1 * e[:, 2])                                    # :585
+                b.set_graph(np.int64(e[:, 0:2]), w)                             # :589
+                if grid_ok:
+                    try:
+                        b.set_grid(H, W, diag, num_neighbor)
+                    except Exception:
+                        pass       # an edge list that is not the grid stencil: general-graph moves only
+            self.blocks[r] = b
+
+    # ---- properties the reference exposes --------------------------------------------------------
+    def _get_covars(self):
+        return self._covars_
+
+    def _set_covars(self, covars):
+        self._covars_ = np.asarray(covars).copy()
+
+    covars_ = property(_get_covars, _set_covars)
+
+    def _pairwise_potential(self):
+        """beta * (1 - delta)  (phylo_hmrf.py:524-536)."""
+        V = np.full((self.n_components, self.n_components), float(self.beta))
+        np.fill_diagonal(V, 0.0)
+        self.edge_potential = V
+        return V
+
+    def _check(self):
+        super(phyloHMRF, self)._check()
+        self.means_ = np.asarray(self.means_)
+        self.n_features = self.means_.shape[1]
+
+    # ---- initialisation (phylo_hmrf.py:205-264) --------------------------------------------------
+    def _init(self, X, lengths=None):
+        super(phyloHMRF, self)._init(X, lengths=lengths)
+        from sklearn import cluster
+        X = np.asarray(X)
+        n_samples, n_features = X.shape
+        seed = None if self.random_state is None else int(self.random_state)
+        kmeans = cluster.MiniBatchKMeans(n_clusters=self.n_components, random_state=seed, batch_size=2000,
+                                         max_iter=1000, n_init=10)              # :234-236
+        kmeans.fit(X)
+        self.means_ = kmeans.cluster_centers_
+        init_label = kmeans.labels_
+        self._log("initialize parameters...")
+        self.init_ou_params = _mstep.init_ou_params(self.tree, X, init_label, self.means_, self.params_vec1,
+                                                    self.initial_w2, self.rng, workers=self.mstep_workers)   # :246
+        self.params_vec1 = self.init_ou_params.copy()
+        self.init_label = np.int64(init_label)
+        self.labels = self.init_label.copy()
+        self.labels_local = self.init_label.copy()
+        self._upload_labels(self.init_label)
+        cv = np.cov(X.T) + self.min_covar * np.eye(n_features)                  # :258
+        self._covars_ = np.tile(np.atleast_2d(cv), (self.n_components, 1, 1))   # :261-262
+        self._log("return from initializing parameters...")
+
+    def _upload_labels(self, labels):
+        for r in self.my_regions:
+            s1, s2 = self.len_vec[r][1], self.len_vec[r][2]
+            self.blocks[r].set_labels(np.asarray(labels[s1:s2]))
+            self.blocks[r].save_labels(SLOT_LOCAL)
+
+    def _snapshot_labels(self, slot):
+        for r in self.my_regions:
+            self.blocks[r].save_labels(slot)
+
+    def _gather_labels(self, slot):
+        out = np.zeros(self.n_samples)
+        for r in self.my_regions:
+            s1, s2 = self.len_vec[r][1], self.len_vec[r][2]
+            out[s1:s2] = self.blocks[r].get_saved_labels(slot)
+        if self.world > 1:
+            out = self.reducer.allreduce(out)
+        return out
+
+    # ---- b1 --------------------------------------------------------------------------------------
+    def _compute_log_likelihood(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        b = Block(X.shape[0], X.shape[1], self.n_components)
+        try:
+            b.set_observations(X)
+            b.emission(self.means_, self._covars_)
+            return b.get_logprob()
+        finally:
+            b.close()
+
+    # ---- b2 --------------------------------------------------------------------------------------
+    def predict(self, X, region_id):
+        """labels and emission log-likelihoods of one region, warm-started from labels_local (:470-484)."""
+        b = self.blocks[region_id]
+        b.restore_labels(SLOT_LOCAL)
+        b.emission(self.means_, self._covars_)
+        b.solve_fast(self.beta, **self.solver_opts)
+        return b.get_labels(), b.get_logprob()
+
+    def _estimate_state_graphcuts_gco(self, X, init_labels1, edge_idList_undirected, edge_weightList_undirected):
+        """Drop-in for the pygco call (:486-507) on an arbitrary graph: GPU label solver, general-graph moves."""
+        from .pygco_compat import cut_general_graph
+        logprob = self._compute_log_likelihood(X)
+        labels = cut_general_graph(edge_idList_undirected, edge_weightList_undirected, -logprob, self.edge_potential,
+                                   n_iter=5000, algorithm="swap", init_labels=init_labels1)
+        return labels, logprob
+
+    # ---- b3 --------------------------------------------------------------------------------------
+    def _compute_posteriors_graph(self, X, label, logprob, region_id):
+        b = self.blocks[region_id]
+        b.set_logprob(logprob)
+        b.set_labels(label)
+        _, costs, post = b.posterior_stats(self.beta, self.estimate_type, want_posteriors=True)
+        n = float(len(label))
+        return post, costs[0] / n, costs[1] / n, costs[2] / n, costs[3] / n
+
+    def _estep_region(self, region_id):
+        b = self.blocks[region_id]
+        b.restore_labels(SLOT_LOCAL)                     # init_labels = labels_local[id1:id2]  (:479)
+        b.emission(self.means_, self._covars_)
+        b.solve_fast(self.beta, **self.solver_opts)
+        stats, costs, _ = b.posterior_stats(self.beta, self.estimate_type)
+        return stats, costs
+
+    def _predict_posteriors(self, X, len_vec, region_id, m_queue=None):
+        """(region_id, stats, labels, pairwise_cost, pairwise_cost_normalize, unary_cost, cost1)  (:297-322)."""
+        stats, costs = self._estep_region(region_id)
+        n = float(len_vec[region_id][0])
+        out = (region_id, stats, self.blocks[region_id].get_labels(), costs[0] / n, costs[1] / n, costs[2] / n, costs[3] / n)
+        if m_queue is not None:
+            m_queue.put(out)
+            return True
+        return out
+
+    # ---- OU parameters <-> Gaussians -------------------------------------------------------------
+    def _ou_param_varied_constraint(self, params_vec):
+        """means_[c], _covars_[c] = OU(params_vec[c]) + min_covar*I   (:985-1036)."""
+        self.means_, self._covars_ = self.tree.mean_cov(np.asarray(params_vec), self.min_covar)
+        return True
+
+    def _check_params(self, params):
+        return _mstep.check_params(self.tree, params)
+
+    def _ou_lik_varied_constraint(self, params, state_id):
+        obj = _mstep.OUObjective(self.tree, self.stats["post"][state_id], self.stats["obs"][state_id],
+                                 self.stats["obs*obs.T"][state_id], self.n_samples, self.lambda_0, self.min_covar)
+        if _mstep.check_params(self.tree, params) <= -2:                        # :1042-1047
+            params = self.init_ou_params[state_id].copy()
+        return obj.value(np.asarray(params, dtype=np.float64))
+
+    def _do_mstep(self, stats):
+        self.stats = {k: np.array(v, copy=True) for k, v in stats.items() if k in ("post", "obs", "obs*obs.T")}
+        if self.world > 1 and self.rank != 0:
+            packed = np.zeros(self.n_components * (self.n_params + self.n_features + self.n_features ** 2))
+        else:
+            params, means, covars, lik = _mstep.do_mstep(
+                self.tree, self.stats, self.params_vec1, self.init_ou_params, self.n_samples, self.lambda_0,
+                self.initial_mode, self.initial_w1, self.initial_w1a, self.initial_w2, self.rng, self.min_covar,
+                workers=self.mstep_workers)
+            self.lik = lik[-1]
+            packed = np.concatenate([params.ravel(), means.ravel(), covars.ravel()])
+        if self.world > 1:      # rank 0 draws the random restarts (:1372-1380); everyone receives its result
+            packed = self.reducer.broadcast(packed, src=0)
+        K, P, S = self.n_components, self.n_params, self.n_features
+        self.params_vec1 = packed[:K * P].reshape(K, P).copy()
+        self.means_ = packed[K * P:K * P + K * S].reshape(K, S).copy()
+        self._covars_ = packed[K * P + K * S:].reshape(K, S, S).copy()
+
+    def close(self):
+        for b in self.blocks.values():
+            b.close()
+        self.blocks = {}

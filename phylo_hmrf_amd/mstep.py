@@ -1,0 +1,275 @@
+"""Host M-step: per state, fit the 3B+2 Ornstein-Uhlenbeck parameters to the sufficient statistics.
+
+Semantics of the reference (phylo_hmrf.py:1500-1528 `_do_mstep`, :1327-1403 `_ou_optimize2(_unit)`,
+:1038-1138 `_ou_lik_varied_constraint`, :1405-1425 `_check_params`):
+
+    minimise  f(p) = N_c * log(det V + 1e-16) / n + tr(V^-1 S_w) / n + lambda_0 / sqrt(n) * |p|^2
+    V   = cov_OU(p) + min_covar * I
+    S_w = obs*obs.T - obs mu^T - mu obs^T + mu mu^T N_c            (N_c = post[c], mu = leaf means)
+    s.t. 1e-16 <= p_i <= 100   for every parameter (:1365-1366), SciPy SLSQP, tol 1e-6,
+    start = a1 * init_ou_params + a2 * current + (1 - a1 - a2) * random     (:1378-1380)
+
+What differs from the reference is speed only (once the E-step takes milliseconds the K
+SLSQP runs cap the EM rate): the objective comes with its ANALYTIC gradient (reverse sweep over the tree), the
+box is passed as `bounds`, and the K independent states are solved in a fork pool.
+"""
+import multiprocessing as mp
+import os
+
+import numpy as np
+from scipy.optimize import minimize
+
+SMALL_EPS = 1e-16          # phylo_hmrf.py:49
+LOWER, UPPER = SMALL_EPS, 100.0
+
+
+def check_params(tree, params):
+    """`_check_params` (phylo_hmrf.py:1405-1425): 1 ok, -1 out of bounds, -2 out of bounds with NaN."""
+    _, beta, lam, theta = tree.split(params)
+    ok1 = (beta >= 0) & (beta <= 100) & (lam >= 0) & (lam <= 100)
+    ok2 = (theta >= -100) & (theta <= 100)
+    if ok1.sum() < tree.branch_dim or ok2.sum() < tree.branch_dim + 1:
+        return -2 if np.isnan(np.asarray(params)[1:]).any() else -1
+    return 1
+
+
+class OUObjective(object):
+    """f(p) and its gradient for one state.  post: N_c; obs: [S]; obsobsT: [S,S]."""
+
+    def __init__(self, tree, post, obs, obsobsT, n_samples, lambda_0, min_covar=1e-3):
+        self.t = tree
+        self.post = float(post)
+        self.obs = np.asarray(obs, dtype=np.float64)
+        self.oo = np.asarray(obsobsT, dtype=np.float64)
+        self.n = float(n_samples)
+        self.reg = float(lambda_0) / np.sqrt(self.n)                                  # :1100-1102, :1113
+        self.min_covar = min_covar
+        self.last_V = None
+        self.last_mean = None
+
+    def _model(self, p):
+        t = self.t
+        mean, var, e, ratio = t.node_moments(p)
+        _, beta, lam, theta = t.split(p)
+        beta_full = np.concatenate([[0.0], beta])
+        s1 = t.A2 @ beta_full
+        ex = np.exp(-s1)
+        S = t.n_features
+        cov = np.zeros((S, S))
+        s2 = var[t.pair_anc] * ex
+        cov[t.pair_a, t.pair_b] = s2
+        cov[t.pair_b, t.pair_a] = s2
+        cov[np.arange(S), np.arange(S)] = var[t.leaf_vec]
+        return mean, var, e, ratio, ex, s2, cov
+
+    def value(self, p):
+        return self.value_and_grad(p, want_grad=False)[0]
+
+    def value_and_grad(self, p, want_grad=True):
+        t = self.t
+        p = np.asarray(p, dtype=np.float64)
+        S = t.n_features
+        mean, var, e, ratio, ex, s2, cov = self._model(p)
+        V = cov + self.min_covar * np.eye(S)                                          # :1090
+        mu = mean[t.leaf_vec]
+        # ill-conditioned V: add min_covar*I up to 10 times, then fall back to the pseudo-inverse (:1108-1133)
+        cnt = 0
+        while not (np.linalg.cond(V) < 1.0 / np.finfo(float).eps) and cnt < 10:
+            V = V + self.min_covar * np.eye(S)
+            cnt += 1
+        well = np.linalg.cond(V) < 1.0 / np.finfo(float).eps
+        Vi = np.linalg.inv(V) if well else np.linalg.pinv(V)
+        om = np.outer(self.obs, mu)
+        Sw = self.oo - om - om.T + np.outer(mu, mu) * self.post                       # :1093-1097
+        detV = np.linalg.det(V)
+        f = self.post * np.log(detV + SMALL_EPS) / self.n + np.sum(Vi * Sw) / self.n + self.reg * float(p @ p)
+        self.last_V, self.last_mean = V, mu                                           # self.cv_mtx / self.values (:1135-1136)
+        if not want_grad:
+            return f, None
+        # ---- reverse sweep ------------------------------------------------------------------------------
+        G = (self.post * (detV / (detV + SMALL_EPS)) * Vi - Vi @ Sw @ Vi) / self.n    # df/dV (symmetric)
+        gmu = 2.0 * (Vi @ (self.post * mu - self.obs)) / self.n                       # df/dmu
+        N, B = t.node_num, t.branch_dim
+        gvar = np.zeros(N)
+        gmean = np.zeros(N)
+        gbeta_full = np.zeros(N)
+        ge = np.zeros(N)
+        gratio = np.zeros(N)
+        gtheta = np.zeros(N)
+        gvar[t.leaf_vec] += np.diag(G)
+        gmean[t.leaf_vec] += gmu
+        gpair = 2.0 * G[t.pair_a, t.pair_b]                                           # V_ab appears twice
+        np.add.at(gvar, t.pair_anc, gpair * ex)
+        gbeta_full += t.A2.T @ (-gpair * s2)
+        for i in reversed(t.order):
+            pa = t.parent[i]
+            gvar[pa] += gvar[i] * e[i] ** 2
+            gratio[i] += gvar[i] * (1.0 - e[i] ** 2)
+            ge[i] += gvar[i] * (2.0 * e[i] * (var[pa] - ratio[i]))
+            gmean[pa] += gmean[i] * e[i]
+            gtheta[i] += gmean[i] * (1.0 - e[i])
+            ge[i] += gmean[i] * (mean[pa] - p[1 + 2 * B + i])
+        _, beta, lam, theta = t.split(p)
+        gb = gbeta_full[1:] - ge[1:] * e[1:]
+        ok = beta > 1e-07
+        safe_beta = np.where(ok, beta, 1.0)
+        glam = np.where(ok, gratio[1:] / (2.0 * safe_beta), 0.0)
+        gb = gb + np.where(ok, -gratio[1:] * lam / (2.0 * safe_beta ** 2), 0.0)
+        roots = np.flatnonzero(t.parent < 0)
+        gtheta[roots] += gmean[roots]
+        g = np.concatenate([[gvar[roots].sum()], gb, glam, gtheta]) + 2.0 * self.reg * p
+        return f, g
+
+
+class OUObjectiveSingle(OUObjective):
+    """`_ou_lik_varied_single` (phylo_hmrf.py:1246-1325): log det V + tr(V^-1 S) on one cluster's sample moments,
+    no ridge term; used by the initialisation (:1427-1498)."""
+
+    def __init__(self, tree, X, min_covar=1e-3):
+        X = np.asarray(X, dtype=np.float64)
+        n = X.shape[0]
+        OUObjective.__init__(self, tree, 1.0, X.mean(axis=0), X.T @ X / n, 1.0, 0.0, min_covar)
+
+
+def _solve_state(args):
+    tree, post, obs, oo, n_samples, lambda_0, guesses, init_params = args
+    obj = OUObjective(tree, post, obs, oo, n_samples, lambda_0)
+    bounds = [(LOWER, UPPER)] * tree.n_params
+    flag, flag1, params1 = 0, -1, init_params
+    for guess in guesses:                                                             # retry loop (:1332-1342)
+        x0 = np.clip(guess, LOWER, UPPER)
+        try:
+            res = minimize(obj.value_and_grad, x0, jac=True, method="SLSQP", bounds=bounds, tol=1e-6,
+                           options={"disp": False, "maxiter": 200})
+            params1 = res.x
+        except Exception:                                                             # (:1386-1392)
+            continue
+        flag = check_params(tree, params1)
+        flag1 = flag
+        if flag > 0:
+            break
+    if not (flag > 0 and flag1 > 0):                                                  # (:1346-1349)
+        params1 = np.array(init_params, dtype=np.float64)
+    lik = obj.value(params1)
+    return params1, lik, obj.last_mean.copy(), obj.last_V.copy()
+
+
+_POOL = None
+_POOL_SIZE = 0
+
+
+def _pool(workers):
+    global _POOL, _POOL_SIZE
+    if workers <= 1:
+        return None
+    if _POOL is None or _POOL_SIZE != workers:
+        if _POOL is not None:
+            _POOL.terminate()
+        _POOL = mp.get_context("fork").Pool(workers)
+        _POOL_SIZE = workers
+    return _POOL
+
+
+def close_pool():
+    global _POOL
+    if _POOL is not None:
+        _POOL.terminate()
+        _POOL = None
+
+
+def do_mstep(tree, stats, params_cur, init_ou_params, n_samples, lambda_0, initial_mode, w1, w1a, w2, rng,
+             min_covar=1e-3, workers=None, retries=3):
+    """`_do_mstep` (phylo_hmrf.py:1500-1528) for all K states.
+    -> params[K,3B+2], means[K,S], covars[K,S,S] (= V + min_covar*I as at :1524), lik[K]."""
+    K = params_cur.shape[0]
+    P = tree.n_params
+    N = tree.node_num
+    tasks = []
+    for c in range(K):
+        guesses = []
+        for _ in range(retries):
+            if initial_mode == 1:                                                     # (:1371-1376)
+                r = 2.0 * rng.random(P) - 1.0
+                r[0:P - N] = rng.random(P - N)
+                r = w2 * r
+            else:
+                r = w2 * rng.random(P)
+            guesses.append(w1 * init_ou_params[c] + w1a * params_cur[c] + (1.0 - w1 - w1a) * r)   # (:1378-1380)
+        tasks.append((tree, stats["post"][c], stats["obs"][c], stats["obs*obs.T"][c], n_samples, lambda_0, guesses,
+                      init_ou_params[c]))
+    if workers is None:
+        workers = min(K, os.cpu_count() or 1)
+    pool = _pool(workers)
+    out = pool.map(_solve_state, tasks) if pool is not None else [_solve_state(t) for t in tasks]
+    S = tree.n_features
+    params = np.zeros((K, P))
+    means = np.zeros((K, S))
+    covars = np.zeros((K, S, S))
+    lik = np.zeros(K)
+    for c, (p, l, mu, V) in enumerate(out):
+        params[c], lik[c], means[c] = p, l, mu
+        covars[c] = V + min_covar * np.eye(S)                                         # (:1524)
+    return params, means, covars, lik
+
+
+def ou_init_guess(tree, mean_values, w2, rng):
+    """`_ou_init_guess` (phylo_hmrf.py:1453-1480): random start with node means propagated up from the leaves."""
+    P, N = tree.n_params, tree.node_num
+    guess = w2 * rng.random(P)
+    mv = np.zeros(N)
+    flag = np.zeros(N)
+    mv[tree.leaf_vec] = mean_values
+    flag[tree.leaf_vec] = 2
+    for j in range(N - 1, 0, -1):
+        p = tree.parent[j]
+        if flag[p] == 0:
+            mv[p] = mv[j]
+            flag[p] += 1
+        elif flag[p] == 1:
+            mv[p] = 0.5 * mv[p] + 0.5 * mv[j]
+            flag[p] += 1
+    guess[P - N:P] = mv
+    return guess
+
+
+def _init_state(args):
+    tree, X, guesses = args
+    obj = OUObjectiveSingle(tree, X)
+    bounds = [(LOWER, UPPER)] * tree.n_params
+    params1, flag = guesses[-1], -1
+    for guess in guesses[:-1]:
+        try:
+            res = minimize(obj.value_and_grad, np.clip(guess, LOWER, UPPER), jac=True, method="SLSQP", bounds=bounds,
+                           tol=1e-6, options={"disp": False, "maxiter": 200})
+        except Exception:
+            continue
+        params1 = res.x
+        flag = check_params(tree, params1)
+        if flag > 0:
+            break
+    if flag <= 0:
+        params1 = guesses[-1]                                                          # (:1446-1448)
+    return params1, obj.value(params1)
+
+
+def init_ou_params(tree, X, init_label, means, params_default, w2, rng, workers=None, max_per_cluster=200000):
+    """`_init_ou_param` (phylo_hmrf.py:184-203): per k-means cluster, fit the OU parameters to that cluster."""
+    K = params_default.shape[0]
+    out = params_default.copy()
+    tasks, idx = [], []
+    for c in range(K):
+        b = np.flatnonzero(init_label == c)
+        if b.shape[0] == 0:
+            continue                                                                  # "empty cluster!" (:191-192)
+        if b.shape[0] > max_per_cluster:
+            b = rng.choice(b, max_per_cluster, replace=False)
+        guesses = [ou_init_guess(tree, means[c], w2, rng) for _ in range(4)]
+        tasks.append((tree, X[b], guesses))
+        idx.append(c)
+    if workers is None:
+        workers = min(max(len(tasks), 1), os.cpu_count() or 1)
+    pool = _pool(workers)
+    res = pool.map(_init_state, tasks) if pool is not None else [_init_state(t) for t in tasks]
+    for c, (p, _) in zip(idx, res):
+        out[c] = p
+    return out

@@ -415,6 +415,41 @@ def test_posterior_stats_oracle(S, K, N):
     b.close()
 
 
+# ------------------------------------------------------------------------------------------------ graph
+@pytest.mark.parametrize("H,W,diagonal,nn", [(61, 61, True, 8), (40, 77, False, 8), (33, 33, True, 4), (1, 50, False, 8), (300, 5, False, 4)])
+def test_device_graph_matches_reference_edge_builder(H, W, diagonal, nn):
+    """phmrf_block_build_grid_graph vs the restated utility.py:1871-2053 edge builder + exp(-beta1 d)."""
+    rng = np.random.default_rng(H * 7 + W)
+    n = H * (H + 1) // 2 if diagonal else H * W
+    X = np.abs(rng.standard_normal((n, 4))) + 0.01
+    X[3] = 0.0                                   # a zero-norm node: the 1e-16 guard (utility.py:1939)
+    e = R.grid_edges(X.astype(np.float32).astype(np.float64), H, W, diagonal, nn)
+    w, eid = R.edge_weights_from_distance(e, 0.5)
+    a = _block(n, 4, 3)
+    a.set_observations(X)
+    a.set_graph(eid, w)
+    a.set_grid(H, W, diagonal, nn)
+    nbr_a, wgt_a = a.get_adjacency()
+    b = _block(n, 4, 3)
+    b.set_observations(X)
+    b.build_grid_graph(H, W, diagonal, nn, 0.5)
+    nbr_b, wgt_b = b.get_adjacency()
+    D = min(nbr_a.shape[1], nbr_b.shape[1])
+    assert np.array_equal(nbr_a[:, :D], nbr_b[:, :D])
+    assert np.all(nbr_a[:, D:] == -1) and np.all(nbr_b[:, D:] == -1)
+    np.testing.assert_allclose(wgt_a[:, :D], wgt_b[:, :D], rtol=2e-6, atol=1e-7)
+    # and the moves built on it behave identically on an exactly representable problem
+    lp = -rng.integers(0, 9, (n, 3)).astype(np.float64)
+    init = rng.integers(0, 3, n)
+    for blk in (a, b):
+        blk.set_logprob(lp)
+        blk.set_labels(init)
+    ra, rb = a.solve(1.0), b.solve(1.0)
+    np.testing.assert_allclose(ra["energy"], rb["energy"], rtol=1e-5)
+    a.close()
+    b.close()
+
+
 # ------------------------------------------------------------------------------------------------ api
 def test_error_paths_and_label_slots():
     from phylo_hmrf_amd import PhmrfError
