@@ -80,8 +80,14 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     const int ncell = ncols * SH;
 
     // ---- phase 1: lane <-> cell: unary costs against the fixed outside, weights / label relations to the four
-    //      already-visited in-strip neighbours
-    for (int t = lane; t < ncell; t += 64) {
+    //      already-visited in-strip neighbours.  A cell whose unary loss exceeds the total weight of its edges can
+    //      never be part of an improving move (adding it to ANY switched set raises the energy), so it is pinned
+    //      (c1 = BIG) and the DP only has to span the pinned-free range [t_lo, t_hi + SH + 1].
+    int t_lo = NCELL_MAX, t_hi = -1;
+    for (int t0 = 0; t0 < ncell; t0 += 64) {
+      const int t = t0 + lane;
+      bool sw = false;
+      if (t < ncell) {
       const int cc = t / SH, rr = t - cc * SH;
       const int sr = rs0 + rr, sc = ca + cc;
       const int node = strip_node(g, sr, sc);
@@ -105,10 +111,13 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
         c1 = can ? -logprob[(int64_t)node * K + p] : BIG;
         const int32_t* nb = nbr + (int64_t)node * D;
         const float* wg = wgt + (int64_t)node * D;
+        float wtot = 0.f;
+        const float du = c1 - c0;
         for (int j = 0; j < D; ++j) {
           const int c = nb[j];
           if (c < 0) continue;
           const float w = beta * wg[j];
+          wtot += w;
           int q = 8;
 #pragma unroll
           for (int z = 0; z < 8; ++z)
@@ -130,19 +139,32 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
             bits |= nib << (4 * q);
           }
         }
+        sw = can && !(du > wtot);
+        if (!sw) c1 = BIG;
       }
       float* r = rec + t * REC;
       r[0] = c0; r[1] = c1; r[2] = w4[0]; r[3] = w4[1]; r[4] = w4[2]; r[5] = w4[3];
       reci[t * REC + 6] = bits;
       reci[t * REC + 7] = node;
+      }
+      const unsigned long long swm = __ballot(sw);
+      if (swm) {
+        const int first = t0 + __ffsll((long long)swm) - 1;
+        const int last = t0 + 63 - __clzll((long long)swm);
+        t_lo = first < t_lo ? first : t_lo;
+        t_hi = last > t_hi ? last : t_hi;
+      }
     }
+    const bool need = t_hi >= 0;
+    int t_end = t_hi + SH + 1;
+    if (t_end > ncell - 1) t_end = ncell - 1;
     __syncthreads();
 
     // ---- phase 2: lane <-> state (6 profile bits)
-    float m = 0.f;
+    float m = lane == 0 ? 0.f : BIG;      // every cell before t_lo keeps its label: profile 000000
     const int b = lane & 1, pl = lane >> 1;
     const int bu = pl & 1, bl = (pl >> 4) & 1, bld = (pl >> 3) & 1;
-    for (int t = 0; t < ncell; ++t) {
+    for (int t = need ? t_lo : ncell; t <= t_end; ++t) {
       const float4 ra = *reinterpret_cast<const float4*>(rec + t * REC);
       const float4 rb = *reinterpret_cast<const float4*>(rec + t * REC + 4);
       const int bits = __builtin_bit_cast(int, rb.z);
@@ -164,10 +186,10 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     __syncthreads();
 
     // ---- backtrack (wave-uniform scalars); the choice bit of cell t replaces the neighbour-relation word
-    if (ncell > 0) {
+    if (need) {
       const float mmin = wave_min_f32(m);
       int s = __ffsll((long long)__ballot(m == mmin)) - 1;
-      for (int t = ncell - 1; t >= 0; --t) {
+      for (int t = t_end; t >= t_lo; --t) {
         const int x = s & 1;
         const int d = (int)((bal[t] >> s) & 1ull);
         s = (s >> 1) | (d << 5);
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     __syncthreads();
 
     // ---- phase 3: lane <-> cell: apply
-    for (int t = lane; t < ncell; t += 64) {
+    for (int t = (need ? t_lo : ncell) + lane; t <= t_end; t += 64) {
       const int node = reci[t * REC + 7];
       if (node >= 0 && reci[t * REC + 6]) {
         labels[node] = prop ? prop[node] : (uint8_t)alpha;

@@ -124,6 +124,16 @@ class phyloHMRF(_BaseGraph):
         self.edge_potential = V
         return V
 
+    def _initialize_sufficient_statistics(self):
+        """phylo_hmrf.py:691-698."""
+        stats = super(phyloHMRF, self)._initialize_sufficient_statistics()
+        K, S = self.n_components, self.n_features
+        stats["post"] = np.zeros(K)
+        stats["obs"] = np.zeros((K, S))
+        stats["obs**2"] = np.zeros((K, S))
+        stats["obs*obs.T"] = np.zeros((K, S, S))
+        return stats
+
     def _check(self):
         super(phyloHMRF, self)._check()
         self.means_ = np.asarray(self.means_)

@@ -1,0 +1,127 @@
+"""CPU: host logic of the EM driver (phylo_hmrf_amd/base.py, hmrf.py) with the oracle-backed test double.
+
+ * the reference's own 8-iteration trace (tests/golden/em_trace.npz: cost_vec, iteration ids, t_labels, parameter
+   snapshots recorded from the reference's fit_accumulate_test with a fixed M-step schedule) is reproduced when the
+   labelling step is the reference's gco;
+ * a 2-rank gloo run gives the same numbers as a single rank (block sharding + all-reduce + label gather).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import gco_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+TREE4 = [[0, 1], [1, 2], [1, 3], [3, 4], [4, 5], [4, 6], [3, 7]]
+
+
+def make_model(g, **kw):
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    from tests.fake_block import FakeBlock
+    X = g["X"]
+    len_vec = g["len_vec"].tolist()
+    K = g["sched"].shape[1]
+    m = phyloHMRF(n_components=K, run_id=0, n_samples=X.shape[0], n_features=X.shape[1], observation=X,
+                  edge_list=TREE4, len_vec=len_vec, type_id=1, branch_list=[1.0] * 7,
+                  edge_list_1=[g["edges0"], g["edges1"]], cons_param=1.0, beta=float(g["beta"]), beta1=float(g["beta1"]),
+                  initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, learning_rate=0.001,
+                  estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, block_factory=FakeBlock, quiet=True,
+                  random_state=0, **kw)
+    sched = g["sched"]
+    S = X.shape[1]
+    state = {"it": 0}
+
+    def fake_init(X_, lengths=None):
+        m.startprob_ = np.full(K, 1.0 / K)
+        m.transmat_ = np.full((K, K), 1.0 / K)
+        m.params_vec1 = sched[0].copy()
+        m.init_ou_params = sched[0].copy()
+        m._ou_param_varied_constraint(sched[0])
+        m._covars_ = m._covars_ + 1e-3 * np.eye(S)
+        m._upload_labels(g["init_label"])
+
+    def fake_mstep(stats):
+        state["it"] += 1
+        m.params_vec1 = sched[state["it"]].copy()
+        m._ou_param_varied_constraint(m.params_vec1)
+        m._covars_ = m._covars_ + 1e-3 * np.eye(S)
+
+    m._init = fake_init
+    m._do_mstep = fake_mstep
+    return m
+
+
+@pytest.mark.skipif(not gco_ref.available(), reason="needs the reference gco (oracle/_ref)")
+def test_driver_reproduces_the_reference_em_trace():
+    g = np.load(os.path.join(G, "em_trace.npz"))
+    m = make_model(g)
+    res = m.fit_accumulate_test(g["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", int(g["m_iter"]))
+    params_vec, params_vec1, params_vecList, it1, it2, cost_vec, t_labels = res
+    np.testing.assert_allclose(cost_vec, g["cost_vec"], rtol=1e-9, atol=1e-12)
+    assert (it1, it2) == (int(g["iter_id1"]), int(g["iter_id2"]))
+    np.testing.assert_allclose(params_vec, g["params_vec"])
+    np.testing.assert_allclose(params_vec1, g["params_vec1"])
+    np.testing.assert_allclose(params_vecList, g["params_vecList"])
+    assert np.array_equal(t_labels, g["t_labels"])
+    np.testing.assert_allclose(m.means_, g["final_means"], rtol=1e-12)
+    np.testing.assert_allclose(m._covars_, g["final_covars"], rtol=1e-12)
+
+
+def test_lpt_assignment_balances_and_is_deterministic():
+    from phylo_hmrf_amd.dist import lpt_assign
+    sizes = [12402690, 11729746, 1630146, 2059870, 1773136, 9046815, 7283121, 165600, 1300000]
+    o1, o2 = lpt_assign(sizes, 4), lpt_assign(sizes, 4)
+    assert np.array_equal(o1, o2)
+    load = np.bincount(o1, weights=sizes, minlength=4)
+    assert load.max() <= max(sizes) + 1e-9 or load.max() / load.mean() < 1.25
+    assert np.array_equal(lpt_assign(sizes, 1), np.zeros(len(sizes), dtype=np.int64))
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+from tests.test_em_driver import make_model, G
+from tests.fake_block import FakeBlock
+FakeBlock.labeller = "model"
+g = np.load(os.path.join(G, "em_trace.npz"))
+m = make_model(g)
+assert m.world == 2 and len(m.my_regions) == 1
+res = m.fit_accumulate_test(g["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", 5)
+if m.rank == 0:
+    np.savez(%(out)r, cost_vec=res[5], t_labels=res[6], it=np.array([res[3], res[4]]))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_run_matches_single_rank(tmp_path):
+    from tests.fake_block import FakeBlock
+    g = np.load(os.path.join(G, "em_trace.npz"))
+    old = FakeBlock.labeller
+    FakeBlock.labeller = "model"
+    try:
+        m = make_model(g, world=1, rank=0)
+        ref = m.fit_accumulate_test(g["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", 5)
+    finally:
+        FakeBlock.labeller = old
+    out = str(tmp_path / "r0.npz")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": out})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29731", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o.decode()[-2000:]
+    d = np.load(out)
+    np.testing.assert_allclose(d["cost_vec"], ref[5], rtol=1e-10)
+    assert np.array_equal(d["t_labels"], ref[6])
+    assert tuple(d["it"]) == (ref[3], ref[4])
