@@ -15,6 +15,7 @@ box is passed as `bounds`, and the K independent states are solved in a fork poo
 """
 import multiprocessing as mp
 import os
+import warnings
 
 import numpy as np
 from scipy.optimize import minimize
@@ -31,6 +32,13 @@ def check_params(tree, params):
     if ok1.sum() < tree.branch_dim or ok2.sum() < tree.branch_dim + 1:
         return -2 if np.isnan(np.asarray(params)[1:]).any() else -1
     return 1
+
+
+def _well_conditioned(V):
+    """np.linalg.cond(V) < 1/eps (phylo_hmrf.py:1109) for the symmetric V, via its eigenvalues."""
+    ev = np.abs(np.linalg.eigvalsh(V))
+    lo = ev.min()
+    return bool(np.isfinite(ev).all() and lo > 0 and ev.max() / lo < 1.0 / np.finfo(float).eps)
 
 
 class OUObjective(object):
@@ -74,10 +82,11 @@ class OUObjective(object):
         mu = mean[t.leaf_vec]
         # ill-conditioned V: add min_covar*I up to 10 times, then fall back to the pseudo-inverse (:1108-1133)
         cnt = 0
-        while not (np.linalg.cond(V) < 1.0 / np.finfo(float).eps) and cnt < 10:
+        well = _well_conditioned(V)
+        while not well and cnt < 10:
             V = V + self.min_covar * np.eye(S)
             cnt += 1
-        well = np.linalg.cond(V) < 1.0 / np.finfo(float).eps
+            well = _well_conditioned(V)
         Vi = np.linalg.inv(V) if well else np.linalg.pinv(V)
         om = np.outer(self.obs, mu)
         Sw = self.oo - om - om.T + np.outer(mu, mu) * self.post                       # :1093-1097
@@ -139,8 +148,10 @@ def _solve_state(args):
     for guess in guesses:                                                             # retry loop (:1332-1342)
         x0 = np.clip(guess, LOWER, UPPER)
         try:
-            res = minimize(obj.value_and_grad, x0, jac=True, method="SLSQP", bounds=bounds, tol=1e-6,
-                           options={"disp": False, "maxiter": 200})
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                res = minimize(obj.value_and_grad, x0, jac=True, method="SLSQP", bounds=bounds, tol=1e-6,
+                               options={"disp": False, "maxiter": 200})
             params1 = res.x
         except Exception:                                                             # (:1386-1392)
             continue
@@ -239,8 +250,10 @@ def _init_state(args):
     params1, flag = guesses[-1], -1
     for guess in guesses[:-1]:
         try:
-            res = minimize(obj.value_and_grad, np.clip(guess, LOWER, UPPER), jac=True, method="SLSQP", bounds=bounds,
-                           tol=1e-6, options={"disp": False, "maxiter": 200})
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                res = minimize(obj.value_and_grad, np.clip(guess, LOWER, UPPER), jac=True, method="SLSQP",
+                               bounds=bounds, tol=1e-6, options={"disp": False, "maxiter": 200})
         except Exception:
             continue
         params1 = res.x

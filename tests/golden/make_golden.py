@@ -23,8 +23,9 @@ Fixtures:
                           estimate_type 0 and 3, with an isolated node
   G5 gco_*.npz            (unary, edges, w, V, init) -> labels, energies: swap(5000) and expansion
                           under pygco and fine quantisation, via the reference's predict() path
-  G6 em_trace.npz         3 iterations of fit_accumulate_test with _do_mstep replaced by a fixed
+  G6 em_trace.npz         8 iterations of fit_accumulate_test with _do_mstep replaced by a fixed
                           parameter schedule: cost_vec, iter ids, t_labels
+  G7 mstep_objective.npz  (params, stats, n, lambda_0) -> _ou_lik_varied_constraint value, V, leaf means
 """
 import importlib
 import os
@@ -306,6 +307,32 @@ def main():
                         iter_id1=it1, iter_id2=it2, cost_vec=cost_vec, t_labels=t_labels,
                         final_means=m.means_, final_covars=m._covars_, beta=1.0, beta1=0.5, threshold=1e-3,
                         m_iter=n_it)
+    # ---------------- G7: M-step objective (_ou_lik_varied_constraint, phylo_hmrf.py:1038-1138) -------------
+    g7 = {}
+    for tag, tree, S in (("t4", TREE4, 4), ("t8", TREE8, 8)):
+        K = 3
+        Xs = np.abs(rng.standard_normal((400, S))) + rng.uniform(0, 3, S)
+        edges = np.stack([np.arange(399), np.arange(1, 400), rng.uniform(0, 1, 399)], 1)
+        mm = make_model(mod, Xs, tree, [[400, 0, 400, 1, 400, 0, 0, 0, 0, 1]], [edges], K)
+        gam = rng.random((400, K))
+        gam /= gam.sum(1, keepdims=True)
+        mm.stats = {"post": gam.sum(0), "obs": gam.T @ Xs, "obs*obs.T": np.einsum("ij,ik,il->jkl", gam, Xs, Xs)}
+        mm.n_samples = 5000
+        mm.init_ou_params = rng.uniform(0.1, 2.0, (K, mm.n_params))
+        P = rng.uniform(0.05, 3.0, (6, mm.n_params))
+        P[1, 1] = 1e-9                                   # beta <= 1e-7 branch
+        lik = np.zeros((6, K))
+        V = np.zeros((6, K, S, S))
+        mu = np.zeros((6, K, S))
+        for i in range(6):
+            for c in range(K):
+                lik[i, c] = quiet(mm._ou_lik_varied_constraint, P[i], c)
+                V[i, c] = mm.cv_mtx
+                mu[i, c] = mm.values[mm.leaf_vec, 0]
+        g7.update({tag + "_params": P, tag + "_lik": lik, tag + "_V": V, tag + "_mu": mu, tag + "_post": mm.stats["post"],
+                   tag + "_obs": mm.stats["obs"], tag + "_obsobsT": mm.stats["obs*obs.T"], tag + "_n_samples": 5000,
+                   tag + "_lambda_0": 1.0, tag + "_check": np.array([mm._check_params(P[i]) for i in range(6)])})
+    np.savez_compressed(os.path.join(HERE, "mstep_objective.npz"), **g7)
     os.chdir(ROOT)
     shutil.rmtree(tmp, ignore_errors=True)
     print("golden fixtures written to", HERE)

@@ -1,0 +1,74 @@
+"""GPU end-to-end: the reference's command line / fit surface on a seeded synthetic block."""
+import os
+
+import numpy as np
+import pytest
+import scipy.io
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_run_synthetic_writes_reference_outputs(tmp_path):
+    import phylo_hmrf as cli
+    out = str(tmp_path)
+    opts = cli.parse_args(["-n", "5", "-r", "3", "--miter", "6", "--output", out, "--synthetic", "64", "--seed", "7",
+                           "-g", "3", "--quiet", "1"])
+    mat = cli.run(opts.num_states, opts.chromvec, opts.root_path, opts.multiple, opts.species_name, opts.sort_states,
+                  opts.run_id, opts.cons_param, opts.method_mode, opts.initial_mode, opts.initial_weight,
+                  opts.initial_weight1, opts.initial_magnitude, opts.position1, opts.position2, opts.filter_sigma,
+                  opts.beta, opts.beta1, opts.num_neighbor, opts.filter_mode, opts.threshold, opts.estimate_type,
+                  opts.simu_version, opts.annotation, opts.reload, opts.dtype, opts.miter, opts.resolution, opts.quantile,
+                  opts.ref_species, opts.output, synthetic=opts.synthetic, seed=opts.seed, quiet=opts.quiet)
+    assert os.path.basename(mat) == "estimate_ou_3_1.00_5.mat"
+    d = scipy.io.loadmat(mat)
+    n = 64 * 65 // 2
+    for key in ("state_vec", "len_vec", "params_vec1", "params_vec2", "iter_id1", "iter_id2", "cost_vec"):
+        assert key in d
+    assert d["state_vec"].size == n and d["params_vec1"].shape == (5, 23)
+    cv = d["cost_vec"]
+    assert cv.shape[1] == 4 and 1 <= cv.shape[0] <= 6 and np.all(np.isfinite(cv))
+    assert list(cv[:, 0]) == list(range(cv.shape[0]))
+    # cache files in the reference's names / formats (phylo_hmrf.py:1676-1704), and --reload 1 reads them back
+    for f in ("data.50Kb.observed.3.npy", "edgelist.50Kb.observed.3.npy", "lenvec.50Kb.observed.3.txt"):
+        assert os.path.exists(os.path.join(out, f))
+    samples, len_vec, edge_list_vec = cli.load_cache(out, 50000, 3)
+    assert samples.shape == (n, 4) and len_vec.shape == (1, 10) and edge_list_vec[0].shape[1] == 3
+
+
+def test_fit_surface_and_predict_shapes():
+    import phylo_hmrf as cli
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    from oracle import ref_numpy as R
+    X, len_vec, edge_list_vec, tree = cli.synthetic_cache(50, 4, 4, 8, 11)
+    n = X.shape[0]
+    m = phyloHMRF(n_components=4, run_id=0, n_samples=n, n_features=4, observation=X, edge_list=tree, len_vec=len_vec,
+                  type_id=1, branch_list=[1.0] * 7, edge_list_1=edge_list_vec, cons_param=1.0, beta=1.0, beta1=0.5,
+                  initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, learning_rate=0.001,
+                  estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, random_state=5, quiet=True, mstep_workers=1)
+    res = m.fit_accumulate_test(X, len_vec, 1e-3, "t", 5)
+    params_vec, params_vec1, params_vecList, it1, it2, cost_vec, t_labels = res
+    assert params_vec.shape == (4, 23) and params_vecList.shape[1:] == (4, 23) and t_labels.shape == (n,)
+    assert cost_vec.shape[1] == 4
+    # b1: _compute_log_likelihood == float64 oracle density within the emission tolerance
+    lp = m._compute_log_likelihood(X)
+    ref = R.log_multivariate_normal_density_full(X, m.means_, m._covars_)
+    assert np.all(np.abs(lp - ref) <= 2e-6 * np.abs(ref) + 2e-4)
+    # predict(): labels + logprob of a region; _compute_posteriors_graph(): the reference's 5-tuple
+    state, logprob = m.predict(X, 0)
+    assert state.shape == (n,) and logprob.shape == (n, 4)
+    post, pc, pcn, uc, c1 = m._compute_posteriors_graph(X, state, logprob, 0)
+    w, eid = R.edge_weights_from_distance(edge_list_vec[0], 0.5)
+    post_ref, pc_r, pcn_r, uc_r, c1_r = R.compute_posteriors_graph(state, logprob, eid, w, R.potts_matrix(4, 1.0), 3)
+    finite = np.isfinite(post_ref).all(axis=1)
+    assert np.max(np.abs(post[finite] - post_ref[finite])) < 2e-5
+    np.testing.assert_allclose([pc, uc], [pc_r, uc_r], rtol=1e-5)
+    # drop-in for the pygco call
+    from phylo_hmrf_amd.pygco_compat import cut_general_graph
+    lab = cut_general_graph(eid, w, -logprob, m.edge_potential, n_iter=5000, algorithm="swap", init_labels=state)
+    assert lab.shape == (n,) and lab.dtype == np.int32
+    e_new = R.mrf_energy(lab, logprob, eid, w, 1.0)[0]
+    e_old = R.mrf_energy(state, logprob, eid, w, 1.0)[0]
+    assert e_new <= e_old + 1e-6 * abs(e_old)
+    with pytest.raises(ValueError):
+        cut_general_graph(eid, w, -logprob, np.arange(16.0).reshape(4, 4))
+    m.close()

@@ -1,0 +1,89 @@
+"""CPU: host M-step (phylo_hmrf_amd/tree.py, mstep.py) against fixtures recorded from the reference's
+_ou_param_varied_constraint / _ou_lik_varied_constraint / _check_params, plus a finite-difference check of the
+analytic gradient and an optimiser sanity check (the optimum is no worse than the start)."""
+import os
+
+import numpy as np
+import pytest
+
+from phylo_hmrf_amd import mstep
+from phylo_hmrf_amd.tree import PhyloTree
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("tag", ["t4", "t8"])
+def test_tree_and_ou_map_match_reference(tag):
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "ou_params.npz"))
+    t = PhyloTree(g1[tag + "_edge_list"])
+    assert np.array_equal(t.leaf_vec, g1[tag + "_leaf_vec"])
+    assert np.array_equal(t.A2, g1[tag + "_A2"])
+    pl = g1[tag + "_pair_list"]
+    assert np.array_equal(t.leaf_vec[t.pair_a], pl[:, 0]) and np.array_equal(t.leaf_vec[t.pair_b], pl[:, 1])
+    assert np.array_equal(t.pair_anc, pl[:, 2])
+    assert t.n_params == int(g1[tag + "_n_params"])
+    means, covars = t.mean_cov(g[tag + "_params"])
+    np.testing.assert_allclose(means, g[tag + "_means"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(covars, g[tag + "_covars"], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("tag", ["t4", "t8"])
+def test_objective_matches_reference(tag):
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "mstep_objective.npz"))
+    t = PhyloTree(g1[tag + "_edge_list"])
+    P = g[tag + "_params"]
+    for c in range(g[tag + "_post"].shape[0]):
+        obj = mstep.OUObjective(t, g[tag + "_post"][c], g[tag + "_obs"][c], g[tag + "_obsobsT"][c],
+                                int(g[tag + "_n_samples"]), float(g[tag + "_lambda_0"]))
+        for i in range(P.shape[0]):
+            f = obj.value(P[i])
+            np.testing.assert_allclose(f, g[tag + "_lik"][i, c], rtol=1e-11)
+            np.testing.assert_allclose(obj.last_V, g[tag + "_V"][i, c], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(obj.last_mean, g[tag + "_mu"][i, c], rtol=1e-12)
+    assert [mstep.check_params(t, P[i]) for i in range(P.shape[0])] == list(g[tag + "_check"])
+    bad = P[0].copy()
+    bad[2] = 101.0
+    assert mstep.check_params(t, bad) == -1
+    bad[3] = np.nan
+    assert mstep.check_params(t, bad) == -2
+
+
+@pytest.mark.parametrize("tag", ["t4", "t8"])
+def test_analytic_gradient(tag):
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "mstep_objective.npz"))
+    t = PhyloTree(g1[tag + "_edge_list"])
+    obj = mstep.OUObjective(t, g[tag + "_post"][0], g[tag + "_obs"][0], g[tag + "_obsobsT"][0], 5000, 1.0)
+    for p in g[tag + "_params"][[0, 2, 5]]:
+        f, gr = obj.value_and_grad(p)
+        num = np.zeros_like(p)
+        for i in range(p.shape[0]):
+            d = np.zeros_like(p)
+            d[i] = 1e-6
+            num[i] = (obj.value(p + d) - obj.value(p - d)) / 2e-6
+        np.testing.assert_allclose(gr, num, rtol=2e-5, atol=2e-7)
+
+
+def test_do_mstep_improves_the_objective_and_respects_the_box():
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "mstep_objective.npz"))
+    t = PhyloTree(g1["t4_edge_list"])
+    stats = {"post": g["t4_post"], "obs": g["t4_obs"], "obs*obs.T": g["t4_obsobsT"]}
+    K = stats["post"].shape[0]
+    cur = g["t4_params"][:K]
+    rng = np.random.default_rng(1)
+    params, means, covars, lik = mstep.do_mstep(t, stats, cur, cur, 5000, 1.0, 0, 0.3, 0.1, 1.0, rng, workers=1)
+    assert params.shape == cur.shape and np.all(params >= 0) and np.all(params <= 100)
+    for c in range(K):
+        obj = mstep.OUObjective(t, stats["post"][c], stats["obs"][c], stats["obs*obs.T"][c], 5000, 1.0)
+        assert lik[c] <= obj.value(np.clip(cur[c], 1e-16, 100)) + 1e-9
+        # EM-time covariance = V + min_covar*I (phylo_hmrf.py:1524)
+        obj.value(params[c])
+        np.testing.assert_allclose(covars[c], obj.last_V + 1e-3 * np.eye(4))
+        np.testing.assert_allclose(means[c], obj.last_mean)
+    # pool path gives a valid result too
+    p2, _, _, lik2 = mstep.do_mstep(t, stats, cur, cur, 5000, 1.0, 1, 0.3, 0.1, 1.0, np.random.default_rng(1), workers=2)
+    assert np.all(np.isfinite(lik2)) and p2.shape == cur.shape
+    mstep.close_pool()
