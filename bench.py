@@ -262,10 +262,11 @@ def cpu_baseline(a, S, K, nn):
     if gco_ref.available():
         kind = "reference"
         labels = gco_ref.cut_general_graph(eid, w, -lp, V, n_iter=5000, algorithm="swap", init_labels=init)
-    else:
+    else:                                   # the oracle's plain-C restatement of gco's swap (oracle/estep_oracle.c)
+        from oracle import estep_c
         kind = "port"
-        g = mrf_moves.Graph(n, eid, w)
-        labels = mrf_moves.solve(g, -lp, init, a.beta, N, N, True, nn)
+        u_i, w_i, v_i = gco_ref.quantise(w, -lp, V, "pygco")
+        labels, _, _ = estep_c.swap_int(eid, w_i, u_i, v_i, init)
     t_cut = time.time() - t0
     t0 = time.time()
     pp = R.pairwise_compare_loops(labels, eid, w, V, 3)                      # phylo_hmrf.py:398-436
@@ -278,7 +279,7 @@ def cpu_baseline(a, S, K, nn):
     return {"value": n / total, "unit": "node-iterations/s", "cores": 1, "kind": kind,
             "sample": "E-step of one %dx%d diagonal block (%d nodes), S=%d K=%d: emission %.2fs, labelling (%s) %.2fs, "
                       "posterior/cost Python loops %.2fs; the reference's M-step (K SLSQP runs) is NOT included"
-                      % (N, N, n, S, K, t_em, "gco swap" if kind == "reference" else "move model", t_cut, t_post)}
+                      % (N, N, n, S, K, t_em, "reference gco swap" if kind == "reference" else "C restatement of gco swap", t_cut, t_post)}
 
 
 if __name__ == "__main__":
