@@ -353,6 +353,7 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->comp_best);
   dev_free(b->comp_gain);
   dev_free(b->comp_move);
+  dev_free(b->alpha_mask);
   dev_free(b->emis_params);
   dev_free(b->posteriors);
   dev_free(b->accum);
@@ -786,14 +787,14 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   return PHMRF_OK;
 }
 
-static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha) {
+static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask = false) {
   if (alpha < 0) {
     tic(b);
     PHMRF_TRY(launch_propose(b, beta));
     toc(b, KC_PROPOSE, 1);
   }
   tic(b);
-  PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha));
+  PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, use_mask));
   toc(b, KC_STRIP, 1);
   return PHMRF_OK;
 }
@@ -850,8 +851,12 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       for (int orient = 0; orient < 2; ++orient) {
         const int sr = (2 * r + 3 * orient) % 6, sc = (17 * r + 31 * orient) % 64;
         PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, -1));
-        if (o.use_expansion)
-          for (int a = 0; a < b->K; ++a) PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, a));
+        if (o.use_expansion) {
+          tic(b);
+          PHMRF_TRY(launch_alpha_mask(b, bf));      // which labels can still pay off where (fresh per orientation)
+          toc(b, KC_PROPOSE, 1);
+          for (int a = 0; a < b->K; ++a) PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, a, true));
+        }
       }
     }
     int64_t ch = 0;

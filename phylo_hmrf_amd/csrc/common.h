@@ -92,6 +92,7 @@ struct phmrf_block {
   int32_t* comp_best = nullptr;             // device [n]
   float* comp_gain = nullptr;               // device [n]
   uint8_t* comp_move = nullptr;             // device [n]
+  unsigned long long* alpha_mask = nullptr; // device [n]: labels a node could profit from (strip expansions)
 
   float* emis_params = nullptr;             // device packed emission parameters
   float* posteriors = nullptr;              // device [n, K], allocated on demand
@@ -132,6 +133,7 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
 int launch_component_pass(phmrf_block* b, float beta);
 int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, double beta1);
 int launch_propose(const phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
-int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha);  // adds relabelled nodes to counters[0]
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask);
+int launch_alpha_mask(phmrf_block* b, float beta);   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
 
 }  // namespace phmrf

@@ -4,15 +4,16 @@
 // chooses between its current label l_i and a proposal p_i (p_i = a constant alpha: an alpha-expansion restricted
 // to the strip; p_i = the node's best alternative label: a fusion move that shifts region fronts); all nodes
 // outside the strip are fixed.  The binary problem is solved exactly by a profile ("broken line") dynamic
-// programme over the cells in column-major order: the state is the choice bit of the last STRIP_H+1 = 6 cells
-// (newest in bit 0), i.e. 64 states = ONE WAVEFRONT with one state per lane.  A cell step is
-//     new[s'] = min_{d in {0,1}} old[(s' >> 1) | (d << 5)] + cost(cell, bit s'&1, neighbour bits in the old state)
-// where the four already-visited 8-neighbours of the cell sit at fixed profile positions (up: bit 0,
-// left-up: bit 5 = the bit being dropped, left: bit 4, left-down: bit 3).  The two predecessor values come from
-// two ds_bpermute shuffles, the decision bits are a 64-bit ballot per step kept in LDS, the backtrack is scalar.
+// programme over the cells in column-major order: the state is the choice bit of the last STRIP_H+1 = 6 cells,
+// i.e. 64 states = ONE WAVEFRONT with one state per lane.  Everything of the sequential phase lives in registers
+// (no LDS): the per-cell records are broadcast with v_readlane, the two predecessor values of a step are the lane's
+// own value and one in-register lane exchange (DPP / v_permlane16_swap / v_permlane32_swap -- see dp_step), the
+// decision bits are one 64-bit ballot per step, the backtrack is scalar.
 // No submodularity is needed (the DP is exact for any 2x2 tables), so fusion proposals are as valid as expansions.
 // Strips of one pass are separated by one fixed row and one fixed column, so simultaneous moves share no edge:
 // the pass never raises the energy.   (Model: oracle/mrf_moves.strip_fusion.)
+
+#include <cstdlib>
 
 #include "common.h"
 
@@ -22,8 +23,6 @@ namespace {
 constexpr int SH = 5;          // strip rows
 constexpr int SL = 63;         // strip columns per segment
 constexpr int NCELL_MAX = SH * SL;
-constexpr int REC = 8;         // dwords per cell record in LDS
-constexpr int CELL_PAD = 320;  // records per wave
 constexpr float BIG = 1.0e30f;
 
 struct StripGeom {
@@ -54,159 +53,268 @@ __device__ __forceinline__ float wave_min_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// lane <-> lane ^ (1 << Q) exchange without LDS: DPP for 1,2,4,8; row / half swaps for 16, 32
+template <int Q>
+__device__ __forceinline__ float xor_exchange(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  if (Q == 0) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xf, 0xf, false));   // [1,0,3,2]
+  if (Q == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xf, 0xf, false));   // [2,3,0,1]
+  if (Q == 2) {  // xor 4 = half_mirror (xor 7) then quad reverse (xor 3)
+    const int a = __builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(a, a, 0x1B, 0xf, 0xf, false));               // [3,2,1,0]
+  }
+  if (Q == 3) {  // xor 8 = row_mirror (xor 15) then half_mirror (xor 7)
+    const int a = __builtin_amdgcn_update_dpp(iv, iv, 0x140, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(a, a, 0x141, 0xf, 0xf, false));
+  }
+  if (Q == 4) {  // odd rows of vdst <-> even rows of vsrc
+    auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+    return __builtin_bit_cast(float, (int)((threadIdx.x & 16) ? r[0] : r[1]));
+  }
+  auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);   // lanes 32..63 of vdst <-> lanes 0..31 of vsrc
+  return __builtin_bit_cast(float, (int)((threadIdx.x & 32) ? r[0] : r[1]));
+}
+
+// One cell step of the profile DP.  The profile is kept in ROTATING positions: cell t owns bit (t mod 6) of the state
+// index (= lane id), so stepping to cell t overwrites the bit of cell t-6 (the left-up neighbour, about to leave the
+// profile) and new[s] = min over that old bit d of old[s with bit q := d] + cost: the two candidates live in lanes
+// s and s ^ (1<<q) -- ONE lane exchange.  Neighbours: up = t-1 at bit q-1, left = t-5 at q+1, left-down = t-4 at q+2.
+template <int Q>
+__device__ __forceinline__ void dp_step(float& m, int lane, float c0, float c1, float wu, float wlu, float wl,
+                                        float wld, int bits, unsigned long long* decision) {
+  constexpr int QU = (Q + 5) % 6, QL = (Q + 1) % 6, QLD = (Q + 2) % 6;
+  const int b = (lane >> Q) & 1;
+  const int bu = (lane >> QU) & 1, bl = (lane >> QL) & 1, bld = (lane >> QLD) & 1;
+  float base = b ? c1 : c0;
+  if ((bits >> (0 + b * 2 + bu)) & 1) base += wu;
+  if ((bits >> (8 + b * 2 + bl)) & 1) base += wl;
+  if ((bits >> (12 + b * 2 + bld)) & 1) base += wld;
+  const float lu0 = ((bits >> (4 + b * 2)) & 1) ? wlu : 0.f;
+  const float lu1 = ((bits >> (5 + b * 2)) & 1) ? wlu : 0.f;
+  const float other = xor_exchange<Q>(m);
+  const float o0 = b ? other : m;      // old value of the state whose bit q (cell t-6) is 0
+  const float o1 = b ? m : other;      //                                              is 1
+  const float a0 = o0 + base + lu0;
+  const float a1 = o1 + base + lu1;
+  const bool take1 = a1 < a0;
+  m = take1 ? a1 : a0;
+  *decision = __ballot(take1);
+}
+
+#define PHMRF_RL(x, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l))
+
+// All steps of pass P (cells t = 64 P + tt): records broadcast with v_readlane, decisions parked in lane tt.
+template <int P>
+__device__ __forceinline__ void dp_pass(float& m, int lane, float c0, float c1, float wu, float wlu, float wl, float wld,
+                                        int bits, int t_lo, int t_end, unsigned int& dlo, unsigned int& dhi) {
+  dlo = 0u;
+  dhi = 0u;
+  if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
+  for (int tb = 0; tb < 66; tb += 6) {   // rotating position q = t mod 6 = (4 P + tt) mod 6: static inside the 6-unroll
+#define PHMRF_STEP(J)                                                                                                \
+  {                                                                                                                  \
+    const int tt = tb + J;                                                                                           \
+    const int t = P * 64 + tt;                                                                                       \
+    if (tt < 64 && t >= t_lo && t <= t_end) {                                                                        \
+      unsigned long long dec;                                                                                        \
+      dp_step<(4 * P + J) % 6>(m, lane, PHMRF_RL(c0, tt), PHMRF_RL(c1, tt), PHMRF_RL(wu, tt), PHMRF_RL(wlu, tt),     \
+                               PHMRF_RL(wl, tt), PHMRF_RL(wld, tt), __builtin_amdgcn_readlane(bits, tt), &dec);      \
+      if (lane == tt) {                                                                                              \
+        dlo = (unsigned int)(dec & 0xffffffffull);                                                                   \
+        dhi = (unsigned int)(dec >> 32);                                                                             \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+    PHMRF_STEP(0) PHMRF_STEP(1) PHMRF_STEP(2) PHMRF_STEP(3) PHMRF_STEP(4) PHMRF_STEP(5)
+#undef PHMRF_STEP
+  }
+}
+
+constexpr int NPASS = 5;   // ceil(315 / 64)
+
 __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __restrict__ logprob, int K, int D,
                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                     uint8_t* __restrict__ labels, const uint8_t* __restrict__ prop,
-                                                    int alpha, float beta, unsigned long long* __restrict__ changed) {
-  extern __shared__ float lds[];
+                                                    int alpha, float beta, unsigned long long* __restrict__ changed,
+                                                    const unsigned long long* __restrict__ node_mask, int debug) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
-  float* rec = lds + wave * (CELL_PAD * REC + CELL_PAD * 2);
-  int* reci = reinterpret_cast<int*>(rec);
-  unsigned long long* bal = reinterpret_cast<unsigned long long*>(rec + CELL_PAD * REC);
   const int nstrips = g.nbands * g.nsegs;
   unsigned int my_changed = 0;
 
-  for (int s0 = blockIdx.x * WPB; s0 < nstrips; s0 += gridDim.x * WPB) {
-    const int strip = s0 + wave;
-    const bool active = strip < nstrips;
-    const int bnd = active ? strip / g.nsegs : 0;
-    const int seg = active ? strip - bnd * g.nsegs : 0;
+  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {   // waves are independent
+    const int bnd = strip / g.nsegs;
+    const int seg = strip - bnd * g.nsegs;
     const int rs0 = bnd * (SH + 1) - g.shift_r;
     const int cs0 = seg * 64 - g.shift_c;
     const int ca = cs0 > 0 ? cs0 : 0;
     const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
-    const int ncols = (active && cb > ca) ? cb - ca : 0;
+    const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
 
-    // ---- phase 1: lane <-> cell: unary costs against the fixed outside, weights / label relations to the four
-    //      already-visited in-strip neighbours.  A cell whose unary loss exceeds the total weight of its edges can
-    //      never be part of an improving move (adding it to ANY switched set raises the energy), so it is pinned
-    //      (c1 = BIG) and the DP only has to span the pinned-free range [t_lo, t_hi + SH + 1].
+    // ---- phase 0 (expansions): node_mask[i] has bit a set when node i could possibly profit from label a
+    //      (alpha_mask_kernel).  A strip none of whose cells has bit alpha is left alone after 5 coalesced-ish loads.
+    if (node_mask && alpha >= 0) {
+      bool any = false;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int t = p * 64 + lane;
+        if (t < ncell) {
+          const int cc = t / SH, rr = t - cc * SH;
+          const int node = strip_node(g, rs0 + rr, ca + cc);
+          if (node >= 0) any |= ((node_mask[node] >> alpha) & 1ull) != 0;
+        }
+      }
+      if (!__any(any)) continue;
+    }
+
+    // ---- phase 1: lane <-> cell (cell t = 64 p + lane): unary costs against the fixed outside, weights / label
+    //      relations to the four already-visited in-strip neighbours -- all kept in registers.  A cell whose unary
+    //      loss du exceeds `gain` (the weight of its edges whose other end could end up with the same proposal)
+    //      cannot be in an optimal switched set (taking it out of the set would lower the energy): it is pinned
+    //      (c1 = BIG); the DP spans [t_lo, t_hi + SH + 1] only, and strips without a free cell are skipped.
+    float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
+    int rbits[NPASS], rnode[NPASS];
     int t_lo = NCELL_MAX, t_hi = -1;
-    for (int t0 = 0; t0 < ncell; t0 += 64) {
-      const int t = t0 + lane;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int t = p * 64 + lane;
       bool sw = false;
-      if (t < ncell) {
-      const int cc = t / SH, rr = t - cc * SH;
-      const int sr = rs0 + rr, sc = ca + cc;
-      const int node = strip_node(g, sr, sc);
       float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
-      int bits = 0;
-      if (node >= 0) {
-        int ids[8];
-        const bool up = rr > 0, dn = rr < SH - 1, lf = cc > 0, rt = cc < ncols - 1;
-        ids[0] = up ? strip_node(g, sr - 1, sc) : -1;              // up
-        ids[1] = (up && lf) ? strip_node(g, sr - 1, sc - 1) : -1;  // left-up
-        ids[2] = lf ? strip_node(g, sr, sc - 1) : -1;              // left
-        ids[3] = (dn && lf) ? strip_node(g, sr + 1, sc - 1) : -1;  // left-down
-        ids[4] = dn ? strip_node(g, sr + 1, sc) : -1;              // forward neighbours (handled from their side)
-        ids[5] = (up && rt) ? strip_node(g, sr - 1, sc + 1) : -1;
-        ids[6] = rt ? strip_node(g, sr, sc + 1) : -1;
-        ids[7] = (dn && rt) ? strip_node(g, sr + 1, sc + 1) : -1;
-        const int l = labels[node];
-        const int p = prop ? (int)prop[node] : alpha;
-        const bool can = p != l;
-        c0 = -logprob[(int64_t)node * K + l];
-        c1 = can ? -logprob[(int64_t)node * K + p] : BIG;
-        const int32_t* nb = nbr + (int64_t)node * D;
-        const float* wg = wgt + (int64_t)node * D;
-        float wtot = 0.f;
-        const float du = c1 - c0;
-        for (int j = 0; j < D; ++j) {
-          const int c = nb[j];
-          if (c < 0) continue;
-          const float w = beta * wg[j];
-          wtot += w;
-          int q = 8;
+      int bits = 0, node = -1;
+      if (t < ncell) {
+        const int cc = t / SH, rr = t - cc * SH;
+        const int sr = rs0 + rr, sc = ca + cc;
+        node = strip_node(g, sr, sc);
+        if (node >= 0) {
+          int ids[8];
+          const bool up = rr > 0, dn = rr < SH - 1, lf = cc > 0, rt = cc < ncols - 1;
+          ids[0] = up ? strip_node(g, sr - 1, sc) : -1;              // up
+          ids[1] = (up && lf) ? strip_node(g, sr - 1, sc - 1) : -1;  // left-up
+          ids[2] = lf ? strip_node(g, sr, sc - 1) : -1;              // left
+          ids[3] = (dn && lf) ? strip_node(g, sr + 1, sc - 1) : -1;  // left-down
+          ids[4] = dn ? strip_node(g, sr + 1, sc) : -1;              // forward neighbours (handled from their side)
+          ids[5] = (up && rt) ? strip_node(g, sr - 1, sc + 1) : -1;
+          ids[6] = rt ? strip_node(g, sr, sc + 1) : -1;
+          ids[7] = (dn && rt) ? strip_node(g, sr + 1, sc + 1) : -1;
+          const int l = labels[node];
+          const int pl = prop ? (int)prop[node] : alpha;
+          const bool can = pl != l;
+          c0 = -logprob[(int64_t)node * K + l];
+          c1 = can ? -logprob[(int64_t)node * K + pl] : BIG;
+          const int32_t* nb = nbr + (int64_t)node * D;
+          const float* wg = wgt + (int64_t)node * D;
+          float gain = 0.f;     // upper bound of what switching this cell can save on its edges (see below)
+          const float du = c1 - c0;
+          for (int j0 = 0; j0 < D; j0 += 4) {
+            const int4 cv = *reinterpret_cast<const int4*>(nb + j0);
+            const float4 wv = *reinterpret_cast<const float4*>(wg + j0);
+            const int cs[4] = {cv.x, cv.y, cv.z, cv.w};
+            const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+            int lcs[4];
 #pragma unroll
-          for (int z = 0; z < 8; ++z)
-            if (c == ids[z]) q = z;
-          if (q < 4) {
-            w4[q] = w;
-          } else if (q == 8) {
-            const int lc = labels[c];
-            if (l != lc) c0 += w;
-            if (can && p != lc) c1 += w;
-          }
-        }
+            for (int z = 0; z < 4; ++z) lcs[z] = cs[z] >= 0 ? (int)labels[cs[z]] : 0;   // 4 gathers in flight
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (ids[q] >= 0) {
-            const int lj = labels[ids[q]];
-            const int pj = prop ? (int)prop[ids[q]] : alpha;
-            const int nib = (l != lj ? 1 : 0) | (l != pj ? 2 : 0) | (p != lj ? 4 : 0) | (p != pj ? 8 : 0);
-            bits |= nib << (4 * q);
+            for (int z = 0; z < 4; ++z) {
+              const int c = cs[z];
+              if (c < 0) continue;
+              const float w = beta * ws[z];
+              int q = 8;
+#pragma unroll
+              for (int y = 0; y < 8; ++y)
+                if (c == ids[y]) q = y;
+              if (q < 4) {
+                w4[q] = w;
+              } else if (q == 8) {
+                if (l != lcs[z]) c0 += w;
+                if (can && pl != lcs[z]) c1 += w;
+              }
+              // switching this cell can only pay on an edge whose other end may END UP with my proposal: the
+              // neighbour already carries it, or it lies in the strip and its own proposal equals mine
+              {
+                bool may = pl == lcs[z];
+                if (!may && q < 8) may = prop ? ((int)prop[c] == pl) : true;
+                if (may) gain += w;
+              }
+            }
           }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (ids[q] >= 0) {
+              const int lj = labels[ids[q]];
+              const int pj = prop ? (int)prop[ids[q]] : alpha;
+              const int nib = (l != lj ? 1 : 0) | (l != pj ? 2 : 0) | (pl != lj ? 4 : 0) | (pl != pj ? 8 : 0);
+              bits |= nib << (4 * q);
+            }
+          }
+          sw = can && !(du > gain);
+          if (!sw) c1 = BIG;
         }
-        sw = can && !(du > wtot);
-        if (!sw) c1 = BIG;
       }
-      float* r = rec + t * REC;
-      r[0] = c0; r[1] = c1; r[2] = w4[0]; r[3] = w4[1]; r[4] = w4[2]; r[5] = w4[3];
-      reci[t * REC + 6] = bits;
-      reci[t * REC + 7] = node;
-      }
+      rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
+      rbits[p] = bits; rnode[p] = node;
       const unsigned long long swm = __ballot(sw);
       if (swm) {
-        const int first = t0 + __ffsll((long long)swm) - 1;
-        const int last = t0 + 63 - __clzll((long long)swm);
+        const int first = p * 64 + __ffsll((long long)swm) - 1;
+        const int last = p * 64 + 63 - __clzll((long long)swm);
         t_lo = first < t_lo ? first : t_lo;
         t_hi = last > t_hi ? last : t_hi;
       }
     }
-    const bool need = t_hi >= 0;
+    if (t_hi < 0 || debug == 1) continue;   // nothing can move in this strip (wave-uniform)
     int t_end = t_hi + SH + 1;
     if (t_end > ncell - 1) t_end = ncell - 1;
-    __syncthreads();
 
-    // ---- phase 2: lane <-> state (6 profile bits)
-    float m = lane == 0 ? 0.f : BIG;      // every cell before t_lo keeps its label: profile 000000
-    const int b = lane & 1, pl = lane >> 1;
-    const int bu = pl & 1, bl = (pl >> 4) & 1, bld = (pl >> 3) & 1;
-    for (int t = need ? t_lo : ncell; t <= t_end; ++t) {
-      const float4 ra = *reinterpret_cast<const float4*>(rec + t * REC);
-      const float4 rb = *reinterpret_cast<const float4*>(rec + t * REC + 4);
-      const int bits = __builtin_bit_cast(int, rb.z);
-      float base = b ? ra.y : ra.x;
-      if ((bits >> (0 + b * 2 + bu)) & 1) base += ra.z;
-      if ((bits >> (8 + b * 2 + bl)) & 1) base += rb.x;
-      if ((bits >> (12 + b * 2 + bld)) & 1) base += rb.y;
-      const float lu0 = ((bits >> (4 + b * 2)) & 1) ? ra.w : 0.f;
-      const float lu1 = ((bits >> (5 + b * 2)) & 1) ? ra.w : 0.f;
-      const float o0 = __shfl(m, pl, 64);
-      const float o1 = __shfl(m, pl + 32, 64);
-      const float a0 = o0 + base + lu0;
-      const float a1 = o1 + base + lu1;
-      const bool take1 = a1 < a0;
-      m = take1 ? a1 : a0;
-      const unsigned long long bt = __ballot(take1);
-      if (lane == 0) bal[t] = bt;
-    }
-    __syncthreads();
+    // ---- phase 2: lane <-> state.  Records are broadcast with v_readlane, decisions are one 64-bit ballot per step
+    //      parked in lane (t mod 64) of a per-pass register pair.
+    float m = lane == 0 ? 0.f : BIG;     // every cell before t_lo keeps its label: profile 000000
+    unsigned int dlo[NPASS], dhi[NPASS];
+    dp_pass<0>(m, lane, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
+    dp_pass<1>(m, lane, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
+    dp_pass<2>(m, lane, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
+    dp_pass<3>(m, lane, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
+    dp_pass<4>(m, lane, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
 
-    // ---- backtrack (wave-uniform scalars); the choice bit of cell t replaces the neighbour-relation word
-    if (need) {
-      const float mmin = wave_min_f32(m);
-      int s = __ffsll((long long)__ballot(m == mmin)) - 1;
-      for (int t = t_end; t >= t_lo; --t) {
-        const int x = s & 1;
-        const int d = (int)((bal[t] >> s) & 1ull);
-        s = (s >> 1) | (d << 5);
-        if (lane == 0) reci[t * REC + 6] = x;
+    if (debug == 2) continue;
+    // ---- final state: among the minimisers take the one whose SHIFT-encoded index (newest cell in bit 0, as in the
+    //      move model) is lowest, so ties are broken exactly like oracle/mrf_moves.strip_fusion
+    const int q_end = t_end % 6;
+    int sidx = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sidx |= ((lane >> ((q_end - j + 6) % 6)) & 1) << j;
+    const float mmin = wave_min_f32(m);
+    const float cand = (m == mmin) ? (float)sidx : 127.f;
+    const float best = wave_min_f32(cand);
+    int s = __ffsll((long long)__ballot(cand == best)) - 1;
+
+    // ---- backtrack on scalars; the choice of cell t lands in lane (t mod 64) of xsel[pass]
+    unsigned int xsel[NPASS];
+#pragma unroll
+    for (int p = NPASS - 1; p >= 0; --p) {
+      xsel[p] = 0u;
+      if (p * 64 > t_end || p * 64 + 63 < t_lo) continue;
+      for (int tt = 63; tt >= 0; --tt) {
+        const int t = p * 64 + tt;
+        if (t > t_end || t < t_lo) continue;
+        const int q = t % 6;
+        const unsigned long long dec =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi[p], tt) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo[p], tt);
+        const int x = (s >> q) & 1;
+        const int d = (int)((dec >> s) & 1ull);
+        s = (s & ~(1 << q)) | (d << q);
+        if (lane == tt) xsel[p] = (unsigned int)x;
       }
     }
-    __syncthreads();
 
     // ---- phase 3: lane <-> cell: apply
-    for (int t = (need ? t_lo : ncell) + lane; t <= t_end; t += 64) {
-      const int node = reci[t * REC + 7];
-      if (node >= 0 && reci[t * REC + 6]) {
-        labels[node] = prop ? prop[node] : (uint8_t)alpha;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      if (xsel[p] && rnode[p] >= 0) {
+        labels[rnode[p]] = prop ? prop[rnode[p]] : (uint8_t)alpha;
         ++my_changed;
       }
     }
-    __syncthreads();
   }
   unsigned int s = my_changed;
 #pragma unroll
@@ -264,9 +372,84 @@ __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ 
   }
 }
 
+// node_mask[i] bit a  <=>  u_i(a) - u_i(l_i) <= beta * sum_{j in N(i)} w_ij   (a != l_i):
+// label a costs node i no more in unary terms than ALL its edges could ever give back.  Every node an
+// alpha-expansion can move satisfies this (it is the strip kernel's own test with every neighbour counted), so a strip
+// without such a node for alpha needs no work.
+template <int VEC>
+__global__ __launch_bounds__(256) void alpha_mask_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp, int D,
+                                                         const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
+                                                         const uint8_t* __restrict__ labels, float beta,
+                                                         unsigned long long* __restrict__ mask) {
+  extern __shared__ float tile[];
+  const int TB = blockDim.x;
+  const int KV = K / VEC;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    for (int q = threadIdx.x; q < rows * KV; q += TB) {
+      const int r = q / KV;
+      const int c = (q - r * KV) * VEC;
+      const float* src = logprob + (base + r) * K + c;
+      float* dst = tile + r * Kp + c;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        dst[0] = -t.x; dst[1] = -t.y; dst[2] = -t.z; dst[3] = -t.w;
+      } else if (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        dst[0] = -t.x; dst[1] = -t.y;
+      } else {
+        dst[0] = -src[0];
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+      const int64_t i = base + threadIdx.x;
+      const float* row = tile + threadIdx.x * Kp;
+      const int cur = labels[i];
+      const int32_t* nb = nbr + i * D;
+      const float* wg = wgt + i * D;
+      float wdiff = 0.f;
+      for (int j0 = 0; j0 < D; j0 += 4) {
+        const int4 cv = *reinterpret_cast<const int4*>(nb + j0);
+        const float4 wv = *reinterpret_cast<const float4*>(wg + j0);
+        if (cv.x >= 0) wdiff += beta * wv.x;
+        if (cv.y >= 0) wdiff += beta * wv.y;
+        if (cv.z >= 0) wdiff += beta * wv.z;
+        if (cv.w >= 0) wdiff += beta * wv.w;
+      }
+      const float thr = row[cur] + wdiff * 1.0001f + 1e-6f;     // a hair of slack: the strip kernel sums in another order
+      unsigned long long m = 0ull;
+      for (int k = 0; k < K; ++k)
+        if (k != cur && !(row[k] > thr)) m |= 1ull << k;
+      mask[i] = m;
+    }
+    __syncthreads();
+  }
+}
+
 inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 }  // namespace
+
+int launch_alpha_mask(phmrf_block* b, float beta) {
+  if (!b->alpha_mask) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->alpha_mask), (size_t)b->n * sizeof(unsigned long long)));
+  const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
+  const size_t lds = (size_t)TB * Kp * sizeof(float);
+  int64_t g64 = (b->n + TB - 1) / TB;
+  const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
+#define PHMRF_LAUNCH_AM(VEC_)                                                                                          \
+  hipLaunchKernelGGL((alpha_mask_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
+                     b->wgt, b->labels, beta, b->alpha_mask)
+  switch (vec_of(K)) {
+    case 4: PHMRF_LAUNCH_AM(4); break;
+    case 2: PHMRF_LAUNCH_AM(2); break;
+    default: PHMRF_LAUNCH_AM(1); break;
+  }
+#undef PHMRF_LAUNCH_AM
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
 
 int launch_propose(const phmrf_block* b, float beta) {
   const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
@@ -286,8 +469,17 @@ int launch_propose(const phmrf_block* b, float beta) {
   return PHMRF_OK;
 }
 
+static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: phase 1 only, 2: no backtrack/apply)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PHMRF_STRIP_DEBUG");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 // alpha < 0: fusion with the proposals in b->labels_tmp (launch_propose); alpha >= 0: strip alpha-expansion
-int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha) {
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask) {
   StripGeom g;
   g.H = b->H;
   g.W = b->W;
@@ -302,11 +494,11 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0) return PHMRF_OK;
   const int TB = 256, WPB = 4;
-  const size_t lds = (size_t)WPB * (CELL_PAD * REC + CELL_PAD * 2) * sizeof(float);
   int grid = (nstrips + WPB - 1) / WPB;
-  if (grid > 256 * 16) grid = 256 * 16;
-  hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), lds, b->stream, g, b->logprob, b->K, b->D, b->nbr, b->wgt,
-                     b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->logprob, b->K, b->D, b->nbr, b->wgt,
+                     b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters,
+                     use_mask ? b->alpha_mask : nullptr, strip_debug());
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
