@@ -110,14 +110,16 @@ PHMRF_API int phmrf_emission_dev(const float* X_dev, int64_t n, int S, int K, co
 
 /* ---- b2: MRF labelling ------------------------------------------------------------------------ */
 typedef struct phmrf_solve_opts {
-  int max_rounds;      /* <=0: default 64.  One round = chain moves + ICM sweep + component moves + strip moves */
+  int max_rounds;      /* <=0: default 64.  One round = chain moves + ICM sweep + component moves + strip fusion */
   int use_chains;      /* 1: exact 1-D chain moves when geometry is known                                      */
   int use_components;  /* 1: whole-component relabel moves                                                     */
   int init_mode;       /* 0: start from the block's current labels (reference warm start, phylo_hmrf.py:479)
                           1: start from argmax_k logprob                                                        */
   int use_strips;      /* 1: exact 5-row strip fusion moves (needs the grid)                                   */
-  int use_expansion;   /* 1: additionally one strip alpha-expansion per label and orientation every round      */
-  int reserved[2];
+  int use_expansion;   /* 1: strip alpha-expansion sweeps (one per label and orientation) whenever the cheaper
+                          moves have gone quiet; the solve ends when such a sweep is quiet too                  */
+  int min_changed;     /* a round / sweep that changes at most this many labels counts as quiet (default 0)     */
+  int reserved[1];
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {

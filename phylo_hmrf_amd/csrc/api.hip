@@ -316,11 +316,11 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
   if (st == PHMRF_OK) guard(dev_alloc(&b->labels, (size_t)n));
   if (st == PHMRF_OK) guard(dev_alloc(&b->labels_tmp, (size_t)n));
   if (st == PHMRF_OK) guard(dev_alloc(&b->accum, (size_t)ACCUM_DOUBLES));
-  if (st == PHMRF_OK) guard(dev_alloc(&b->counters, (size_t)8));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->counters, (size_t)(8 + 64)));
   if (st == PHMRF_OK) guard(dev_alloc(&b->emis_params, (size_t)K * (S + S * (S + 1) / 2 + 1)));
   if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->accum_host), ACCUM_DOUBLES * sizeof(double)) != hipSuccess)
     guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
-  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->counters_host), 8 * sizeof(unsigned long long)) != hipSuccess)
+  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->counters_host), (8 + 64) * sizeof(unsigned long long)) != hipSuccess)
     guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
   if (st == PHMRF_OK && (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess))
     guard(fail(PHMRF_ERR_HIP, "hipEventCreate failed"));
@@ -704,7 +704,7 @@ static int read_counter(phmrf_block_t b, int64_t* v) {
 }
 
 static int zero_counter(phmrf_block_t b) {
-  PHMRF_HIP(hipMemsetAsync(b->counters, 0, 8 * sizeof(unsigned long long), b->stream));
+  PHMRF_HIP(hipMemsetAsync(b->counters, 0, (8 + 64) * sizeof(unsigned long long), b->stream));
   return PHMRF_OK;
 }
 
@@ -837,8 +837,23 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   int64_t total = 0;
   int rounds = 0, converged = 0;
   const bool chains = o.use_chains && b->has_grid;
-  for (int r = 0; r < o.max_rounds; ++r) {
-    PHMRF_TRY(zero_counter(b));
+  const bool strips = o.use_strips && b->has_grid;
+  const int64_t tol = o.min_changed > 0 ? o.min_changed : 0;
+  // One round = chain moves, ICM, component moves, strip fusion (both orientations), then strip alpha-expansions for the
+  // ACTIVE labels.  A label stays active while its expansions still move something; when the active set runs dry, or
+  // a round no longer lowers the energy, a VERIFICATION round with every label active decides: quiet -> done.
+  // "Quiet" = at most `min_changed` labels changed OR the energy did not go down.  (Two labellings of exactly equal
+  // energy can each be the canonical minimiser of a different move type and would otherwise alternate forever; gco
+  // stops on the same criterion, GCoptimization.cpp:1298: while old_energy > new_energy.)
+  double e_prev_u = 0, e_prev_p = 0;
+  PHMRF_TRY(energy_now(b, beta, &e_prev_u, &e_prev_p));
+  double e_prev = e_prev_u + e_prev_p;
+  const int K = b->K;
+  std::vector<char> active(K, 1);
+  bool all_active = true;
+  while (rounds < o.max_rounds) {
+    const int r = rounds;
+    PHMRF_HIP(hipMemsetAsync(b->counters, 0, (8 + 64) * sizeof(unsigned long long), b->stream));
     if (chains)
       for (int f = 0; f < (int)b->families.size(); ++f) PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1));
     PHMRF_TRY(icm_sweep_nocount(b, bf));
@@ -847,7 +862,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       PHMRF_TRY(launch_component_pass(b, bf));
       toc(b, KC_COMPONENT, 1);
     }
-    if (o.use_strips && b->has_grid) {
+    if (strips) {
       for (int orient = 0; orient < 2; ++orient) {
         const int sr = (2 * r + 3 * orient) % 6, sc = (17 * r + 31 * orient) % 64;
         PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, -1));
@@ -855,17 +870,43 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           tic(b);
           PHMRF_TRY(launch_alpha_mask(b, bf));      // which labels can still pay off where (fresh per orientation)
           toc(b, KC_PROPOSE, 1);
-          for (int a = 0; a < b->K; ++a) PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, a, true));
+          for (int a = 0; a < K; ++a)
+            if (active[a]) PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, a, true));
         }
       }
     }
-    int64_t ch = 0;
-    PHMRF_TRY(read_counter(b, &ch));
+    PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, (8 + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                             b->stream));
+    double eu = 0, ep = 0;
+    PHMRF_TRY(energy_now(b, beta, &eu, &ep));       // synchronises the stream
+    const double e_now = eu + ep;
+    const int64_t ch = (int64_t)b->counters_host[0];
     total += ch;
     ++rounds;
-    if (ch == 0) {
-      converged = 1;
-      break;
+    const bool improved = e_now < e_prev - 1e-11 * std::fabs(e_prev);
+    if (e_now < e_prev) e_prev = e_now;
+    const bool quiet = ch <= tol || !improved;
+    const bool expansions = strips && o.use_expansion;
+    if (quiet) {
+      if (all_active || !expansions) {
+        converged = 1;
+        break;
+      }
+      std::fill(active.begin(), active.end(), 1);    // verification round
+      all_active = true;
+      continue;
+    }
+    if (expansions) {
+      int n_act = 0;
+      for (int a = 0; a < K; ++a) {
+        active[a] = b->counters_host[8 + a] > 0 ? 1 : 0;
+        n_act += active[a];
+      }
+      all_active = n_act == K;
+      if (n_act == 0) {
+        std::fill(active.begin(), active.end(), 1);
+        all_active = true;
+      }
     }
   }
   b->has_labels = true;

@@ -319,7 +319,10 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
   unsigned int s = my_changed;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
+  if (lane == 0 && s) {
+    atomicAdd(changed, (unsigned long long)s);
+    if (alpha >= 0) atomicAdd(changed + 8 + alpha, (unsigned long long)s);   // per-label activity (solve schedule)
+  }
 }
 
 // best alternative label per node: argmin_{k != l_i} ( -logprob[i,k] - beta * sum_{j in N(i), l_j == k} w_ij )
