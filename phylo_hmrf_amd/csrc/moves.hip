@@ -14,6 +14,8 @@
 //
 // Both are energy non-increasing by construction (simultaneous moves never share an edge).
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace phmrf {
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
                                                     const int32_t* __restrict__ seg_len, int nseg, int K, int Kp, int D,
                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                     uint8_t* __restrict__ labels, float beta,
-                                                    unsigned long long* __restrict__ changed) {
+                                                    unsigned long long* __restrict__ changed, int debug) {
   extern __shared__ float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -90,21 +92,29 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
       float* row = tile + lane * Kp;
       const int32_t* nb = nbr + (int64_t)node * D;
       const float* wg = wgt + (int64_t)node * D;
-      for (int j = 0; j < D; ++j) {
-        const int c = nb[j];
-        if (c < 0) continue;
-        const float w = wg[j];
-        if (c == nx) { link = w; continue; }
-        if (c == pv) continue;
-        row[labels[c]] -= beta * w;
+      for (int j0 = 0; j0 < D; j0 += 4) {          // 4 neighbour ids + weights per 16-byte load, 4 label gathers in flight
+        const int4 cv = *reinterpret_cast<const int4*>(nb + j0);
+        const float4 wv = *reinterpret_cast<const float4*>(wg + j0);
+        const int cs[4] = {cv.x, cv.y, cv.z, cv.w};
+        const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+        int ls[4];
+#pragma unroll
+        for (int z = 0; z < 4; ++z) ls[z] = (cs[z] >= 0 && cs[z] != nx && cs[z] != pv) ? (int)labels[cs[z]] : -1;
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+          if (cs[z] < 0) continue;
+          if (cs[z] == nx) { link = ws[z]; continue; }
+          if (ls[z] >= 0) row[ls[z]] -= beta * ws[z];
+        }
       }
       old = labels[node];
     }
     __syncthreads();
     // phase 2: forward pass, lane <-> label
+    const int len2 = debug == 1 ? 0 : len;
     float m = (lane < K && len > 0) ? tile[lane] : BIG;
     unsigned int jm_lo = 0, jm_hi = 0, am_v = 0;  // lane t holds the decisions of step t
-    for (int t = 1; t < len; ++t) {
+    for (int t = 1; t < len2; ++t) {
       const float th = lane < K ? tile[t * Kp + lane] : 0.f;
       const float mmin = wave_min_f32(m);
       const unsigned long long eq = __ballot(m == mmin);
@@ -121,8 +131,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
       }
     }
     // backtrack on scalars
-    int newl = 0;
-    if (len > 0) {
+    int newl = old;
+    if (len2 > 0 && debug != 2) {
       const float mmin = wave_min_f32(m);
       int cur = __ffsll((long long)__ballot(m == mmin)) - 1;
       for (int t = len - 1; t >= 1; --t) {
@@ -340,6 +350,15 @@ int ensure(T** p, size_t count) {
 
 }  // namespace
 
+static int chain_debug() {   // timing experiments only (PHMRF_CHAIN_DEBUG=1: phase 1 only, 2: no backtrack)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PHMRF_CHAIN_DEBUG");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase) {
   const ChainFamily& f = b->families[family];
   const int nseg = f.nseg[phase][colour];
@@ -352,7 +371,7 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
 #define PHMRF_LAUNCH_CHAIN(VEC_)                                                                                      \
   hipLaunchKernelGGL((chain_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, f.nodes,                  \
                      f.seg_start[phase][colour], f.seg_len[phase][colour], nseg, K, Kp, b->D, b->nbr, b->wgt, b->labels, \
-                     beta, b->counters)
+                     beta, b->counters, chain_debug())
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_CHAIN(4); break;
     case 2: PHMRF_LAUNCH_CHAIN(2); break;

@@ -103,6 +103,11 @@ __device__ __forceinline__ void dp_step(float& m, int lane, float c0, float c1, 
 
 #define PHMRF_RL(x, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l))
 
+// one uniform value into one lane of a VGPR as a plain select (v_cmp + v_cndmask, no exec juggling)
+__device__ __forceinline__ void write_lane(unsigned int& dst, unsigned int value, int lane_sel) {
+  dst = ((int)(threadIdx.x & 63) == lane_sel) ? value : dst;
+}
+
 // All steps of pass P (cells t = 64 P + tt): records broadcast with v_readlane, decisions parked in lane tt.
 template <int P>
 __device__ __forceinline__ void dp_pass(float& m, int lane, float c0, float c1, float wu, float wlu, float wl, float wld,
@@ -110,19 +115,22 @@ __device__ __forceinline__ void dp_pass(float& m, int lane, float c0, float c1, 
   dlo = 0u;
   dhi = 0u;
   if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
-  for (int tb = 0; tb < 66; tb += 6) {   // rotating position q = t mod 6 = (4 P + tt) mod 6: static inside the 6-unroll
+  // [t_lo, t_end] is wave-uniform and already widened to whole groups of 6 steps (cells outside the true range are
+  // pinned or absent, so visiting them is harmless); the only per-step test left is the static tail of the pass.
+  int tb0 = t_lo - P * 64;
+  tb0 = tb0 < 0 ? 0 : tb0 - tb0 % 6;
+  int tb1 = t_end - P * 64;
+  tb1 = tb1 > 63 ? 63 : tb1;
+  for (int tb = tb0; tb <= tb1; tb += 6) {   // rotating position q = t mod 6 = (4 P + tt) mod 6: static in the 6-unroll
 #define PHMRF_STEP(J)                                                                                                \
   {                                                                                                                  \
     const int tt = tb + J;                                                                                           \
-    const int t = P * 64 + tt;                                                                                       \
-    if (tt < 64 && t >= t_lo && t <= t_end) {                                                                        \
+    if (J < 4 || tt < 64) {                                                                                          \
       unsigned long long dec;                                                                                        \
       dp_step<(4 * P + J) % 6>(m, lane, PHMRF_RL(c0, tt), PHMRF_RL(c1, tt), PHMRF_RL(wu, tt), PHMRF_RL(wlu, tt),     \
                                PHMRF_RL(wl, tt), PHMRF_RL(wld, tt), __builtin_amdgcn_readlane(bits, tt), &dec);      \
-      if (lane == tt) {                                                                                              \
-        dlo = (unsigned int)(dec & 0xffffffffull);                                                                   \
-        dhi = (unsigned int)(dec >> 32);                                                                             \
-      }                                                                                                              \
+      write_lane(dlo, (unsigned int)(dec & 0xffffffffull), tt);                                                      \
+      write_lane(dhi, (unsigned int)(dec >> 32), tt);                                                                \
     }                                                                                                                \
   }
     PHMRF_STEP(0) PHMRF_STEP(1) PHMRF_STEP(2) PHMRF_STEP(3) PHMRF_STEP(4) PHMRF_STEP(5)
@@ -262,8 +270,17 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
       }
     }
     if (t_hi < 0 || debug == 1) continue;   // nothing can move in this strip (wave-uniform)
-    int t_end = t_hi + SH + 1;
-    if (t_end > ncell - 1) t_end = ncell - 1;
+    t_lo = __builtin_amdgcn_readfirstlane(t_lo);
+    int t_end = __builtin_amdgcn_readfirstlane(t_hi) + SH + 1;
+    {   // widen to whole groups of 6 steps counted from each pass start (the DP passes run in such groups)
+      const int pe = t_end >> 6, re = t_end & 63;
+      int r6 = re - re % 6 + 5;
+      if (r6 > 63) r6 = 63;
+      t_end = pe * 64 + r6;
+      if (t_end > NPASS * 64 - 1) t_end = NPASS * 64 - 1;
+      const int pl = t_lo >> 6, rl = t_lo & 63;
+      t_lo = pl * 64 + (rl - rl % 6);
+    }
 
     // ---- phase 2: lane <-> state.  Records are broadcast with v_readlane, decisions are one 64-bit ballot per step
     //      parked in lane (t mod 64) of a per-pass register pair.
@@ -293,9 +310,12 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     for (int p = NPASS - 1; p >= 0; --p) {
       xsel[p] = 0u;
       if (p * 64 > t_end || p * 64 + 63 < t_lo) continue;
-      for (int tt = 63; tt >= 0; --tt) {
+      int tt_hi = t_end - p * 64;
+      tt_hi = tt_hi > 63 ? 63 : tt_hi;
+      int tt_lo = t_lo - p * 64;
+      tt_lo = tt_lo < 0 ? 0 : tt_lo;
+      for (int tt = tt_hi; tt >= tt_lo; --tt) {
         const int t = p * 64 + tt;
-        if (t > t_end || t < t_lo) continue;
         const int q = t % 6;
         const unsigned long long dec =
             ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi[p], tt) << 32) |
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
         const int x = (s >> q) & 1;
         const int d = (int)((dec >> s) & 1ull);
         s = (s & ~(1 << q)) | (d << q);
-        if (lane == tt) xsel[p] = (unsigned int)x;
+        write_lane(xsel[p], (unsigned int)x, tt);
       }
     }
 
