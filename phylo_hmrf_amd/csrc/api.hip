@@ -354,6 +354,8 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->comp_gain);
   dev_free(b->comp_move);
   dev_free(b->alpha_mask);
+  dev_free(b->stamp);
+  dev_free(b->memo);
   dev_free(b->emis_params);
   dev_free(b->posteriors);
   dev_free(b->accum);
@@ -716,6 +718,7 @@ static int check_solvable(phmrf_block_t b) {
 }
 
 static int icm_sweep_nocount(phmrf_block_t b, float beta) {
+  if (b->tick) ++b->tick;
   tic(b);
   for (int c = 0; c < b->n_colours; ++c) PHMRF_TRY(launch_icm_colour(b, beta, c));
   toc(b, KC_ICM, b->n_colours);
@@ -724,6 +727,7 @@ static int icm_sweep_nocount(phmrf_block_t b, float beta) {
 
 static int chain_sweep_nocount(phmrf_block_t b, float beta, int family, int phase) {
   const ChainFamily& f = b->families[family];
+  if (b->tick) ++b->tick;
   tic(b);
   for (int c = 0; c < f.n_colours; ++c) PHMRF_TRY(launch_chain_colour(b, beta, family, c, phase));
   toc(b, KC_CHAIN, f.n_colours);
@@ -787,14 +791,16 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   return PHMRF_OK;
 }
 
-static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask = false) {
+static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask = false,
+                              int geom = -1) {
   if (alpha < 0) {
     tic(b);
     PHMRF_TRY(launch_propose(b, beta));
     toc(b, KC_PROPOSE, 1);
   }
   tic(b);
-  PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, use_mask));
+  if (b->tick) ++b->tick;
+  PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, use_mask, geom));
   toc(b, KC_STRIP, 1);
   return PHMRF_OK;
 }
@@ -851,6 +857,29 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   const int K = b->K;
   std::vector<char> active(K, 1);
   bool all_active = true;
+  // change stamps + per-strip memo of quiet expansions (exact skip of strips whose inputs did not change)
+  static const int GEOM_R[3] = {0, 2, 4}, GEOM_C[3] = {0, 21, 42};
+  if (strips && o.use_expansion) {
+    int64_t max_strips = 0;
+    for (int orient = 0; orient < 2; ++orient) {
+      const int Hs = orient ? b->W : b->H, Ws = orient ? b->H : b->W;
+      const int64_t ns = (int64_t)((Hs + 5 + 5) / 6) * ((Ws + 63 + 63) / 64);
+      max_strips = std::max(max_strips, ns);
+    }
+    if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
+    if (!b->memo || b->memo_strips < max_strips) {
+      dev_free(b->memo);
+      PHMRF_TRY(dev_alloc(&b->memo, (size_t)6 * max_strips * K));
+      b->memo_strips = max_strips;
+    }
+    PHMRF_HIP(hipMemsetAsync(b->stamp, 0, (size_t)b->n * sizeof(uint16_t), b->stream));
+    PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * K * sizeof(uint16_t), b->stream));
+    b->tick = 1;
+  }
+  struct TickOff {
+    phmrf_block* blk;
+    ~TickOff() { blk->tick = 0; }
+  } tick_off{b};
   while (rounds < o.max_rounds) {
     const int r = rounds;
     PHMRF_HIP(hipMemsetAsync(b->counters, 0, (8 + 64) * sizeof(unsigned long long), b->stream));
@@ -858,6 +887,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       for (int f = 0; f < (int)b->families.size(); ++f) PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1));
     PHMRF_TRY(icm_sweep_nocount(b, bf));
     if (o.use_components) {
+      if (b->tick) ++b->tick;
       tic(b);
       PHMRF_TRY(launch_component_pass(b, bf));
       toc(b, KC_COMPONENT, 1);
@@ -867,11 +897,12 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         const int sr = (2 * r + 3 * orient) % 6, sc = (17 * r + 31 * orient) % 64;
         PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, -1));
         if (o.use_expansion) {
+          const int geom = r % 3;                   // expansions cycle through three fixed cuts so the memo applies
           tic(b);
           PHMRF_TRY(launch_alpha_mask(b, bf));      // which labels can still pay off where (fresh per orientation)
           toc(b, KC_PROPOSE, 1);
           for (int a = 0; a < K; ++a)
-            if (active[a]) PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, a, true));
+            if (active[a]) PHMRF_TRY(strip_pass_nocount(b, bf, orient, GEOM_R[geom], GEOM_C[geom], a, true, geom));
         }
       }
     }

@@ -93,6 +93,13 @@ struct phmrf_block {
   float* comp_gain = nullptr;               // device [n]
   uint8_t* comp_move = nullptr;             // device [n]
   unsigned long long* alpha_mask = nullptr; // device [n]: labels a node could profit from (strip expansions)
+  // change stamps: stamp[i] = tick of the launch that last changed node i's label (0 = not since the solve began);
+  // memo[orient][geom][strip][alpha] = tick of the last strip alpha-expansion of that strip that found nothing to do.
+  // A strip whose cells and border have no stamp newer than its memo would see identical inputs: skipped.
+  uint16_t* stamp = nullptr;                // device [n]
+  uint16_t* memo = nullptr;                 // device [2][3][memo_strips][K]
+  int64_t memo_strips = 0;
+  int tick = 0;                             // host launch counter inside one solve (0 = stamping off)
 
   float* emis_params = nullptr;             // device packed emission parameters
   float* posteriors = nullptr;              // device [n, K], allocated on demand
@@ -133,7 +140,8 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
 int launch_component_pass(phmrf_block* b, float beta);
 int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, double beta1);
 int launch_propose(const phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
-int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask);
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
+                      int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
 int launch_alpha_mask(phmrf_block* b, float beta);   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
 
 }  // namespace phmrf

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void icm_kernel(const float* __restrict__ logp
                                                   int64_t count, int K, int Kp, int D,
                                                   const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                   uint8_t* __restrict__ labels, float beta,
-                                                  unsigned long long* __restrict__ changed) {
+                                                  unsigned long long* __restrict__ changed,
+                                                  uint16_t* __restrict__ stamp, int tick) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   unsigned int my_changed = 0;
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void icm_kernel(const float* __restrict__ logp
       }
       if (bk != cur) {
         labels[node] = (uint8_t)bk;
+        if (stamp) stamp[node] = (uint16_t)tick;
         ++my_changed;
       }
     }
@@ -496,9 +498,9 @@ int launch_icm_colour(const phmrf_block* b, float beta, int colour) {
   const int grid = grid_for(count, TB);
   const int32_t* nodes = b->colour_nodes + lo;
   switch (vec_of(K)) {
-    case 4: hipLaunchKernelGGL((icm_kernel<4>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters); break;
-    case 2: hipLaunchKernelGGL((icm_kernel<2>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters); break;
-    default: hipLaunchKernelGGL((icm_kernel<1>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters); break;
+    case 4: hipLaunchKernelGGL((icm_kernel<4>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters, b->tick ? b->stamp : nullptr, b->tick); break;
+    case 2: hipLaunchKernelGGL((icm_kernel<2>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters, b->tick ? b->stamp : nullptr, b->tick); break;
+    default: hipLaunchKernelGGL((icm_kernel<1>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters, b->tick ? b->stamp : nullptr, b->tick); break;
   }
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
                                                     const int32_t* __restrict__ seg_len, int nseg, int K, int Kp, int D,
                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                     uint8_t* __restrict__ labels, float beta,
-                                                    unsigned long long* __restrict__ changed, int debug) {
+                                                    unsigned long long* __restrict__ changed, int debug,
+                                                    uint16_t* __restrict__ stamp, int tick) {
   extern __shared__ float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
     }
     if (lane < len && newl != old) {
       labels[node] = (uint8_t)newl;
+      if (stamp) stamp[node] = (uint16_t)tick;
       ++my_changed;
     }
     __syncthreads();
@@ -319,13 +321,14 @@ __global__ void comp_block_kernel(int64_t n, int D, const int32_t* __restrict__ 
 
 __global__ void comp_apply_kernel(int64_t n, const int32_t* __restrict__ comp, const int32_t* __restrict__ best,
                                   const uint8_t* __restrict__ blocked, uint8_t* __restrict__ labels,
-                                  unsigned long long* __restrict__ changed) {
+                                  unsigned long long* __restrict__ changed, uint16_t* __restrict__ stamp, int tick) {
   unsigned int mine = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int ci = comp[i];
     const int bk = best[ci];
     if (bk >= 0 && !blocked[ci]) {
       labels[i] = (uint8_t)bk;
+      if (stamp) stamp[i] = (uint16_t)tick;
       ++mine;
     }
   }
@@ -371,7 +374,7 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
 #define PHMRF_LAUNCH_CHAIN(VEC_)                                                                                      \
   hipLaunchKernelGGL((chain_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, f.nodes,                  \
                      f.seg_start[phase][colour], f.seg_len[phase][colour], nseg, K, Kp, b->D, b->nbr, b->wgt, b->labels, \
-                     beta, b->counters, chain_debug())
+                     beta, b->counters, chain_debug(), b->tick ? b->stamp : nullptr, b->tick)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_CHAIN(4); break;
     case 2: PHMRF_LAUNCH_CHAIN(2); break;
@@ -424,7 +427,7 @@ int launch_component_pass(phmrf_block* b, float beta) {
                      b->comp_gain);
   hipLaunchKernelGGL(comp_block_kernel, dim3(g), dim3(256), 0, st, n, D, b->nbr, b->comp, b->comp_gain, b->comp_move);
   hipLaunchKernelGGL(comp_apply_kernel, dim3(g), dim3(256), 0, st, n, b->comp, b->comp_best, b->comp_move, b->labels,
-                     b->counters);
+                     b->counters, b->tick ? b->stamp : nullptr, b->tick);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

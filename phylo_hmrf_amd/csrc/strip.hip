@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                     uint8_t* __restrict__ labels, const uint8_t* __restrict__ prop,
                                                     int alpha, float beta, unsigned long long* __restrict__ changed,
-                                                    const unsigned long long* __restrict__ node_mask, int debug) {
+                                                    const unsigned long long* __restrict__ node_mask, int debug,
+                                                    uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo, int tick) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
@@ -160,6 +161,31 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
 
+    // ---- memo test (expansions inside a solve): if no label of the strip or of its fixed border has changed since
+    //      this very strip was last found quiet for alpha, its inputs are identical -> nothing to do
+    uint16_t* my_memo = (memo && alpha >= 0) ? memo + (int64_t)strip * K + alpha : nullptr;
+    if (my_memo) {
+      const int last_quiet = *my_memo;
+      if (last_quiet) {
+        int newest = 0;
+        const int ew = ncols + 2;                       // extended rectangle: (SH + 2) x (ncols + 2)
+        for (int e = lane; e < (SH + 2) * ew; e += 64) {
+          const int er = e / ew, ec = e - er * ew;
+          const int node = strip_node(g, rs0 - 1 + er, ca - 1 + ec);
+          if (node >= 0) {
+            const int st = stamp[node];
+            newest = st > newest ? st : newest;
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const int o2 = __shfl_xor(newest, off, 64);
+          newest = o2 > newest ? o2 : newest;
+        }
+        if (newest < last_quiet) continue;
+      }
+    }
+
     // ---- phase 0 (expansions): node_mask[i] has bit a set when node i could possibly profit from label a
     //      (alpha_mask_kernel).  A strip none of whose cells has bit alpha is left alone after 5 coalesced-ish loads.
     if (node_mask && alpha >= 0) {
@@ -173,7 +199,10 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
           if (node >= 0) any |= ((node_mask[node] >> alpha) & 1ull) != 0;
         }
       }
-      if (!__any(any)) continue;
+      if (!__any(any)) {
+        if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+        continue;
+      }
     }
 
     // ---- phase 1: lane <-> cell (cell t = 64 p + lane): unary costs against the fixed outside, weights / label
@@ -269,7 +298,10 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
         t_hi = last > t_hi ? last : t_hi;
       }
     }
-    if (t_hi < 0 || debug == 1) continue;   // nothing can move in this strip (wave-uniform)
+    if (t_hi < 0 || debug == 1) {           // nothing can move in this strip (wave-uniform)
+      if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+      continue;
+    }
     t_lo = __builtin_amdgcn_readfirstlane(t_lo);
     int t_end = __builtin_amdgcn_readfirstlane(t_hi) + SH + 1;
     {   // widen to whole groups of 6 steps counted from each pass start (the DP passes run in such groups)
@@ -328,12 +360,19 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     }
 
     // ---- phase 3: lane <-> cell: apply
+    bool moved = false;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       if (xsel[p] && rnode[p] >= 0) {
         labels[rnode[p]] = prop ? prop[rnode[p]] : (uint8_t)alpha;
+        if (stamp) stamp[rnode[p]] = (uint16_t)tick;
         ++my_changed;
+        moved = true;
       }
+    }
+    {
+      const bool any_moved = __any(moved);
+      if (my_memo && lane == 0) *my_memo = any_moved ? (uint16_t)0 : (uint16_t)tick;
     }
   }
   unsigned int s = my_changed;
@@ -502,7 +541,8 @@ static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: ph
 }
 
 // alpha < 0: fusion with the proposals in b->labels_tmp (launch_propose); alpha >= 0: strip alpha-expansion
-int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask) {
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
+                      int geom) {
   StripGeom g;
   g.H = b->H;
   g.W = b->W;
@@ -521,7 +561,11 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   if (grid > 256 * 32) grid = 256 * 32;
   hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->logprob, b->K, b->D, b->nbr, b->wgt,
                      b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters,
-                     use_mask ? b->alpha_mask : nullptr, strip_debug());
+                     use_mask ? b->alpha_mask : nullptr, strip_debug(), b->tick ? b->stamp : nullptr,
+                     (b->tick && geom >= 0 && alpha >= 0 && (int64_t)nstrips <= b->memo_strips)
+                         ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * b->K
+                         : nullptr,
+                     b->tick);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
