@@ -92,6 +92,12 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C phylo_hmrf_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        try:
+            # PyTorch ships its own libamdhip64; two HIP runtimes in one process do not both see the GPU.  Importing
+            # torch first makes the loader resolve libphmrf.so against the runtime torch uses (plumbing only).
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)

@@ -5,10 +5,11 @@
 // to the strip; p_i = the node's best alternative label: a fusion move that shifts region fronts); all nodes
 // outside the strip are fixed.  The binary problem is solved exactly by a profile ("broken line") dynamic
 // programme over the cells in column-major order: the state is the choice bit of the last STRIP_H+1 = 6 cells,
-// i.e. 64 states = ONE WAVEFRONT with one state per lane.  Everything of the sequential phase lives in registers
-// (no LDS): the per-cell records are broadcast with v_readlane, the two predecessor values of a step are the lane's
-// own value and one in-register lane exchange (DPP / v_permlane16_swap / v_permlane32_swap -- see dp_step), the
-// decision bits are one 64-bit ballot per step, the backtrack is scalar.
+// i.e. 64 states = ONE WAVEFRONT with one state per lane.  Per pass of 64 cells the cost of a cell for every
+// combination of (own bit, three neighbour bits) is tabulated in a 5 KB LDS slab; a DP step is then two LDS reads that
+// do not depend on the DP state, one in-register lane exchange (DPP / v_permlane16_swap / v_permlane32_swap -- see
+// dp_step) for the two predecessor values, a compare whose mask IS the decision ballot, and an add.  The decision
+// ballots stay in registers (lane t mod 64 of a per-pass register pair); the backtrack is scalar.
 // No submodularity is needed (the DP is exact for any 2x2 tables), so fusion proposals are as valid as expansions.
 // Strips of one pass are separated by one fixed row and one fixed column, so simultaneous moves share no edge:
 // the pass never raises the energy.   (Model: oracle/mrf_moves.strip_fusion.)
@@ -75,29 +76,57 @@ __device__ __forceinline__ float xor_exchange(float v) {
   return __builtin_bit_cast(float, (int)((threadIdx.x & 32) ? r[0] : r[1]));
 }
 
+// ---- per-cell cost tables (LDS, one pass of 64 cells at a time) ---------------------------------------------------
+// Cell record in LDS (20 floats = 80 B, conflict-free for ds_write_b128 at this stride):
+//   [0..15]  base[b][bu][bl][bld] = c_b + wu*N_u[b][bu] + wl*N_l[b][bl] + wld*N_ld[b][bld]
+//   [16..19] lu[b][d]             = wlu*N_lu[b][d]           (d = choice of the left-up cell leaving the profile)
+constexpr int TAB = 20;
+
+__device__ __forceinline__ void build_table(float* tab, int lane, float c0, float c1, float wu, float wlu, float wl,
+                                            float wld, int bits) {
+  float4* dst = reinterpret_cast<float4*>(tab + lane * TAB);
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = g4 * 4 + e;
+      const int b = idx >> 3, bu = (idx >> 2) & 1, bl = (idx >> 1) & 1, bld = idx & 1;
+      float x = b ? c1 : c0;
+      if ((bits >> (0 + b * 2 + bu)) & 1) x += wu;
+      if ((bits >> (8 + b * 2 + bl)) & 1) x += wl;
+      if ((bits >> (12 + b * 2 + bld)) & 1) x += wld;
+      v[e] = x;
+    }
+    dst[g4] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  dst[4] = make_float4(((bits >> 4) & 1) ? wlu : 0.f, ((bits >> 5) & 1) ? wlu : 0.f, ((bits >> 6) & 1) ? wlu : 0.f,
+                       ((bits >> 7) & 1) ? wlu : 0.f);
+}
+
 // One cell step of the profile DP.  The profile is kept in ROTATING positions: cell t owns bit (t mod 6) of the state
 // index (= lane id), so stepping to cell t overwrites the bit of cell t-6 (the left-up neighbour, about to leave the
-// profile) and new[s] = min over that old bit d of old[s with bit q := d] + cost: the two candidates live in lanes
-// s and s ^ (1<<q) -- ONE lane exchange.  Neighbours: up = t-1 at bit q-1, left = t-5 at q+1, left-down = t-4 at q+2.
+// profile) and new[s] = base[s] + min over that old bit d of (old[s with bit q := d] + lu[b][d]): the two candidates
+// live in lanes s and s ^ (1<<q) -- ONE in-register lane exchange.  Neighbours: up = t-1 at bit q-1, left = t-5 at
+// q+1, left-down = t-4 at q+2; the lane's table index (b, bu, bl, bld) is therefore a compile-time function of
+// (lane, q).  base / lu come from two LDS reads that do not depend on the DP state (issued one step ahead).
 template <int Q>
-__device__ __forceinline__ void dp_step(float& m, int lane, float c0, float c1, float wu, float wlu, float wl,
-                                        float wld, int bits, unsigned long long* decision) {
+__device__ __forceinline__ int tab_offset(int lane) {   // byte offsets of this lane's entries for position Q
   constexpr int QU = (Q + 5) % 6, QL = (Q + 1) % 6, QLD = (Q + 2) % 6;
+  const int b = (lane >> Q) & 1, bu = (lane >> QU) & 1, bl = (lane >> QL) & 1, bld = (lane >> QLD) & 1;
+  return (b * 8 + bu * 4 + bl * 2 + bld) * 4;
+}
+
+template <int Q>
+__device__ __forceinline__ void dp_step(float& m, int lane, float base, float lu0, float lu1, unsigned long long* decision) {
   const int b = (lane >> Q) & 1;
-  const int bu = (lane >> QU) & 1, bl = (lane >> QL) & 1, bld = (lane >> QLD) & 1;
-  float base = b ? c1 : c0;
-  if ((bits >> (0 + b * 2 + bu)) & 1) base += wu;
-  if ((bits >> (8 + b * 2 + bl)) & 1) base += wl;
-  if ((bits >> (12 + b * 2 + bld)) & 1) base += wld;
-  const float lu0 = ((bits >> (4 + b * 2)) & 1) ? wlu : 0.f;
-  const float lu1 = ((bits >> (5 + b * 2)) & 1) ? wlu : 0.f;
   const float other = xor_exchange<Q>(m);
   const float o0 = b ? other : m;      // old value of the state whose bit q (cell t-6) is 0
   const float o1 = b ? m : other;      //                                              is 1
-  const float a0 = o0 + base + lu0;
-  const float a1 = o1 + base + lu1;
-  const bool take1 = a1 < a0;
-  m = take1 ? a1 : a0;
+  const float e0 = o0 + lu0;
+  const float e1 = o1 + lu1;
+  const bool take1 = e1 < e0;
+  m = base + (take1 ? e1 : e0);
   *decision = __ballot(take1);
 }
 
@@ -108,33 +137,71 @@ __device__ __forceinline__ void write_lane(unsigned int& dst, unsigned int value
   dst = ((int)(threadIdx.x & 63) == lane_sel) ? value : dst;
 }
 
-// All steps of pass P (cells t = 64 P + tt): records broadcast with v_readlane, decisions parked in lane tt.
+// All steps of pass P (cells t = 64 P + tt): the pass's 64 cell tables are built into the wave's LDS slab, then walked.
 template <int P>
-__device__ __forceinline__ void dp_pass(float& m, int lane, float c0, float c1, float wu, float wlu, float wl, float wld,
-                                        int bits, int t_lo, int t_end, unsigned int& dlo, unsigned int& dhi) {
+__device__ __forceinline__ void dp_pass(float& m, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
+                                        float wld, int bits, int t_lo, int t_end, unsigned int& dlo, unsigned int& dhi) {
   dlo = 0u;
   dhi = 0u;
   if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
+  build_table(tab, lane, c0, c1, wu, wlu, wl, wld, bits);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   // [t_lo, t_end] is wave-uniform and already widened to whole groups of 6 steps (cells outside the true range are
   // pinned or absent, so visiting them is harmless); the only per-step test left is the static tail of the pass.
   int tb0 = t_lo - P * 64;
   tb0 = tb0 < 0 ? 0 : tb0 - tb0 % 6;
   int tb1 = t_end - P * 64;
   tb1 = tb1 > 63 ? 63 : tb1;
+  const char* tabc = reinterpret_cast<const char*>(tab);
   for (int tb = tb0; tb <= tb1; tb += 6) {   // rotating position q = t mod 6 = (4 P + tt) mod 6: static in the 6-unroll
 #define PHMRF_STEP(J)                                                                                                \
   {                                                                                                                  \
     const int tt = tb + J;                                                                                           \
     if (J < 4 || tt < 64) {                                                                                          \
+      constexpr int Q = (4 * P + J) % 6;                                                                             \
+      const char* rec = tabc + tt * (TAB * 4);                                                                       \
+      const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(lane));                                 \
+      const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((lane >> Q) & 1) * 8);                          \
       unsigned long long dec;                                                                                        \
-      dp_step<(4 * P + J) % 6>(m, lane, PHMRF_RL(c0, tt), PHMRF_RL(c1, tt), PHMRF_RL(wu, tt), PHMRF_RL(wlu, tt),     \
-                               PHMRF_RL(wl, tt), PHMRF_RL(wld, tt), __builtin_amdgcn_readlane(bits, tt), &dec);      \
+      dp_step<Q>(m, lane, base, lu.x, lu.y, &dec);                                                                   \
       write_lane(dlo, (unsigned int)(dec & 0xffffffffull), tt);                                                      \
       write_lane(dhi, (unsigned int)(dec >> 32), tt);                                                                \
     }                                                                                                                \
   }
     PHMRF_STEP(0) PHMRF_STEP(1) PHMRF_STEP(2) PHMRF_STEP(3) PHMRF_STEP(4) PHMRF_STEP(5)
 #undef PHMRF_STEP
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Backtrack of pass P on scalars: x_t = bit q of the state, then the state gets back the bit of cell t-6.
+template <int P>
+__device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, unsigned int dlo, unsigned int dhi,
+                                               unsigned int& xsel) {
+  xsel = 0u;
+  if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
+  int tb0 = t_lo - P * 64;
+  tb0 = tb0 < 0 ? 0 : tb0 - tb0 % 6;
+  int tb1 = t_end - P * 64;
+  tb1 = tb1 > 63 ? 63 : tb1;
+  tb1 = tb1 - tb1 % 6;                        // first step of the last group
+  for (int tb = tb1; tb >= tb0; tb -= 6) {
+#define PHMRF_BACK(J)                                                                                                \
+  {                                                                                                                  \
+    const int tt = tb + J;                                                                                           \
+    if (J < 4 || tt < 64) {                                                                                          \
+      constexpr int Q = (4 * P + J) % 6;                                                                             \
+      const unsigned long long dec = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, tt) << 32) | \
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, tt);      \
+      const int x = (s >> Q) & 1;                                                                                    \
+      const int d = (int)((dec >> s) & 1ull);                                                                        \
+      s = (s & ~(1 << Q)) | (d << Q);                                                                                \
+      write_lane(xsel, (unsigned int)x, tt);                                                                         \
+    }                                                                                                                \
+  }
+    PHMRF_BACK(5) PHMRF_BACK(4) PHMRF_BACK(3) PHMRF_BACK(2) PHMRF_BACK(1) PHMRF_BACK(0)
+#undef PHMRF_BACK
   }
 }
 
@@ -146,9 +213,11 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
                                                     int alpha, float beta, unsigned long long* __restrict__ changed,
                                                     const unsigned long long* __restrict__ node_mask, int debug,
                                                     uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo, int tick) {
+  __shared__ float tabs[4 * 64 * TAB];   // one 5 KB slab per wave: the cost tables of the pass being walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
+  float* tab = tabs + wave * 64 * TAB;
   unsigned int my_changed = 0;
 
   for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {   // waves are independent
@@ -318,11 +387,11 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     //      parked in lane (t mod 64) of a per-pass register pair.
     float m = lane == 0 ? 0.f : BIG;     // every cell before t_lo keeps its label: profile 000000
     unsigned int dlo[NPASS], dhi[NPASS];
-    dp_pass<0>(m, lane, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
-    dp_pass<1>(m, lane, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
-    dp_pass<2>(m, lane, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
-    dp_pass<3>(m, lane, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
-    dp_pass<4>(m, lane, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
+    dp_pass<0>(m, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
+    dp_pass<1>(m, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
+    dp_pass<2>(m, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
+    dp_pass<3>(m, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
+    dp_pass<4>(m, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
 
     if (debug == 2) continue;
     // ---- final state: among the minimisers take the one whose SHIFT-encoded index (newest cell in bit 0, as in the
@@ -338,26 +407,12 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
 
     // ---- backtrack on scalars; the choice of cell t lands in lane (t mod 64) of xsel[pass]
     unsigned int xsel[NPASS];
-#pragma unroll
-    for (int p = NPASS - 1; p >= 0; --p) {
-      xsel[p] = 0u;
-      if (p * 64 > t_end || p * 64 + 63 < t_lo) continue;
-      int tt_hi = t_end - p * 64;
-      tt_hi = tt_hi > 63 ? 63 : tt_hi;
-      int tt_lo = t_lo - p * 64;
-      tt_lo = tt_lo < 0 ? 0 : tt_lo;
-      for (int tt = tt_hi; tt >= tt_lo; --tt) {
-        const int t = p * 64 + tt;
-        const int q = t % 6;
-        const unsigned long long dec =
-            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi[p], tt) << 32) |
-            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo[p], tt);
-        const int x = (s >> q) & 1;
-        const int d = (int)((dec >> s) & 1ull);
-        s = (s & ~(1 << q)) | (d << q);
-        write_lane(xsel[p], (unsigned int)x, tt);
-      }
-    }
+    s = __builtin_amdgcn_readfirstlane(s);
+    backtrack_pass<4>(s, t_lo, t_end, dlo[4], dhi[4], xsel[4]);
+    backtrack_pass<3>(s, t_lo, t_end, dlo[3], dhi[3], xsel[3]);
+    backtrack_pass<2>(s, t_lo, t_end, dlo[2], dhi[2], xsel[2]);
+    backtrack_pass<1>(s, t_lo, t_end, dlo[1], dhi[1], xsel[1]);
+    backtrack_pass<0>(s, t_lo, t_end, dlo[0], dhi[0], xsel[0]);
 
     // ---- phase 3: lane <-> cell: apply
     bool moved = false;

@@ -478,3 +478,74 @@ def test_error_paths_and_label_slots():
     with pytest.raises(PhmrfError):
         b.restore_labels(2)
     b.close()
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_full_size_cfg2_properties():
+    """BASELINE configs[1] at full size (2000 x 2000 diagonal block, 2,001,000 nodes, S=4, K=10) through
+    size-independent properties: sampled emission rows vs the float64 oracle, sampled adjacency rows vs the restated
+    edge builder, energy monotone under the solver and equal to the oracle's energy of the returned labels, statistics
+    identities (sum_k post = n, sum_k obs*obs.T = X^T X, sum_k obs = sum_i x_i), idempotence of the converged solve."""
+    import torch
+    from phylo_hmrf_amd import Block, synthetic
+    from phylo_hmrf_amd.tree import PhyloTree
+    N, S, K = 2000, 4, 10
+    n = N * (N + 1) // 2
+    tree = PhyloTree(synthetic.tree_for(S))
+    rng = np.random.default_rng(0)
+    P = synthetic.sample_ou_params(rng, tree, K)
+    mu, cv = tree.mean_cov(P)
+    cv = cv + 1e-3 * np.eye(S)
+    dev = torch.device("cuda", 0)
+    Xd = synthetic.device_observations(torch, dev, 5, N, N, True, K, mu, cv)
+    torch.cuda.synchronize()
+    X = Xd.cpu().numpy().astype(np.float64)
+    b = Block(n, S, K)
+    b.set_observations_dev(Xd.data_ptr())
+    b.sync()
+    b.build_grid_graph(N, N, True, 8, 0.5)
+    b.emission(mu, cv)
+    lp = b.get_logprob()
+    idx = rng.choice(n, 20000, replace=False)
+    ref = R.log_multivariate_normal_density_full(X[idx], mu, cv)
+    assert np.all(np.abs(lp[idx] - ref) <= _emission_tol(ref))
+    # adjacency of sampled nodes: neighbours are exactly the valid 8-stencil cells, weights exp(-beta1 d)
+    nbr, wgt = b.get_adjacency()
+    ii, jj = np.triu_indices(N)
+    start = np.concatenate([[0], np.cumsum(N - np.arange(N))])
+    for v in rng.choice(n, 300, replace=False):
+        i, j = ii[v], jj[v]
+        exp_ids, exp_w = [], []
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                a, c = i + di, j + dj
+                if (di or dj) and 0 <= a < N and 0 <= c < N and a <= c:
+                    u = start[a] + (c - a)
+                    d = ((X[v] - X[u]) ** 2).sum() / (np.linalg.norm(X[v]) * np.linalg.norm(X[u]) + 1e-16)
+                    if i == j and a == c:
+                        d *= 0.5
+                    exp_ids.append(u)
+                    exp_w.append(np.exp(-0.5 * d))
+        got = nbr[v][nbr[v] >= 0]
+        assert list(got) == sorted(exp_ids)
+        order = np.argsort(exp_ids)
+        np.testing.assert_allclose(wgt[v][:len(got)], np.array(exp_w)[order], rtol=2e-6, atol=1e-7)
+    res = b.solve(1.0, init_mode=1)
+    assert res["converged"] and res["energy"] < res["energy_init"]
+    labels = b.get_labels()
+    # oracle energy of the returned labels from the device adjacency (each undirected edge appears twice)
+    e_un = -lp[np.arange(n), labels].sum()
+    valid = nbr >= 0
+    diff = valid & (labels[np.where(valid, nbr, 0)] != labels[:, None])
+    e_pw = 0.5 * (wgt.astype(np.float64) * diff).sum()
+    np.testing.assert_allclose(res["energy"], e_un + e_pw, rtol=1e-6)
+    res2 = b.solve(1.0)
+    assert res2["energy"] <= res["energy"] * (1 + 1e-9) and res2["rounds"] <= 2
+    stats, costs, _ = b.posterior_stats(1.0, 3)
+    np.testing.assert_allclose(stats["post"].sum(), n, rtol=1e-6)
+    np.testing.assert_allclose(stats["obs"].sum(axis=0), X.sum(axis=0), rtol=2e-5)
+    np.testing.assert_allclose(stats["obs*obs.T"].sum(axis=0), X.T @ X, rtol=2e-5)
+    np.testing.assert_allclose(costs[2], e_un, rtol=1e-6)          # unary cost numerator = unary energy
+    np.testing.assert_allclose(costs[0], 2.0 * e_pw, rtol=1e-5)    # pairwise cost counts every edge from both ends
+    np.testing.assert_allclose(costs[3], costs[1] + costs[2], rtol=1e-12)
+    b.close()
