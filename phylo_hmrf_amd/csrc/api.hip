@@ -316,11 +316,11 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
   if (st == PHMRF_OK) guard(dev_alloc(&b->labels, (size_t)n));
   if (st == PHMRF_OK) guard(dev_alloc(&b->labels_tmp, (size_t)n));
   if (st == PHMRF_OK) guard(dev_alloc(&b->accum, (size_t)ACCUM_DOUBLES));
-  if (st == PHMRF_OK) guard(dev_alloc(&b->counters, (size_t)(8 + 64)));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->counters, (size_t)128));
   if (st == PHMRF_OK) guard(dev_alloc(&b->emis_params, (size_t)K * (S + S * (S + 1) / 2 + 1)));
   if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->accum_host), ACCUM_DOUBLES * sizeof(double)) != hipSuccess)
     guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
-  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->counters_host), (8 + 64) * sizeof(unsigned long long)) != hipSuccess)
+  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->counters_host), 128 * sizeof(unsigned long long)) != hipSuccess)
     guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
   if (st == PHMRF_OK && (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess))
     guard(fail(PHMRF_ERR_HIP, "hipEventCreate failed"));
@@ -706,7 +706,8 @@ static int read_counter(phmrf_block_t b, int64_t* v) {
 }
 
 static int zero_counter(phmrf_block_t b) {
-  PHMRF_HIP(hipMemsetAsync(b->counters, 0, (8 + 64) * sizeof(unsigned long long), b->stream));
+  PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
+  b->counter_slot = 0;
   return PHMRF_OK;
 }
 
@@ -845,21 +846,27 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   const bool chains = o.use_chains && b->has_grid;
   const bool strips = o.use_strips && b->has_grid;
   const int64_t tol = o.min_changed > 0 ? o.min_changed : 0;
-  // One round = chain moves, ICM, component moves, strip fusion (both orientations), then strip alpha-expansions for the
-  // ACTIVE labels.  A label stays active while its expansions still move something; when the active set runs dry, or
-  // a round no longer lowers the energy, a VERIFICATION round with every label active decides: quiet -> done.
-  // "Quiet" = at most `min_changed` labels changed OR the energy did not go down.  (Two labellings of exactly equal
-  // energy can each be the canonical minimiser of a different move type and would otherwise alternate forever; gco
-  // stops on the same criterion, GCoptimization.cpp:1298: while old_energy > new_energy.)
-  double e_prev_u = 0, e_prev_p = 0;
-  PHMRF_TRY(energy_now(b, beta, &e_prev_u, &e_prev_p));
-  double e_prev = e_prev_u + e_prev_p;
   const int K = b->K;
-  std::vector<char> active(K, 1);
+  // move types and their change counters (slot in b->counters): chain families 72..75, ICM 76, components 77,
+  // strip fusion 78/79, strip expansion of label a: 8 + a.
+  const bool expansions = strips && o.use_expansion;
+  const int n_fam = chains ? (int)b->families.size() : 0;
+  std::vector<int> slots;
+  for (int f = 0; f < n_fam; ++f) slots.push_back(72 + f);
+  slots.push_back(76);
+  if (o.use_components) slots.push_back(77);
+  if (strips) {
+    slots.push_back(78);
+    slots.push_back(79);
+  }
+  if (expansions)
+    for (int a = 0; a < K; ++a) slots.push_back(8 + a);
+  std::vector<char> active(128, 0);
+  for (int sl : slots) active[sl] = 1;
   bool all_active = true;
   // change stamps + per-strip memo of quiet expansions (exact skip of strips whose inputs did not change)
   static const int GEOM_R[3] = {0, 2, 4}, GEOM_C[3] = {0, 21, 42};
-  if (strips && o.use_expansion) {
+  if (expansions) {
     int64_t max_strips = 0;
     for (int orient = 0; orient < 2; ++orient) {
       const int Hs = orient ? b->W : b->H, Ws = orient ? b->H : b->W;
@@ -876,17 +883,35 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * K * sizeof(uint16_t), b->stream));
     b->tick = 1;
   }
-  struct TickOff {
+  struct SolveScope {
     phmrf_block* blk;
-    ~TickOff() { blk->tick = 0; }
-  } tick_off{b};
+    ~SolveScope() {
+      blk->tick = 0;
+      blk->counter_slot = 0;
+    }
+  } scope{b};
+  // One round runs every ACTIVE move type: chain families, ICM, component moves, strip fusion per orientation, strip
+  // alpha-expansion per label.  A type stays active while it still changes labels.  When a round is quiet (at most
+  // `min_changed` labels changed, or the energy did not go down) a VERIFICATION round with every type active decides:
+  // quiet again -> done.  (The energy test also ends the alternation between two labellings of exactly equal energy
+  // that different move types prefer; gco stops on the same criterion, GCoptimization.cpp:1298.)
+  double e_prev_u = 0, e_prev_p = 0;
+  PHMRF_TRY(energy_now(b, beta, &e_prev_u, &e_prev_p));
+  double e_prev = e_prev_u + e_prev_p;
   while (rounds < o.max_rounds) {
     const int r = rounds;
-    PHMRF_HIP(hipMemsetAsync(b->counters, 0, (8 + 64) * sizeof(unsigned long long), b->stream));
-    if (chains)
-      for (int f = 0; f < (int)b->families.size(); ++f) PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1));
-    PHMRF_TRY(icm_sweep_nocount(b, bf));
-    if (o.use_components) {
+    PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
+    for (int f = 0; f < n_fam; ++f)
+      if (active[72 + f]) {
+        b->counter_slot = 72 + f;
+        PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1));
+      }
+    if (active[76]) {
+      b->counter_slot = 76;
+      PHMRF_TRY(icm_sweep_nocount(b, bf));
+    }
+    if (o.use_components && active[77]) {
+      b->counter_slot = 77;
       if (b->tick) ++b->tick;
       tic(b);
       PHMRF_TRY(launch_component_pass(b, bf));
@@ -894,50 +919,58 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     if (strips) {
       for (int orient = 0; orient < 2; ++orient) {
-        const int sr = (2 * r + 3 * orient) % 6, sc = (17 * r + 31 * orient) % 64;
-        PHMRF_TRY(strip_pass_nocount(b, bf, orient, sr, sc, -1));
-        if (o.use_expansion) {
+        if (active[78 + orient]) {
+          b->counter_slot = 78 + orient;
+          PHMRF_TRY(strip_pass_nocount(b, bf, orient, (2 * r + 3 * orient) % 6, (17 * r + 31 * orient) % 64, -1));
+        }
+        if (expansions) {
           const int geom = r % 3;                   // expansions cycle through three fixed cuts so the memo applies
-          tic(b);
-          PHMRF_TRY(launch_alpha_mask(b, bf));      // which labels can still pay off where (fresh per orientation)
-          toc(b, KC_PROPOSE, 1);
+          bool any = false;
+          for (int a = 0; a < K; ++a) any = any || active[8 + a];
+          if (any) {
+            tic(b);
+            PHMRF_TRY(launch_alpha_mask(b, bf));    // which labels can still pay off where (fresh per orientation)
+            toc(b, KC_PROPOSE, 1);
+          }
           for (int a = 0; a < K; ++a)
-            if (active[a]) PHMRF_TRY(strip_pass_nocount(b, bf, orient, GEOM_R[geom], GEOM_C[geom], a, true, geom));
+            if (active[8 + a]) {
+              b->counter_slot = 8 + a;
+              PHMRF_TRY(strip_pass_nocount(b, bf, orient, GEOM_R[geom], GEOM_C[geom], a, true, geom));
+            }
         }
       }
     }
-    PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, (8 + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    b->counter_slot = 0;
+    PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                              b->stream));
     double eu = 0, ep = 0;
     PHMRF_TRY(energy_now(b, beta, &eu, &ep));       // synchronises the stream
     const double e_now = eu + ep;
-    const int64_t ch = (int64_t)b->counters_host[0];
+    int64_t ch = 0;
+    for (int sl : slots) ch += (int64_t)b->counters_host[sl];
     total += ch;
     ++rounds;
     const bool improved = e_now < e_prev - 1e-11 * std::fabs(e_prev);
     if (e_now < e_prev) e_prev = e_now;
     const bool quiet = ch <= tol || !improved;
-    const bool expansions = strips && o.use_expansion;
     if (quiet) {
-      if (all_active || !expansions) {
+      if (all_active) {
         converged = 1;
         break;
       }
-      std::fill(active.begin(), active.end(), 1);    // verification round
+      for (int sl : slots) active[sl] = 1;           // verification round
       all_active = true;
       continue;
     }
-    if (expansions) {
-      int n_act = 0;
-      for (int a = 0; a < K; ++a) {
-        active[a] = b->counters_host[8 + a] > 0 ? 1 : 0;
-        n_act += active[a];
-      }
-      all_active = n_act == K;
-      if (n_act == 0) {
-        std::fill(active.begin(), active.end(), 1);
-        all_active = true;
-      }
+    int n_act = 0;
+    for (int sl : slots) {
+      active[sl] = b->counters_host[sl] > 0 ? 1 : 0;
+      n_act += active[sl];
+    }
+    all_active = n_act == (int)slots.size();
+    if (n_act == 0) {
+      for (int sl : slots) active[sl] = 1;
+      all_active = true;
     }
   }
   b->has_labels = true;

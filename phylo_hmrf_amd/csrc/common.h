@@ -100,6 +100,7 @@ struct phmrf_block {
   uint16_t* memo = nullptr;                 // device [2][3][memo_strips][K]
   int64_t memo_strips = 0;
   int tick = 0;                             // host launch counter inside one solve (0 = stamping off)
+  int counter_slot = 0;                     // which of counters[128] the next move launches add their changes to
 
   float* emis_params = nullptr;             // device packed emission parameters
   float* posteriors = nullptr;              // device [n, K], allocated on demand

@@ -498,9 +498,9 @@ int launch_icm_colour(const phmrf_block* b, float beta, int colour) {
   const int grid = grid_for(count, TB);
   const int32_t* nodes = b->colour_nodes + lo;
   switch (vec_of(K)) {
-    case 4: hipLaunchKernelGGL((icm_kernel<4>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters, b->tick ? b->stamp : nullptr, b->tick); break;
-    case 2: hipLaunchKernelGGL((icm_kernel<2>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters, b->tick ? b->stamp : nullptr, b->tick); break;
-    default: hipLaunchKernelGGL((icm_kernel<1>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters, b->tick ? b->stamp : nullptr, b->tick); break;
+    case 4: hipLaunchKernelGGL((icm_kernel<4>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick); break;
+    case 2: hipLaunchKernelGGL((icm_kernel<2>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick); break;
+    default: hipLaunchKernelGGL((icm_kernel<1>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, nodes, count, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick); break;
   }
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;

@@ -374,7 +374,7 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
 #define PHMRF_LAUNCH_CHAIN(VEC_)                                                                                      \
   hipLaunchKernelGGL((chain_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, f.nodes,                  \
                      f.seg_start[phase][colour], f.seg_len[phase][colour], nseg, K, Kp, b->D, b->nbr, b->wgt, b->labels, \
-                     beta, b->counters, chain_debug(), b->tick ? b->stamp : nullptr, b->tick)
+                     beta, b->counters + b->counter_slot, chain_debug(), b->tick ? b->stamp : nullptr, b->tick)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_CHAIN(4); break;
     case 2: PHMRF_LAUNCH_CHAIN(2); break;
@@ -427,7 +427,7 @@ int launch_component_pass(phmrf_block* b, float beta) {
                      b->comp_gain);
   hipLaunchKernelGGL(comp_block_kernel, dim3(g), dim3(256), 0, st, n, D, b->nbr, b->comp, b->comp_gain, b->comp_move);
   hipLaunchKernelGGL(comp_apply_kernel, dim3(g), dim3(256), 0, st, n, b->comp, b->comp_best, b->comp_move, b->labels,
-                     b->counters, b->tick ? b->stamp : nullptr, b->tick);
+                     b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

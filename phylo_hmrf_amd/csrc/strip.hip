@@ -433,10 +433,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
   unsigned int s = my_changed;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0 && s) {
-    atomicAdd(changed, (unsigned long long)s);
-    if (alpha >= 0) atomicAdd(changed + 8 + alpha, (unsigned long long)s);   // per-label activity (solve schedule)
-  }
+  if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
 }
 
 // best alternative label per node: argmin_{k != l_i} ( -logprob[i,k] - beta * sum_{j in N(i), l_j == k} w_ij )
@@ -615,7 +612,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   int grid = (nstrips + WPB - 1) / WPB;
   if (grid > 256 * 32) grid = 256 * 32;
   hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->logprob, b->K, b->D, b->nbr, b->wgt,
-                     b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters,
+                     b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters + b->counter_slot,
                      use_mask ? b->alpha_mask : nullptr, strip_debug(), b->tick ? b->stamp : nullptr,
                      (b->tick && geom >= 0 && alpha >= 0 && (int64_t)nstrips <= b->memo_strips)
                          ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * b->K
