@@ -212,7 +212,7 @@ def main():
     if dom_launches and dom_ms > 0 and dom_bytes > 0:
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a.workload, dom_name),
                     "avg_launch_us": round(dom_ms * 1e3 / dom_launches, 2), "launches": int(dom_launches),
                     "algorithmic_bytes_per_launch": int(dom_bytes / dom_launches)}
     kernels = {k: {"ms": round(v[0], 3), "launches": int(v[1]),
@@ -240,6 +240,19 @@ def main():
     mstep.close_pool()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, kernel_class):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; see profiles/README.md).
+    None when no measurement for this workload / kernel is on file."""
+    fn = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        d = json.load(open(fn))
+        rec = d[workload][kernel_class]
+        return int(rec["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(a, S, K, nn):
