@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=360, help="side N of the diagonal block used for the CPU baseline")
     ap.add_argument("--no-expansion", action="store_true")
+    ap.add_argument("--energy-tol-ppb", type=int, default=1000,
+                    help="stop the label solver when a round lowers the energy by less than this many ppb (0 = exact "
+                         "fixed point); energy parity with gco at this setting: tests/test_gpu_estep.py")
     return ap.parse_args()
 
 
@@ -131,7 +134,8 @@ def main():
     setup_s = time.time() - t_setup
     stats_dev = torch.zeros((len(blocks), n_stats + 4), dtype=torch.float64, device=dev)
     state = dict(min_cost=1e30, params=params_cur, means=means, covars=covars)
-    solver = dict(max_rounds=64, use_chains=True, use_components=True, use_strips=True, use_expansion=not a.no_expansion)
+    solver = dict(max_rounds=64, use_chains=True, use_components=True, use_strips=True, use_expansion=not a.no_expansion,
+                  energy_tol_ppb=a.energy_tol_ppb)
     n_global = n_total * world
     t_e, t_m = [], []
 

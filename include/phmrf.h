@@ -118,8 +118,9 @@ typedef struct phmrf_solve_opts {
   int use_strips;      /* 1: exact 5-row strip fusion moves (needs the grid)                                   */
   int use_expansion;   /* 1: strip alpha-expansion sweeps (one per label and orientation) whenever the cheaper
                           moves have gone quiet; the solve ends when such a sweep is quiet too                  */
-  int min_changed;     /* a round / sweep that changes at most this many labels counts as quiet (default 0)     */
-  int reserved[1];
+  int min_changed;     /* a round that changes at most this many labels counts as quiet (default 0)             */
+  int energy_tol_ppb;  /* > 0: stop as soon as a round lowers the energy by less than this many parts per billion
+                          of |E| (no verification round); 0: run to the exact fixed point                       */
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {

@@ -108,19 +108,19 @@ class Block(object):
 
     # -- b2 ---------------------------------------------------------------------------------------
     def solve(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
-              use_expansion=True, min_changed=0):
+              use_expansion=True, min_changed=0, energy_tol_ppb=0):
         o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
-                      int(use_expansion), int(min_changed))
+                      int(use_expansion), int(min_changed), int(energy_tol_ppb))
         r = SolveResult()
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), ctypes.byref(r)))
         return dict(energy=r.energy, energy_unary=r.energy_unary, energy_pair=r.energy_pair,
                     energy_init=r.energy_init, rounds=r.rounds, converged=bool(r.converged), changed=r.changed)
 
     def solve_fast(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
-                   use_expansion=True, min_changed=0):
+                   use_expansion=True, min_changed=0, energy_tol_ppb=0):
         """Same without the two energy evaluations."""
         o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
-                      int(use_expansion), int(min_changed))
+                      int(use_expansion), int(min_changed), int(energy_tol_ppb))
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), None))
 
     def icm_sweep(self, beta):

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -951,7 +952,18 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     total += ch;
     ++rounds;
     const bool improved = e_now < e_prev - 1e-11 * std::fabs(e_prev);
+    if (getenv("PHMRF_SOLVE_TRACE")) {
+      int n_active = 0;
+      for (int sl : slots) n_active += active[sl];
+      fprintf(stderr, "[phmrf solve] round %d active %d/%d changed %lld energy %.6f delta %.3e\n", r, n_active,
+              (int)slots.size(), (long long)ch, e_now, e_now - e_prev);
+    }
+    const double gain = e_prev - e_now;
     if (e_now < e_prev) e_prev = e_now;
+    if (o.energy_tol_ppb > 0 && gain < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
+      converged = 1;                                  // accepted tolerance: the remaining moves are worth less
+      break;
+    }
     const bool quiet = ch <= tol || !improved;
     if (quiet) {
       if (all_active) {
