@@ -94,8 +94,12 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.load().phmrf_set_device(local_rank))
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PHMRF_FORCE_DIST=1 exercises the RCCL path (all-reduce, broadcast, barrier) with a single rank
+    use_dist = world > 1 or os.environ.get("PHMRF_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- synthetic multi-species Hi-C, generated on the device ----------------------------
@@ -149,7 +153,7 @@ def main():
         for b in blocks:
             b.sync()
         tot = stats_dev.sum(dim=0)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tot)                               # RCCL: K(1+S+S^2)+4 doubles
         tot = tot.cpu().numpy()
         stats = unpack_stats(tot[:n_stats], K, S)
@@ -165,7 +169,7 @@ def main():
             packed = np.concatenate([p.ravel(), mu.ravel(), cv.ravel()])
         else:
             packed = np.zeros(K * (tree.n_params + S + S * S))
-        if world > 1:
+        if use_dist:
             t = torch.from_numpy(packed).to(dev)
             dist.broadcast(t, src=0)
             packed = t.cpu().numpy()
@@ -179,7 +183,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -195,7 +199,7 @@ def main():
         em_step()
     barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -238,12 +242,19 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, S, K, nn)
-        print(json.dumps(out))
     for b in blocks:
         b.close()
     mstep.close_pool()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:     # the JSON line must be the LAST line on stdout: RCCL (NCCL_DEBUG=VERSION) leaves a banner in
+        try:          # libc's stdout buffer that would otherwise be flushed after it, at exit
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def pmc_traffic(workload, kernel_class):

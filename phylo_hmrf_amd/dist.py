@@ -37,9 +37,12 @@ class Reducer(object):
         self.device = device
         self._buf = None
         if world > 1:
+            import torch
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised before a multi-rank fit")
+            if self.device is None and dist.get_backend() == "nccl":      # RCCL needs device tensors
+                self.device = torch.device("cuda", torch.cuda.current_device())
 
     def allreduce(self, vec):
         vec = np.ascontiguousarray(vec, dtype=np.float64)
