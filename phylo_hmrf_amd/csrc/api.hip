@@ -99,6 +99,7 @@ void free_family(ChainFamily& f) {
     for (int c = 0; c < 3; ++c) {
       dev_free(f.seg_start[p][c]);
       dev_free(f.seg_len[p][c]);
+      dev_free(f.memo[p][c]);
     }
 }
 
@@ -357,6 +358,7 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->alpha_mask);
   dev_free(b->stamp);
   dev_free(b->memo);
+  dev_free(b->strip_newest);
   dev_free(b->emis_params);
   dev_free(b->posteriors);
   dev_free(b->accum);
@@ -867,6 +869,17 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   bool all_active = true;
   // change stamps + per-strip memo of quiet expansions (exact skip of strips whose inputs did not change)
   static const int GEOM_R[3] = {0, 2, 4}, GEOM_C[3] = {0, 21, 42};
+  if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
+  PHMRF_HIP(hipMemsetAsync(b->stamp, 0, (size_t)b->n * sizeof(uint16_t), b->stream));
+  b->tick = 1;
+  if (chains)
+    for (auto& f : b->families)
+      for (int p = 0; p < 2; ++p)
+        for (int c = 0; c < f.n_colours; ++c)
+          if (f.nseg[p][c] > 0) {
+            if (!f.memo[p][c]) PHMRF_TRY(dev_alloc(&f.memo[p][c], (size_t)f.nseg[p][c]));
+            PHMRF_HIP(hipMemsetAsync(f.memo[p][c], 0, (size_t)f.nseg[p][c] * sizeof(uint16_t), b->stream));
+          }
   if (expansions) {
     int64_t max_strips = 0;
     for (int orient = 0; orient < 2; ++orient) {
@@ -874,15 +887,16 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       const int64_t ns = (int64_t)((Hs + 5 + 5) / 6) * ((Ws + 63 + 63) / 64);
       max_strips = std::max(max_strips, ns);
     }
-    if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
     if (!b->memo || b->memo_strips < max_strips) {
       dev_free(b->memo);
-      PHMRF_TRY(dev_alloc(&b->memo, (size_t)6 * max_strips * K));
+      dev_free(b->strip_newest);
+      b->memo = nullptr;
+      b->strip_newest = nullptr;
+      PHMRF_TRY(dev_alloc(&b->memo, (size_t)6 * max_strips * (K + 1)));
+      PHMRF_TRY(dev_alloc(&b->strip_newest, (size_t)max_strips));
       b->memo_strips = max_strips;
     }
-    PHMRF_HIP(hipMemsetAsync(b->stamp, 0, (size_t)b->n * sizeof(uint16_t), b->stream));
-    PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * K * sizeof(uint16_t), b->stream));
-    b->tick = 1;
+    PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * (K + 1) * sizeof(uint16_t), b->stream));
   }
   struct SolveScope {
     phmrf_block* blk;
@@ -931,7 +945,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           if (any) {
             tic(b);
             PHMRF_TRY(launch_alpha_mask(b, bf));    // which labels can still pay off where (fresh per orientation)
-            toc(b, KC_PROPOSE, 1);
+            PHMRF_TRY(launch_strip_newest(b, orient, GEOM_R[geom], GEOM_C[geom]));
+            toc(b, KC_PROPOSE, 2);
           }
           for (int a = 0; a < K; ++a)
             if (active[8 + a]) {

@@ -44,6 +44,7 @@ struct ChainFamily {
   int32_t* nodes = nullptr;            // device [n]
   int32_t* seg_start[2][3] = {};       // device [nseg]: position in `nodes` of the segment's first node
   int32_t* seg_len[2][3] = {};         // device [nseg]: 1..63
+  uint16_t* memo[2][3] = {};           // device [nseg]: tick of the segment's last quiet run (0 = none), per solve
   int nseg[2][3] = {};
   int n_chains = 0;
   int n_colours = 0;
@@ -97,7 +98,8 @@ struct phmrf_block {
   // memo[orient][geom][strip][alpha] = tick of the last strip alpha-expansion of that strip that found nothing to do.
   // A strip whose cells and border have no stamp newer than its memo would see identical inputs: skipped.
   uint16_t* stamp = nullptr;                // device [n]
-  uint16_t* memo = nullptr;                 // device [2][3][memo_strips][K]
+  uint16_t* memo = nullptr;                 // device [2][3][memo_strips][K+1]  (slot K: the fusion pass)
+  uint16_t* strip_newest = nullptr;         // device [memo_strips]: newest stamp among a strip's cells (current cut)
   int64_t memo_strips = 0;
   int tick = 0;                             // host launch counter inside one solve (0 = stamping off)
   int counter_slot = 0;                     // which of counters[128] the next move launches add their changes to
@@ -143,6 +145,7 @@ int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, 
 int launch_propose(const phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
                       int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
-int launch_alpha_mask(phmrf_block* b, float beta);   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
+int launch_alpha_mask(phmrf_block* b, float beta);
+int launch_strip_newest(const phmrf_block* b, int orient, int shift_r, int shift_c);   // -> strip_newest   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
 
 }  // namespace phmrf

@@ -231,7 +231,11 @@ __global__ __launch_bounds__(256) void icm_kernel(const float* __restrict__ logp
       }
       if (bk != cur) {
         labels[node] = (uint8_t)bk;
-        if (stamp) stamp[node] = (uint16_t)tick;
+        if (stamp) {          // dilated change stamp: the node and every neighbour see new inputs from this tick on
+          stamp[node] = (uint16_t)tick;
+          for (int j = 0; j < D; ++j)
+            if (nb[j] >= 0) stamp[nb[j]] = (uint16_t)tick;
+        }
         ++my_changed;
       }
     }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                     uint8_t* __restrict__ labels, float beta,
                                                     unsigned long long* __restrict__ changed, int debug,
-                                                    uint16_t* __restrict__ stamp, int tick) {
+                                                    uint16_t* __restrict__ stamp, int tick, uint16_t* __restrict__ memo) {
   extern __shared__ float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -62,7 +62,20 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
     const int seg = seg0 + wave;
     const bool active = seg < nseg;
     const int p0 = active ? seg_start[seg] : 0;
-    const int len = active ? seg_len[seg] : 0;
+    int len = active ? seg_len[seg] : 0;
+    // memo: a segment none of whose nodes (nor their neighbours: the stamps are dilated) changed since its last run
+    // that found nothing to do sees identical inputs and is skipped.  (The barriers below stay wave-uniform.)
+    if (memo && active) {
+      const int last_quiet = memo[seg];
+      int st = (lane < len) ? (int)stamp[order[p0 + lane]] : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o2 = __shfl_xor(st, off, 64);
+        st = o2 > st ? o2 : st;
+      }
+      if (last_quiet && st < last_quiet) len = 0;
+    }
+    const bool ran = len > 0;
     // phase 1a: theta rows <- -logprob rows (K/VEC lanes per row, coalesced)
     for (int q = lane; q < len * KV; q += 64) {
       const int r = q / KV;
@@ -144,9 +157,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
       }
       if (lane == 0) newl = cur;
     }
+    const bool seg_changed = __any(lane < len && newl != old);
+    if (memo && ran && lane == 0) memo[seg] = seg_changed ? (uint16_t)0 : (uint16_t)tick;
     if (lane < len && newl != old) {
       labels[node] = (uint8_t)newl;
-      if (stamp) stamp[node] = (uint16_t)tick;
+      if (stamp) {
+        stamp[node] = (uint16_t)tick;
+        const int32_t* nb2 = nbr + (int64_t)node * D;
+        for (int j = 0; j < D; ++j)
+          if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick;
+      }
       ++my_changed;
     }
     __syncthreads();
@@ -370,14 +390,20 @@ __global__ void comp_block_kernel(int64_t n, int D, const int32_t* __restrict__ 
 
 __global__ void comp_apply_kernel(int64_t n, const int32_t* __restrict__ comp, const int32_t* __restrict__ best,
                                   const uint8_t* __restrict__ blocked, uint8_t* __restrict__ labels,
-                                  unsigned long long* __restrict__ changed, uint16_t* __restrict__ stamp, int tick) {
+                                  unsigned long long* __restrict__ changed, uint16_t* __restrict__ stamp, int tick,
+                                  const int32_t* __restrict__ nbr, int D) {
   unsigned int mine = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int ci = comp[i];
     const int bk = best[ci];
     if (bk >= 0 && !blocked[ci]) {
       labels[i] = (uint8_t)bk;
-      if (stamp) stamp[i] = (uint16_t)tick;
+      if (stamp) {
+        stamp[i] = (uint16_t)tick;
+        const int32_t* nb2 = nbr + i * D;
+        for (int j = 0; j < D; ++j)
+          if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick;
+      }
       ++mine;
     }
   }
@@ -423,7 +449,8 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
 #define PHMRF_LAUNCH_CHAIN(VEC_)                                                                                      \
   hipLaunchKernelGGL((chain_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, f.nodes,                  \
                      f.seg_start[phase][colour], f.seg_len[phase][colour], nseg, K, Kp, b->D, b->nbr, b->wgt, b->labels, \
-                     beta, b->counters + b->counter_slot, chain_debug(), b->tick ? b->stamp : nullptr, b->tick)
+                     beta, b->counters + b->counter_slot, chain_debug(), b->tick ? b->stamp : nullptr, b->tick, \
+                     (b->tick && f.memo[phase][colour]) ? f.memo[phase][colour] : nullptr)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_CHAIN(4); break;
     case 2: PHMRF_LAUNCH_CHAIN(2); break;
@@ -467,7 +494,7 @@ int launch_component_pass(phmrf_block* b, float beta) {
                      b->comp_gain);
   hipLaunchKernelGGL(comp_block_kernel, dim3(g), dim3(256), 0, st, n, D, b->nbr, b->comp, b->comp_gain, b->comp_move);
   hipLaunchKernelGGL(comp_apply_kernel, dim3(g), dim3(256), 0, st, n, b->comp, b->comp_best, b->comp_move, b->labels,
-                     b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick);
+                     b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick, b->nbr, D);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

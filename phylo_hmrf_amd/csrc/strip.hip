@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
                                                     uint8_t* __restrict__ labels, const uint8_t* __restrict__ prop,
                                                     int alpha, float beta, unsigned long long* __restrict__ changed,
                                                     const unsigned long long* __restrict__ node_mask, int debug,
-                                                    uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo, int tick) {
+                                                    uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
+                                                    uint16_t* __restrict__ newest, int tick) {
   __shared__ float tabs[4 * 64 * TAB];   // one 5 KB slab per wave: the cost tables of the pass being walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -230,29 +231,14 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
 
-    // ---- memo test (expansions inside a solve): if no label of the strip or of its fixed border has changed since
-    //      this very strip was last found quiet for alpha, its inputs are identical -> nothing to do
-    uint16_t* my_memo = (memo && alpha >= 0) ? memo + (int64_t)strip * K + alpha : nullptr;
+    // ---- memo test (inside a solve): `newest[strip]` is the newest DILATED change stamp among the strip's cells
+    //      (strip_newest_kernel, kept current by this kernel); a stamp is renewed whenever the node or one of its
+    //      neighbours changes label, so it covers the fixed border too.  If nothing changed since this very strip was
+    //      last found quiet for this move, its inputs are identical -> nothing to do.
+    uint16_t* my_memo = memo ? memo + (int64_t)strip * (K + 1) + (alpha >= 0 ? alpha : K) : nullptr;
     if (my_memo) {
       const int last_quiet = *my_memo;
-      if (last_quiet) {
-        int newest = 0;
-        const int ew = ncols + 2;                       // extended rectangle: (SH + 2) x (ncols + 2)
-        for (int e = lane; e < (SH + 2) * ew; e += 64) {
-          const int er = e / ew, ec = e - er * ew;
-          const int node = strip_node(g, rs0 - 1 + er, ca - 1 + ec);
-          if (node >= 0) {
-            const int st = stamp[node];
-            newest = st > newest ? st : newest;
-          }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          const int o2 = __shfl_xor(newest, off, 64);
-          newest = o2 > newest ? o2 : newest;
-        }
-        if (newest < last_quiet) continue;
-      }
+      if (last_quiet && (int)newest[strip] < last_quiet) continue;
     }
 
     // ---- phase 0 (expansions): node_mask[i] has bit a set when node i could possibly profit from label a
@@ -420,20 +406,60 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     for (int p = 0; p < NPASS; ++p) {
       if (xsel[p] && rnode[p] >= 0) {
         labels[rnode[p]] = prop ? prop[rnode[p]] : (uint8_t)alpha;
-        if (stamp) stamp[rnode[p]] = (uint16_t)tick;
+        if (stamp) {
+          stamp[rnode[p]] = (uint16_t)tick;
+          const int32_t* nb2 = nbr + (int64_t)rnode[p] * D;
+          for (int j = 0; j < D; ++j)
+            if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick;
+        }
         ++my_changed;
         moved = true;
       }
     }
     {
       const bool any_moved = __any(moved);
-      if (my_memo && lane == 0) *my_memo = any_moved ? (uint16_t)0 : (uint16_t)tick;
+      if (my_memo && lane == 0) {
+        *my_memo = any_moved ? (uint16_t)0 : (uint16_t)tick;
+        if (any_moved) newest[strip] = (uint16_t)tick;
+      }
     }
   }
   unsigned int s = my_changed;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
+}
+
+// newest[strip] = max dilated change stamp over the cells of the strip (one wave per strip)
+__global__ __launch_bounds__(256) void strip_newest_kernel(StripGeom g, const uint16_t* __restrict__ stamp,
+                                                           uint16_t* __restrict__ newest) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int WPB = blockDim.x >> 6;
+  const int nstrips = g.nbands * g.nsegs;
+  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
+    const int bnd = strip / g.nsegs;
+    const int seg = strip - bnd * g.nsegs;
+    const int rs0 = bnd * (SH + 1) - g.shift_r;
+    const int cs0 = seg * 64 - g.shift_c;
+    const int ca = cs0 > 0 ? cs0 : 0;
+    const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
+    const int ncols = cb > ca ? cb - ca : 0;
+    int nw = 0;
+    for (int e = lane; e < SH * ncols; e += 64) {      // row-major here: consecutive lanes read consecutive nodes
+      const int rr = e / ncols, cc = e - rr * ncols;
+      const int node = strip_node(g, rs0 + rr, ca + cc);
+      if (node >= 0) {
+        const int st = stamp[node];
+        nw = st > nw ? st : nw;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o2 = __shfl_xor(nw, off, 64);
+      nw = o2 > nw ? o2 : nw;
+    }
+    if (lane == 0) newest[strip] = (uint16_t)nw;
+  }
 }
 
 // best alternative label per node: argmin_{k != l_i} ( -logprob[i,k] - beta * sum_{j in N(i), l_j == k} w_ij )
@@ -592,9 +618,7 @@ static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: ph
   return v;
 }
 
-// alpha < 0: fusion with the proposals in b->labels_tmp (launch_propose); alpha >= 0: strip alpha-expansion
-int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
-                      int geom) {
+static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int shift_c) {
   StripGeom g;
   g.H = b->H;
   g.W = b->W;
@@ -606,18 +630,36 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   g.Ws = orient ? b->H : b->W;
   g.nbands = (g.Hs + shift_r + SH) / (SH + 1);
   g.nsegs = (g.Ws + shift_c + 63) / 64;
+  return g;
+}
+
+int launch_strip_newest(const phmrf_block* b, int orient, int shift_r, int shift_c) {
+  const StripGeom g = make_geom(b, orient, shift_r, shift_c);
+  const int nstrips = g.nbands * g.nsegs;
+  if (nstrips <= 0 || !b->tick || (int64_t)nstrips > b->memo_strips) return PHMRF_OK;
+  int grid = (nstrips + 3) / 4;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(strip_newest_kernel, dim3(grid), dim3(256), 0, b->stream, g, b->stamp, b->strip_newest);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+// alpha < 0: fusion with the proposals in b->labels_tmp (launch_propose); alpha >= 0: strip alpha-expansion.
+// geom >= 0 names one of the fixed cuts whose memo (and b->strip_newest, see launch_strip_newest) applies.
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
+                      int geom) {
+  const StripGeom g = make_geom(b, orient, shift_r, shift_c);
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0) return PHMRF_OK;
   const int TB = 256, WPB = 4;
   int grid = (nstrips + WPB - 1) / WPB;
   if (grid > 256 * 32) grid = 256 * 32;
+  const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
   hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->logprob, b->K, b->D, b->nbr, b->wgt,
                      b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters + b->counter_slot,
                      use_mask ? b->alpha_mask : nullptr, strip_debug(), b->tick ? b->stamp : nullptr,
-                     (b->tick && geom >= 0 && alpha >= 0 && (int64_t)nstrips <= b->memo_strips)
-                         ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * b->K
-                         : nullptr,
-                     b->tick);
+                     use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,
+                     use_memo ? b->strip_newest : nullptr, b->tick);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
