@@ -972,6 +972,24 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       for (int sl : slots) n_active += active[sl];
       fprintf(stderr, "[phmrf solve] round %d active %d/%d changed %lld energy %.6f delta %.3e\n", r, n_active,
               (int)slots.size(), (long long)ch, e_now, e_now - e_prev);
+      if (b->timing) {                                // per-round time of each kernel class (ms)
+        static double seen[PHMRF_NUM_KERNEL_CLASSES] = {};
+        resolve_timing(b);
+        fprintf(stderr, "[phmrf solve]   ms:");
+        static const char* NM[PHMRF_NUM_KERNEL_CLASSES] = {"emis", "icm", "chain", "comp", "energy", "post", "strip", "prop"};
+        for (int kc = 0; kc < PHMRF_NUM_KERNEL_CLASSES; ++kc) {
+          fprintf(stderr, " %s %.2f", NM[kc], b->ms[kc] - seen[kc]);
+          seen[kc] = b->ms[kc];
+        }
+        fprintf(stderr, "  changed by slot:");
+        for (int sl : slots)
+          if (b->counters_host[sl]) fprintf(stderr, " %d:%llu", sl, b->counters_host[sl]);
+        fprintf(stderr, "\n");
+        if (b->counters_host[100])
+          fprintf(stderr, "[phmrf solve]   expansion strips: launched %llu, past memo+mask %llu, into DP %llu, DP steps %llu, with a move %llu\n",
+                  b->counters_host[100], b->counters_host[101], b->counters_host[102], b->counters_host[103],
+                  b->counters_host[104]);
+      }
     }
     const double gain = e_prev - e_now;
     if (e_now < e_prev) e_prev = e_now;

@@ -118,7 +118,11 @@ __device__ __forceinline__ int tab_offset(int lane) {   // byte offsets of this 
 }
 
 template <int Q>
-__device__ __forceinline__ void dp_step(float& m, int lane, float base, float lu0, float lu1, unsigned long long* decision) {
+__device__ __forceinline__ void dp_step(float& m, float& zz, int lane, float base, float lu0, float lu1,
+                                        unsigned long long* decision) {
+  // zz: in lane 0 (state 000000) the cost of the path on which NO cell switches, accumulated with the very operations
+  // the DP uses for that path, so that "the optimum is the current labelling" can be tested bit-exactly afterwards
+  zz = base + (zz + lu0);
   const int b = (lane >> Q) & 1;
   const float other = xor_exchange<Q>(m);
   const float o0 = b ? other : m;      // old value of the state whose bit q (cell t-6) is 0
@@ -139,7 +143,7 @@ __device__ __forceinline__ void write_lane(unsigned int& dst, unsigned int value
 
 // All steps of pass P (cells t = 64 P + tt): the pass's 64 cell tables are built into the wave's LDS slab, then walked.
 template <int P>
-__device__ __forceinline__ void dp_pass(float& m, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
+__device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
                                         float wld, int bits, int t_lo, int t_end, unsigned int& dlo, unsigned int& dhi) {
   dlo = 0u;
   dhi = 0u;
@@ -164,7 +168,7 @@ __device__ __forceinline__ void dp_pass(float& m, int lane, float* tab, float c0
       const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(lane));                                 \
       const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((lane >> Q) & 1) * 8);                          \
       unsigned long long dec;                                                                                        \
-      dp_step<Q>(m, lane, base, lu.x, lu.y, &dec);                                                                   \
+      dp_step<Q>(m, zz, lane, base, lu.x, lu.y, &dec);                                                                  \
       write_lane(dlo, (unsigned int)(dec & 0xffffffffull), tt);                                                      \
       write_lane(dhi, (unsigned int)(dec >> 32), tt);                                                                \
     }                                                                                                                \
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     //      (strip_newest_kernel, kept current by this kernel); a stamp is renewed whenever the node or one of its
     //      neighbours changes label, so it covers the fixed border too.  If nothing changed since this very strip was
     //      last found quiet for this move, its inputs are identical -> nothing to do.
+    if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 100, 1ull);   // strips seen (expansion slots only)
     uint16_t* my_memo = memo ? memo + (int64_t)strip * (K + 1) + (alpha >= 0 ? alpha : K) : nullptr;
     if (my_memo) {
       const int last_quiet = *my_memo;
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
       }
     }
 
+    if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
     // ---- phase 1: lane <-> cell (cell t = 64 p + lane): unary costs against the fixed outside, weights / label
     //      relations to the four already-visited in-strip neighbours -- all kept in registers.  A cell whose unary
     //      loss du exceeds `gain` (the weight of its edges whose other end could end up with the same proposal)
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
         t_hi = last > t_hi ? last : t_hi;
       }
     }
-    if (t_hi < 0 || debug == 1) {           // nothing can move in this strip (wave-uniform)
+    if (t_hi < 0 || (debug & 3) == 1) {           // nothing can move in this strip (wave-uniform)
       if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
       continue;
     }
@@ -369,17 +375,22 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
       t_lo = pl * 64 + (rl - rl % 6);
     }
 
+    if ((debug & 4) && lane == 0) {
+      atomicAdd(changed - alpha - 8 + 102, 1ull);                                // strips reaching the DP
+      atomicAdd(changed - alpha - 8 + 103, (unsigned long long)(t_end - t_lo + 1));   // DP steps
+    }
     // ---- phase 2: lane <-> state.  Records are broadcast with v_readlane, decisions are one 64-bit ballot per step
     //      parked in lane (t mod 64) of a per-pass register pair.
     float m = lane == 0 ? 0.f : BIG;     // every cell before t_lo keeps its label: profile 000000
+    float zz = 0.f;
     unsigned int dlo[NPASS], dhi[NPASS];
-    dp_pass<0>(m, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
-    dp_pass<1>(m, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
-    dp_pass<2>(m, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
-    dp_pass<3>(m, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
-    dp_pass<4>(m, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
+    dp_pass<0>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
+    dp_pass<1>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
+    dp_pass<2>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
+    dp_pass<3>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
+    dp_pass<4>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
 
-    if (debug == 2) continue;
+    if ((debug & 3) == 2) continue;
     // ---- final state: among the minimisers take the one whose SHIFT-encoded index (newest cell in bit 0, as in the
     //      move model) is lowest, so ties are broken exactly like oracle/mrf_moves.strip_fusion
     const int q_end = t_end % 6;
@@ -387,6 +398,14 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
 #pragma unroll
     for (int j = 0; j < 6; ++j) sidx |= ((lane >> ((q_end - j + 6) % 6)) & 1) << j;
     const float mmin = wave_min_f32(m);
+    {   // the no-change path is optimal (bit-exactly, see dp_step): nothing to backtrack or apply
+      const float m0 = PHMRF_RL(m, 0), z0 = PHMRF_RL(zz, 0);
+      if (m0 == mmin && z0 == m0) {
+        if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+        continue;
+      }
+    }
+    if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 104, 1ull);   // DPs that found a move
     const float cand = (m == mmin) ? (float)sidx : 127.f;
     const float best = wave_min_f32(cand);
     int s = __ffsll((long long)__ballot(cand == best)) - 1;
@@ -609,7 +628,7 @@ int launch_propose(const phmrf_block* b, float beta) {
   return PHMRF_OK;
 }
 
-static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: phase 1 only, 2: no backtrack/apply)
+static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: phase 1 only, 2: no backtrack/apply, +4: count strips)
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PHMRF_STRIP_DEBUG");
@@ -657,7 +676,8 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
   hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->logprob, b->K, b->D, b->nbr, b->wgt,
                      b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters + b->counter_slot,
-                     use_mask ? b->alpha_mask : nullptr, strip_debug(), b->tick ? b->stamp : nullptr,
+                     use_mask ? b->alpha_mask : nullptr,
+                     (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3), b->tick ? b->stamp : nullptr,
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,
                      use_memo ? b->strip_newest : nullptr, b->tick);
   PHMRF_HIP(hipGetLastError());
