@@ -247,7 +247,7 @@ int setup_grid_tables(phmrf_block* b, const Geometry& g, int num_neighbor) {
   b->diagonal = g.diagonal;
   b->num_neighbor = num_neighbor;
   b->has_grid = true;
-  return PHMRF_OK;
+  return launch_fwd_weights(b);          // grid-native edge weights of the strip kernels
 }
 
 }  // namespace
@@ -359,6 +359,10 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->stamp);
   dev_free(b->memo);
   dev_free(b->strip_newest);
+  dev_free(b->strip_mask);
+  dev_free(b->fwd_w);
+  dev_free(b->uT);
+  dev_free(b->u_cur);
   dev_free(b->emis_params);
   dev_free(b->posteriors);
   dev_free(b->accum);
@@ -677,6 +681,7 @@ int phmrf_emission(phmrf_block_t b, const double* means, const double* covars) {
   PHMRF_TRY(launch_emission(b->X, b->n, b->S, b->K, b->emis_params, b->logprob, b->stream));
   toc(b, KC_EMISSION, 1);
   b->has_logprob = true;
+  b->uT_valid = false;
   return PHMRF_OK;
 }
 
@@ -697,6 +702,7 @@ int phmrf_block_set_logprob(phmrf_block_t b, const double* logprob) {
   for (size_t i = 0; i < cnt; ++i) tmp[i] = (float)logprob[i];
   PHMRF_TRY(upload(b->logprob, tmp.data(), cnt * sizeof(float), b->stream));
   b->has_logprob = true;
+  b->uT_valid = false;
   return PHMRF_OK;
 }
 
@@ -802,6 +808,11 @@ static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift
     PHMRF_TRY(launch_propose(b, beta));
     toc(b, KC_PROPOSE, 1);
   }
+  if (!b->uT_valid) {
+    tic(b);
+    PHMRF_TRY(launch_unary_planes(b));
+    toc(b, KC_PROPOSE, 1);
+  }
   tic(b);
   if (b->tick) ++b->tick;
   PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, use_mask, geom));
@@ -890,10 +901,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     if (!b->memo || b->memo_strips < max_strips) {
       dev_free(b->memo);
       dev_free(b->strip_newest);
-      b->memo = nullptr;
-      b->strip_newest = nullptr;
+      dev_free(b->strip_mask);
       PHMRF_TRY(dev_alloc(&b->memo, (size_t)6 * max_strips * (K + 1)));
       PHMRF_TRY(dev_alloc(&b->strip_newest, (size_t)max_strips));
+      PHMRF_TRY(dev_alloc(&b->strip_mask, (size_t)max_strips));
       b->memo_strips = max_strips;
     }
     PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * (K + 1) * sizeof(uint16_t), b->stream));
@@ -945,7 +956,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           if (any) {
             tic(b);
             PHMRF_TRY(launch_alpha_mask(b, bf));    // which labels can still pay off where (fresh per orientation)
-            PHMRF_TRY(launch_strip_newest(b, orient, GEOM_R[geom], GEOM_C[geom]));
+            PHMRF_TRY(launch_strip_scan(b, orient, GEOM_R[geom], GEOM_C[geom]));
             toc(b, KC_PROPOSE, 2);
           }
           for (int a = 0; a < K; ++a)

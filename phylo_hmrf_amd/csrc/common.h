@@ -94,7 +94,14 @@ struct phmrf_block {
   float* comp_gain = nullptr;               // device [n]
   uint8_t* comp_move = nullptr;             // device [n]
   unsigned long long* alpha_mask = nullptr; // device [n]: labels a node could profit from (strip expansions)
-  // change stamps: stamp[i] = tick of the launch that last changed node i's label (0 = not since the solve began);
+  // grid-native inputs of the strip kernels
+  float4* fwd_w = nullptr;                  // device [n]: weights of the four forward grid edges (E, SW, S, SE)
+  float* uT = nullptr;                      // device [K][n]: unary planes, uT[k][i] = -logprob[i][k]
+  bool uT_valid = false;                    //   ... current with logprob
+  float* u_cur = nullptr;                   // device [n]: -logprob[i][l_i], kept current during the expansions of a round
+  unsigned long long* strip_mask = nullptr; // device [memo_strips]: OR of alpha_mask over a strip's cells (current cut)
+  // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS
+  // (0 = not since the solve began);
   // memo[orient][geom][strip][alpha] = tick of the last strip alpha-expansion of that strip that found nothing to do.
   // A strip whose cells and border have no stamp newer than its memo would see identical inputs: skipped.
   uint16_t* stamp = nullptr;                // device [n]
@@ -146,6 +153,8 @@ int launch_propose(const phmrf_block* b, float beta);  // best alternative label
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
                       int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
 int launch_alpha_mask(phmrf_block* b, float beta);
-int launch_strip_newest(const phmrf_block* b, int orient, int shift_r, int shift_c);   // -> strip_newest   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
+int launch_strip_scan(const phmrf_block* b, int orient, int shift_r, int shift_c);   // -> strip_newest, strip_mask
+int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
+int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
 
 }  // namespace phmrf

@@ -81,7 +81,39 @@ __global__ void grid_graph_kernel(const float* __restrict__ X, int64_t n, int H,
   }
 }
 
+// fwd_w[v] = weights of v's four FORWARD grid edges: x = E (i, j+1), y = SW (i+1, j-1), z = S (i+1, j), w = SE (i+1, j+1);
+// 0 where the edge does not exist.  Every undirected grid edge is held exactly once, by its upper / left end, so the
+// strip kernels read 16 B per cell instead of an ELL row of ids and weights.
+__global__ void fwd_weights_kernel(int64_t n, int H, int W, int diagonal, int D, const int32_t* __restrict__ nbr,
+                                   const float* __restrict__ wgt, float4* __restrict__ fwd_w) {
+  const int FI[4] = {0, 1, 1, 1};
+  const int FJ[4] = {1, -1, 0, 1};
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    int i, j;
+    node_coords(v, W, diagonal, &i, &j);
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t u = node_of(i + FI[q], j + FJ[q], H, W, diagonal);
+      if (u < 0) continue;
+      for (int x = 0; x < D; ++x)
+        if (nbr[v * D + x] == (int32_t)u) out[q] = wgt[v * D + x];
+    }
+    fwd_w[v] = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 }  // namespace
+
+int launch_fwd_weights(phmrf_block* b) {
+  if (!b->fwd_w) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->fwd_w), (size_t)b->n * sizeof(float4)));
+  int64_t g64 = (b->n + 255) / 256;
+  const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
+  hipLaunchKernelGGL(fwd_weights_kernel, dim3(grid), dim3(256), 0, b->stream, b->n, b->H, b->W, b->diagonal, b->D, b->nbr,
+                     b->wgt, b->fwd_w);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
 
 int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, double beta1) {
   int64_t g64 = (b->n + 255) / 256;

@@ -81,6 +81,10 @@ __device__ __forceinline__ float xor_exchange(float v) {
 //   [0..15]  base[b][bu][bl][bld] = c_b + wu*N_u[b][bu] + wl*N_l[b][bl] + wld*N_ld[b][bld]
 //   [16..19] lu[b][d]             = wlu*N_lu[b][d]           (d = choice of the left-up cell leaving the profile)
 constexpr int TAB = 20;
+// phase-1 staging record per cell (same LDS slab, before the tables are built): the four forward grid weights of the
+// cell (times beta) and its packed labels (l | p << 8 | present << 16); stride 5 words: conflict-free.
+constexpr int REC = 5;
+constexpr int SLAB = 320 * REC;   // floats per wave: >= 64 * TAB and >= 5 passes * 64 cells * REC
 
 __device__ __forceinline__ void build_table(float* tab, int lane, float c0, float c1, float wu, float wlu, float wl,
                                             float wld, int bits) {
@@ -211,18 +215,19 @@ __device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, unsi
 
 constexpr int NPASS = 5;   // ceil(315 / 64)
 
-__global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __restrict__ logprob, int K, int D,
-                                                    const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
+__global__ __launch_bounds__(256, 4) void strip_kernel(StripGeom g, int64_t n, int K, int D,
+                                                    const int32_t* __restrict__ nbr, const float4* __restrict__ fwd_w,
+                                                    const float* __restrict__ uT, float* __restrict__ u_cur,
                                                     uint8_t* __restrict__ labels, const uint8_t* __restrict__ prop,
                                                     int alpha, float beta, unsigned long long* __restrict__ changed,
-                                                    const unsigned long long* __restrict__ node_mask, int debug,
+                                                    const unsigned long long* __restrict__ strip_mask, int debug,
                                                     uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                     uint16_t* __restrict__ newest, int tick) {
-  __shared__ float tabs[4 * 64 * TAB];   // one 5 KB slab per wave: the cost tables of the pass being walked
+  __shared__ float tabs[4 * SLAB];   // one 6.4 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
-  float* tab = tabs + wave * 64 * TAB;
+  float* tab = tabs + wave * SLAB;
   unsigned int my_changed = 0;
 
   for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {   // waves are independent
@@ -246,111 +251,107 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
       if (last_quiet && (int)newest[strip] < last_quiet) continue;
     }
 
-    // ---- phase 0 (expansions): node_mask[i] has bit a set when node i could possibly profit from label a
-    //      (alpha_mask_kernel).  A strip none of whose cells has bit alpha is left alone after 5 coalesced-ish loads.
-    if (node_mask && alpha >= 0) {
-      bool any = false;
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int t = p * 64 + lane;
-        if (t < ncell) {
-          const int cc = t / SH, rr = t - cc * SH;
-          const int node = strip_node(g, rs0 + rr, ca + cc);
-          if (node >= 0) any |= ((node_mask[node] >> alpha) & 1ull) != 0;
-        }
-      }
-      if (!__any(any)) {
-        if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
-        continue;
-      }
+    // ---- phase 0 (expansions): strip_mask[strip] has bit a set when some cell of the strip could possibly profit from
+    //      label a (alpha_mask_kernel, OR-ed per strip by strip_scan_kernel).  Otherwise: one 8-byte load and out.
+    if (strip_mask && alpha >= 0 && !((strip_mask[strip] >> alpha) & 1ull)) {
+      if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+      continue;
     }
 
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
-    // ---- phase 1: lane <-> cell (cell t = 64 p + lane): unary costs against the fixed outside, weights / label
-    //      relations to the four already-visited in-strip neighbours -- all kept in registers.  A cell whose unary
-    //      loss du exceeds `gain` (the weight of its edges whose other end could end up with the same proposal)
-    //      cannot be in an optimal switched set (taking it out of the set would lower the energy): it is pinned
-    //      (c1 = BIG); the DP spans [t_lo, t_hi + SH + 1] only, and strips without a free cell are skipped.
+    // ---- phase 1: lane <-> cell (cell t = 64 p + lane, column-major: cc = t / 5, rr = t % 5).
+    //      Step A: every cell loads its own 1 + 16 + 4 + 4 bytes (label, forward weights, two unary values) and
+    //      stages weights and labels in LDS.  Step B: the four already-visited in-strip neighbours (cells t-1, t-6,
+    //      t-5, t-4) are read back from LDS -- each grid edge weight is held by its upper/left end --; only the cells
+    //      on the rim of the strip gather labels (and backward weights) of the fixed nodes outside.
     float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
     int rbits[NPASS], rnode[NPASS];
     int t_lo = NCELL_MAX, t_hi = -1;
+    int* tabi = reinterpret_cast<int*>(tab);
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int t = p * 64 + lane;
-      bool sw = false;
-      float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
-      int bits = 0, node = -1;
+      int node = -1, lw = 0;
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      float u0 = 0.f, u1 = BIG;
       if (t < ncell) {
         const int cc = t / SH, rr = t - cc * SH;
-        const int sr = rs0 + rr, sc = ca + cc;
-        node = strip_node(g, sr, sc);
+        node = strip_node(g, rs0 + rr, ca + cc);
         if (node >= 0) {
-          int ids[8];
-          const bool up = rr > 0, dn = rr < SH - 1, lf = cc > 0, rt = cc < ncols - 1;
-          ids[0] = up ? strip_node(g, sr - 1, sc) : -1;              // up
-          ids[1] = (up && lf) ? strip_node(g, sr - 1, sc - 1) : -1;  // left-up
-          ids[2] = lf ? strip_node(g, sr, sc - 1) : -1;              // left
-          ids[3] = (dn && lf) ? strip_node(g, sr + 1, sc - 1) : -1;  // left-down
-          ids[4] = dn ? strip_node(g, sr + 1, sc) : -1;              // forward neighbours (handled from their side)
-          ids[5] = (up && rt) ? strip_node(g, sr - 1, sc + 1) : -1;
-          ids[6] = rt ? strip_node(g, sr, sc + 1) : -1;
-          ids[7] = (dn && rt) ? strip_node(g, sr + 1, sc + 1) : -1;
           const int l = labels[node];
           const int pl = prop ? (int)prop[node] : alpha;
-          const bool can = pl != l;
-          c0 = -logprob[(int64_t)node * K + l];
-          c1 = can ? -logprob[(int64_t)node * K + pl] : BIG;
-          const int32_t* nb = nbr + (int64_t)node * D;
-          const float* wg = wgt + (int64_t)node * D;
-          float gain = 0.f;     // upper bound of what switching this cell can save on its edges (see below)
-          const float du = c1 - c0;
-          for (int j0 = 0; j0 < D; j0 += 4) {
-            const int4 cv = *reinterpret_cast<const int4*>(nb + j0);
-            const float4 wv = *reinterpret_cast<const float4*>(wg + j0);
-            const int cs[4] = {cv.x, cv.y, cv.z, cv.w};
-            const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
-            int lcs[4];
-#pragma unroll
-            for (int z = 0; z < 4; ++z) lcs[z] = cs[z] >= 0 ? (int)labels[cs[z]] : 0;   // 4 gathers in flight
-#pragma unroll
-            for (int z = 0; z < 4; ++z) {
-              const int c = cs[z];
-              if (c < 0) continue;
-              const float w = beta * ws[z];
-              int q = 8;
-#pragma unroll
-              for (int y = 0; y < 8; ++y)
-                if (c == ids[y]) q = y;
-              if (q < 4) {
-                w4[q] = w;
-              } else if (q == 8) {
-                if (l != lcs[z]) c0 += w;
-                if (can && pl != lcs[z]) c1 += w;
-              }
-              // switching this cell can only pay on an edge whose other end may END UP with my proposal: the
-              // neighbour already carries it, or it lies in the strip and its own proposal equals mine
-              {
-                bool may = pl == lcs[z];
-                if (!may && q < 8) may = prop ? ((int)prop[c] == pl) : true;
-                if (may) gain += w;
-              }
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (ids[q] >= 0) {
-              const int lj = labels[ids[q]];
-              const int pj = prop ? (int)prop[ids[q]] : alpha;
-              const int nib = (l != lj ? 1 : 0) | (l != pj ? 2 : 0) | (pl != lj ? 4 : 0) | (pl != pj ? 8 : 0);
-              bits |= nib << (4 * q);
-            }
-          }
-          sw = can && !(du > gain);
-          if (!sw) c1 = BIG;
+          f = fwd_w[node];
+          f.x *= beta; f.y *= beta; f.z *= beta; f.w *= beta;
+          u0 = u_cur ? u_cur[node] : uT[(int64_t)l * n + node];
+          if (pl != l) u1 = uT[(int64_t)pl * n + node];
+          lw = l | (pl << 8) | (1 << 16);
         }
       }
+      tab[t * REC + 0] = f.x;
+      tab[t * REC + 1] = f.y;
+      tab[t * REC + 2] = f.z;
+      tab[t * REC + 3] = f.w;
+      tabi[t * REC + 4] = lw;
+      rc0[p] = u0; rc1[p] = u1; rnode[p] = node;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int cu = g.orient ? 0 : 2;      // component of the UP cell's record that holds the edge to me
+    const int cl = g.orient ? 2 : 0;      //              of the LEFT cell's
+    const int ld_off = g.orient ? 4 : 0;  // the left-down edge is held by that cell (orient 1) or by me (orient 0)
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int t = p * 64 + lane;
+      const int node = rnode[p];
+      bool sw = false;
+      float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
+      int bits = 0;
+      if (node >= 0) {
+        const int cc = t / SH, rr = t - cc * SH;
+        const bool up = rr > 0, dn = rr < SH - 1, lf = cc > 0;
+        const int lw = tabi[t * REC + 4];
+        const int l = lw & 255, pl = (lw >> 8) & 255;
+        const bool can = pl != l;
+        c0 = rc0[p];
+        c1 = rc1[p];
+        int nlab[4] = {0, 0, 0, 0};
+        if (up) { w4[0] = tab[(t - 1) * REC + cu]; nlab[0] = tabi[(t - 1) * REC + 4]; }
+        if (up && lf) { w4[1] = tab[(t - 6) * REC + 3]; nlab[1] = tabi[(t - 6) * REC + 4]; }
+        if (lf) { w4[2] = tab[(t - 5) * REC + cl]; nlab[2] = tabi[(t - 5) * REC + 4]; }
+        if (dn && lf) { w4[3] = tab[(t - ld_off) * REC + 1]; nlab[3] = tabi[(t - 4) * REC + 4]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!((nlab[q] >> 16) & 1)) { w4[q] = 0.f; continue; }      // absent cell (outside the grid / triangle)
+          const int lj = nlab[q] & 255, pj = (nlab[q] >> 8) & 255;
+          const int nib = (l != lj ? 1 : 0) | (l != pj ? 2 : 0) | (pl != lj ? 4 : 0) | (pl != pj ? 8 : 0);
+          bits |= nib << (4 * q);
+        }
+        // the rim: neighbours outside the strip rectangle keep their labels
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+          constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+          const int r2 = rr + DR[d], c2 = cc + DC[d];
+          if (r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols) continue;
+          const int j = strip_node(g, rs0 + r2, ca + c2);
+          if (j < 0) continue;
+          const int di = g.orient ? DC[d] : DR[d], dj = g.orient ? DR[d] : DC[d];   // grid direction of the edge
+          // forward edges (E, SW, S, SE) are mine; backward ones (W, NE, N, NW) are the neighbour's, same component
+          const int comp = (di == 0) ? 0 : (dj + 2);          // E/W -> 0, SW/NE -> 1, S/N -> 2, SE/NW -> 3 (with di = +-1)
+          const int comp_b = (di == 0) ? 0 : (2 - dj);        // backward: (-1,+1) NE -> 1, (-1,0) N -> 2, (-1,-1) NW -> 3
+          const bool fwd = di > 0 || (di == 0 && dj > 0);
+          float w;
+          if (fwd) w = tab[t * REC + comp];
+          else w = beta * reinterpret_cast<const float*>(fwd_w + j)[comp_b];
+          const int lj = labels[j];
+          if (l != lj) c0 += w;
+          if (can && pl != lj) c1 += w;
+        }
+        sw = can;
+        if (!sw) c1 = BIG;
+      }
       rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
-      rbits[p] = bits; rnode[p] = node;
+      rbits[p] = bits;
       const unsigned long long swm = __ballot(sw);
       if (swm) {
         const int first = p * 64 + __ffsll((long long)swm) - 1;
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
         t_hi = last > t_hi ? last : t_hi;
       }
     }
+    __builtin_amdgcn_wave_barrier();      // the slab is about to be reused for the cost tables
     if (t_hi < 0 || (debug & 3) == 1) {           // nothing can move in this strip (wave-uniform)
       if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
       continue;
@@ -425,6 +427,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
     for (int p = 0; p < NPASS; ++p) {
       if (xsel[p] && rnode[p] >= 0) {
         labels[rnode[p]] = prop ? prop[rnode[p]] : (uint8_t)alpha;
+        if (u_cur) u_cur[rnode[p]] = uT[(int64_t)alpha * n + rnode[p]];
         if (stamp) {
           stamp[rnode[p]] = (uint16_t)tick;
           const int32_t* nb2 = nbr + (int64_t)rnode[p] * D;
@@ -449,9 +452,12 @@ __global__ __launch_bounds__(256) void strip_kernel(StripGeom g, const float* __
   if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
 }
 
-// newest[strip] = max dilated change stamp over the cells of the strip (one wave per strip)
-__global__ __launch_bounds__(256) void strip_newest_kernel(StripGeom g, const uint16_t* __restrict__ stamp,
-                                                           uint16_t* __restrict__ newest) {
+// One wave per strip of the current cut: newest[strip] = max dilated change stamp over the strip's cells (memo test),
+// smask[strip] = OR of the cells' alpha masks (phase 0 of the expansions).
+__global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, const uint16_t* __restrict__ stamp,
+                                                         const unsigned long long* __restrict__ node_mask,
+                                                         uint16_t* __restrict__ newest,
+                                                         unsigned long long* __restrict__ smask) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
@@ -464,20 +470,55 @@ __global__ __launch_bounds__(256) void strip_newest_kernel(StripGeom g, const ui
     const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
     const int ncols = cb > ca ? cb - ca : 0;
     int nw = 0;
-    for (int e = lane; e < SH * ncols; e += 64) {      // row-major here: consecutive lanes read consecutive nodes
-      const int rr = e / ncols, cc = e - rr * ncols;
+    unsigned int mlo = 0u, mhi = 0u;
+    for (int e = lane; e < SH * ncols; e += 64) {
+      // consecutive lanes along the memory-contiguous axis: strip columns for orient 0, strip rows for orient 1
+      int rr, cc;
+      if (g.orient) { cc = e / SH; rr = e - cc * SH; }
+      else { rr = e / ncols; cc = e - rr * ncols; }
       const int node = strip_node(g, rs0 + rr, ca + cc);
       if (node >= 0) {
-        const int st = stamp[node];
-        nw = st > nw ? st : nw;
+        if (stamp) {
+          const int st = stamp[node];
+          nw = st > nw ? st : nw;
+        }
+        if (node_mask) {
+          const unsigned long long m = node_mask[node];
+          mlo |= (unsigned int)m;
+          mhi |= (unsigned int)(m >> 32);
+        }
       }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const int o2 = __shfl_xor(nw, off, 64);
       nw = o2 > nw ? o2 : nw;
+      mlo |= (unsigned int)__shfl_xor((int)mlo, off, 64);
+      mhi |= (unsigned int)__shfl_xor((int)mhi, off, 64);
     }
-    if (lane == 0) newest[strip] = (uint16_t)nw;
+    if (lane == 0) {
+      newest[strip] = (uint16_t)nw;
+      smask[strip] = ((unsigned long long)mhi << 32) | mlo;
+    }
+  }
+}
+
+// uT[k][i] = -logprob[i][k]: one plane per label, so an expansion of label a reads its unary terms contiguously
+__global__ __launch_bounds__(256) void unary_planes_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp,
+                                                           float* __restrict__ uT) {
+  extern __shared__ float tile[];
+  const int TB = blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    for (int q = threadIdx.x; q < rows * K; q += TB) {      // coalesced read of rows*K consecutive floats
+      const int r = q / K, c = q - r * K;
+      tile[r * Kp + c] = -logprob[base * K + q];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < rows)
+      for (int k = 0; k < K; ++k) uT[(int64_t)k * n + base + threadIdx.x] = tile[threadIdx.x * Kp + k];
+    __syncthreads();
   }
 }
 
@@ -539,7 +580,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void alpha_mask_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp, int D,
                                                          const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                          const uint8_t* __restrict__ labels, float beta,
-                                                         unsigned long long* __restrict__ mask) {
+                                                         unsigned long long* __restrict__ mask, float* __restrict__ u_cur) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   const int KV = K / VEC;
@@ -582,6 +623,7 @@ __global__ __launch_bounds__(256) void alpha_mask_kernel(const float* __restrict
       for (int k = 0; k < K; ++k)
         if (k != cur && !(row[k] > thr)) m |= 1ull << k;
       mask[i] = m;
+      u_cur[i] = row[cur];
     }
     __syncthreads();
   }
@@ -593,13 +635,14 @@ inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 int launch_alpha_mask(phmrf_block* b, float beta) {
   if (!b->alpha_mask) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->alpha_mask), (size_t)b->n * sizeof(unsigned long long)));
+  if (!b->u_cur) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->u_cur), (size_t)b->n * sizeof(float)));
   const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
   const size_t lds = (size_t)TB * Kp * sizeof(float);
   int64_t g64 = (b->n + TB - 1) / TB;
   const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
 #define PHMRF_LAUNCH_AM(VEC_)                                                                                          \
   hipLaunchKernelGGL((alpha_mask_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
-                     b->wgt, b->labels, beta, b->alpha_mask)
+                     b->wgt, b->labels, beta, b->alpha_mask, b->u_cur)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_AM(4); break;
     case 2: PHMRF_LAUNCH_AM(2); break;
@@ -652,32 +695,51 @@ static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int sh
   return g;
 }
 
-int launch_strip_newest(const phmrf_block* b, int orient, int shift_r, int shift_c) {
+int launch_unary_planes(phmrf_block* b) {
+  if (b->uT_valid) return PHMRF_OK;
+  if (!b->uT) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->uT), (size_t)b->n * b->K * sizeof(float)));
+  const int K = b->K, TB = 256, Kp = padded_k(K);
+  const size_t lds = (size_t)TB * Kp * sizeof(float);
+  int64_t g64 = (b->n + TB - 1) / TB;
+  const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
+  hipLaunchKernelGGL(unary_planes_kernel, dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->uT);
+  PHMRF_HIP(hipGetLastError());
+  b->uT_valid = true;
+  return PHMRF_OK;
+}
+
+// per-strip tables of the cut (orient, shift_r, shift_c): newest stamp and OR of the alpha masks (inside a solve)
+int launch_strip_scan(const phmrf_block* b, int orient, int shift_r, int shift_c) {
   const StripGeom g = make_geom(b, orient, shift_r, shift_c);
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0 || !b->tick || (int64_t)nstrips > b->memo_strips) return PHMRF_OK;
   int grid = (nstrips + 3) / 4;
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(strip_newest_kernel, dim3(grid), dim3(256), 0, b->stream, g, b->stamp, b->strip_newest);
+  hipLaunchKernelGGL(strip_scan_kernel, dim3(grid), dim3(256), 0, b->stream, g, b->stamp, b->alpha_mask, b->strip_newest,
+                     b->strip_mask);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
 
 // alpha < 0: fusion with the proposals in b->labels_tmp (launch_propose); alpha >= 0: strip alpha-expansion.
-// geom >= 0 names one of the fixed cuts whose memo (and b->strip_newest, see launch_strip_newest) applies.
+// geom >= 0 names one of the fixed cuts whose memo and per-strip tables (launch_strip_scan) apply; use_mask additionally
+// says that b->alpha_mask / b->u_cur / b->strip_mask are current (launch_alpha_mask + launch_strip_scan ran for this cut).
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
                       int geom) {
   const StripGeom g = make_geom(b, orient, shift_r, shift_c);
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0) return PHMRF_OK;
+  if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
   const int TB = 256, WPB = 4;
   int grid = (nstrips + WPB - 1) / WPB;
   if (grid > 256 * 32) grid = 256 * 32;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
-  hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->logprob, b->K, b->D, b->nbr, b->wgt,
-                     b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters + b->counter_slot,
-                     use_mask ? b->alpha_mask : nullptr,
-                     (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3), b->tick ? b->stamp : nullptr,
+  const bool masks = use_mask && use_memo && alpha >= 0;
+  hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT,
+                     masks ? b->u_cur : nullptr, b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta,
+                     b->counters + b->counter_slot, masks ? b->strip_mask : nullptr,
+                     (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3),
+                     b->tick ? b->stamp : nullptr,
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,
                      use_memo ? b->strip_newest : nullptr, b->tick);
   PHMRF_HIP(hipGetLastError());
