@@ -84,7 +84,9 @@ constexpr int TAB = 20;
 // phase-1 staging record per cell (same LDS slab, before the tables are built): the four forward grid weights of the
 // cell (times beta) and its packed labels (l | p << 8 | present << 16); stride 5 words: conflict-free.
 constexpr int REC = 5;
-constexpr int SLAB = 320 * REC;   // floats per wave: >= 64 * TAB and >= 5 passes * 64 cells * REC
+constexpr int EH = 7;                   // rows of the staged rectangle: the strip's 5 plus the fixed row above and below
+constexpr int ECELLS = EH * (63 + 2);   // ... times its columns plus the fixed column left and right
+constexpr int SLAB = (ECELLS * REC + 3) / 4 * 4;   // floats per wave (9.1 KB, 16-byte multiple) >= 64 * TAB
 
 __device__ __forceinline__ void build_table(float* tab, int lane, float c0, float c1, float wu, float wlu, float wl,
                                             float wld, int bits) {
@@ -215,7 +217,11 @@ __device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, unsi
 
 constexpr int NPASS = 5;   // ceil(315 / 64)
 
-__global__ __launch_bounds__(256, 4) void strip_kernel(StripGeom g, int64_t n, int K, int D,
+#ifndef PHMRF_STRIP_WPE
+#define PHMRF_STRIP_WPE 4
+#endif
+template <int ORIENT>
+__global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g, int64_t n, int K, int D,
                                                     const int32_t* __restrict__ nbr, const float4* __restrict__ fwd_w,
                                                     const float* __restrict__ uT, float* __restrict__ u_cur,
                                                     uint8_t* __restrict__ labels, const uint8_t* __restrict__ prop,
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256, 4) void strip_kernel(StripGeom g, int64_t n, i
                                                     const unsigned long long* __restrict__ strip_mask, int debug,
                                                     uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                     uint16_t* __restrict__ newest, int tick) {
-  __shared__ float tabs[4 * SLAB];   // one 6.4 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
+  __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];   // one 9.1 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
@@ -259,99 +265,91 @@ __global__ __launch_bounds__(256, 4) void strip_kernel(StripGeom g, int64_t n, i
     }
 
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
-    // ---- phase 1: lane <-> cell (cell t = 64 p + lane, column-major: cc = t / 5, rr = t % 5).
-    //      Step A: every cell loads its own 1 + 16 + 4 + 4 bytes (label, forward weights, two unary values) and
-    //      stages weights and labels in LDS.  Step B: the four already-visited in-strip neighbours (cells t-1, t-6,
-    //      t-5, t-4) are read back from LDS -- each grid edge weight is held by its upper/left end --; only the cells
-    //      on the rim of the strip gather labels (and backward weights) of the fixed nodes outside.
+    // ---- phase 1.  Step A: the strip's rectangle PLUS its fixed rim (7 x (ncols + 2) cells, lane <-> cell) is staged
+    //      in LDS: per cell the four forward grid weights (times beta) and the packed labels -- 1 + 16 coalesced bytes
+    //      per cell, each grid edge weight read once, by its upper/left end.  Step B: lane <-> strip cell
+    //      (t = 64 p + lane, column-major: cc = t / 5, rr = t % 5) reads its eight neighbours back from LDS at
+    //      compile-time offsets: the four already-visited in-strip ones give the pair tables, the rim ones are folded
+    //      into the unary costs.
     float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
     int rbits[NPASS], rnode[NPASS];
     int t_lo = NCELL_MAX, t_hi = -1;
     int* tabi = reinterpret_cast<int*>(tab);
+    const int ecells = EH * (ncols + 2);
+    for (int e = lane; e < ecells; e += 64) {
+      const int ec = e / EH, er = e - ec * EH;
+      const int node = strip_node(g, rs0 - 1 + er, ca - 1 + ec);
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      int lw = 0;
+      if (node >= 0) {
+        const int l = labels[node];
+        const int pl = prop ? (int)prop[node] : alpha;
+        f = fwd_w[node];
+        f.x *= beta; f.y *= beta; f.z *= beta; f.w *= beta;
+        lw = l | (pl << 8);
+      }
+      tab[e * REC + 0] = f.x;
+      tab[e * REC + 1] = f.y;
+      tab[e * REC + 2] = f.z;
+      tab[e * REC + 3] = f.w;
+      tabi[e * REC + 4] = lw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int t = p * 64 + lane;
-      int node = -1, lw = 0;
-      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-      float u0 = 0.f, u1 = BIG;
+      bool sw = false;
+      float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
+      int bits = 0, node = -1;
       if (t < ncell) {
         const int cc = t / SH, rr = t - cc * SH;
         node = strip_node(g, rs0 + rr, ca + cc);
         if (node >= 0) {
-          const int l = labels[node];
-          const int pl = prop ? (int)prop[node] : alpha;
-          f = fwd_w[node];
-          f.x *= beta; f.y *= beta; f.z *= beta; f.w *= beta;
-          u0 = u_cur ? u_cur[node] : uT[(int64_t)l * n + node];
-          if (pl != l) u1 = uT[(int64_t)pl * n + node];
-          lw = l | (pl << 8) | (1 << 16);
-        }
-      }
-      tab[t * REC + 0] = f.x;
-      tab[t * REC + 1] = f.y;
-      tab[t * REC + 2] = f.z;
-      tab[t * REC + 3] = f.w;
-      tabi[t * REC + 4] = lw;
-      rc0[p] = u0; rc1[p] = u1; rnode[p] = node;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int cu = g.orient ? 0 : 2;      // component of the UP cell's record that holds the edge to me
-    const int cl = g.orient ? 2 : 0;      //              of the LEFT cell's
-    const int ld_off = g.orient ? 4 : 0;  // the left-down edge is held by that cell (orient 1) or by me (orient 0)
+          const int e0 = (cc + 1) * EH + (rr + 1);
+          const int lw = tabi[e0 * REC + 4];
+          const int l = lw & 255, pl = (lw >> 8) & 255;
+          const bool can = pl != l;
+          const float u0 = u_cur ? u_cur[node] : uT[(int64_t)l * n + node];
+          const float u1 = can ? uT[(int64_t)pl * n + node] : BIG;
+          float a0 = 0.f, a1 = 0.f;            // rim sums
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      const int t = p * 64 + lane;
-      const int node = rnode[p];
-      bool sw = false;
-      float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
-      int bits = 0;
-      if (node >= 0) {
-        const int cc = t / SH, rr = t - cc * SH;
-        const bool up = rr > 0, dn = rr < SH - 1, lf = cc > 0;
-        const int lw = tabi[t * REC + 4];
-        const int l = lw & 255, pl = (lw >> 8) & 255;
-        const bool can = pl != l;
-        c0 = rc0[p];
-        c1 = rc1[p];
-        int nlab[4] = {0, 0, 0, 0};
-        if (up) { w4[0] = tab[(t - 1) * REC + cu]; nlab[0] = tabi[(t - 1) * REC + 4]; }
-        if (up && lf) { w4[1] = tab[(t - 6) * REC + 3]; nlab[1] = tabi[(t - 6) * REC + 4]; }
-        if (lf) { w4[2] = tab[(t - 5) * REC + cl]; nlab[2] = tabi[(t - 5) * REC + 4]; }
-        if (dn && lf) { w4[3] = tab[(t - ld_off) * REC + 1]; nlab[3] = tabi[(t - 4) * REC + 4]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (!((nlab[q] >> 16) & 1)) { w4[q] = 0.f; continue; }      // absent cell (outside the grid / triangle)
-          const int lj = nlab[q] & 255, pj = (nlab[q] >> 8) & 255;
-          const int nib = (l != lj ? 1 : 0) | (l != pj ? 2 : 0) | (pl != lj ? 4 : 0) | (pl != pj ? 8 : 0);
-          bits |= nib << (4 * q);
+          for (int d = 0; d < 8; ++d) {
+            constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+            constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+            const int dr = DR[d], dc = DC[d];
+            const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;       // grid direction of the edge
+            // forward edges (E, SW, S, SE) are held by me, backward ones (W, NE, N, NW) by the neighbour, same component:
+            // E/W -> 0, SW/NE -> 1, S/N -> 2, SE/NW -> 3
+            const bool fwd = di > 0 || (di == 0 && dj > 0);
+            const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
+            const int en = e0 + dc * EH + dr;
+            const float w = fwd ? tab[e0 * REC + comp] : tab[en * REC + comp];
+            const int nl = tabi[en * REC + 4];
+            const int lj = nl & 255, pj = (nl >> 8) & 255;
+            const int r2 = rr + dr, c2 = cc + dc;
+            const bool inside = r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols;
+            // visited-before neighbours: up (d 1), left-up (d 0), left (d 3), left-down (d 5)
+            constexpr int QOF[8] = {1, 0, -1, 2, -1, 3, -1, -1};
+            if (QOF[d] >= 0) {
+              if (inside) {
+                w4[QOF[d]] = w;
+                const int nib = (l != lj ? 1 : 0) | (l != pj ? 2 : 0) | (pl != lj ? 4 : 0) | (pl != pj ? 8 : 0);
+                bits |= nib << (4 * QOF[d]);
+              }
+            }
+            if (!inside) {                       // fixed neighbour (an absent one has weight 0)
+              if (l != lj) a0 += w;
+              if (pl != lj) a1 += w;
+            }
+          }
+          c0 = u0 + a0;
+          c1 = can ? u1 + a1 : BIG;
+          sw = can;
         }
-        // the rim: neighbours outside the strip rectangle keep their labels
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-          constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-          const int r2 = rr + DR[d], c2 = cc + DC[d];
-          if (r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols) continue;
-          const int j = strip_node(g, rs0 + r2, ca + c2);
-          if (j < 0) continue;
-          const int di = g.orient ? DC[d] : DR[d], dj = g.orient ? DR[d] : DC[d];   // grid direction of the edge
-          // forward edges (E, SW, S, SE) are mine; backward ones (W, NE, N, NW) are the neighbour's, same component
-          const int comp = (di == 0) ? 0 : (dj + 2);          // E/W -> 0, SW/NE -> 1, S/N -> 2, SE/NW -> 3 (with di = +-1)
-          const int comp_b = (di == 0) ? 0 : (2 - dj);        // backward: (-1,+1) NE -> 1, (-1,0) N -> 2, (-1,-1) NW -> 3
-          const bool fwd = di > 0 || (di == 0 && dj > 0);
-          float w;
-          if (fwd) w = tab[t * REC + comp];
-          else w = beta * reinterpret_cast<const float*>(fwd_w + j)[comp_b];
-          const int lj = labels[j];
-          if (l != lj) c0 += w;
-          if (can && pl != lj) c1 += w;
-        }
-        sw = can;
-        if (!sw) c1 = BIG;
       }
       rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
-      rbits[p] = bits;
+      rbits[p] = bits; rnode[p] = node;
       const unsigned long long swm = __ballot(sw);
       if (swm) {
         const int first = p * 64 + __ffsll((long long)swm) - 1;
@@ -359,6 +357,7 @@ __global__ __launch_bounds__(256, 4) void strip_kernel(StripGeom g, int64_t n, i
         t_lo = first < t_lo ? first : t_lo;
         t_hi = last > t_hi ? last : t_hi;
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the passes apart: interleaving them only costs registers
     }
     __builtin_amdgcn_wave_barrier();      // the slab is about to be reused for the cost tables
     if (t_hi < 0 || (debug & 3) == 1) {           // nothing can move in this strip (wave-uniform)
@@ -735,13 +734,17 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   if (grid > 256 * 32) grid = 256 * 32;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
   const bool masks = use_mask && use_memo && alpha >= 0;
-  hipLaunchKernelGGL(strip_kernel, dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT,
-                     masks ? b->u_cur : nullptr, b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta,
-                     b->counters + b->counter_slot, masks ? b->strip_mask : nullptr,
-                     (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3),
-                     b->tick ? b->stamp : nullptr,
-                     use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,
-                     use_memo ? b->strip_newest : nullptr, b->tick);
+#define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
+  hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
+                     masks ? b->u_cur : nullptr, b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta,          \
+                     b->counters + b->counter_slot, masks ? b->strip_mask : nullptr,                                   \
+                     (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3),               \
+                     b->tick ? b->stamp : nullptr,                                                                     \
+                     use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
+                     use_memo ? b->strip_newest : nullptr, b->tick)
+  if (orient) PHMRF_LAUNCH_STRIP(1);
+  else PHMRF_LAUNCH_STRIP(0);
+#undef PHMRF_LAUNCH_STRIP
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
