@@ -150,10 +150,14 @@ __device__ __forceinline__ void write_lane(unsigned int& dst, unsigned int value
 // All steps of pass P (cells t = 64 P + tt): the pass's 64 cell tables are built into the wave's LDS slab, then walked.
 template <int P>
 __device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
-                                        float wld, int bits, int t_lo, int t_end, unsigned int& dlo, unsigned int& dhi) {
-  dlo = 0u;
-  dhi = 0u;
-  if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
+                                        float wld, int bits, int t_lo, int t_end) {
+  // decision ballots of the pass: lane tt keeps the ballot of step tt; parked in LDS behind the tables at the end
+  unsigned int dlo = 0u, dhi = 0u;
+  uint2* decs = reinterpret_cast<uint2*>(tab + 64 * TAB) + P * 64;
+  if (P * 64 > t_end || P * 64 + 63 < t_lo) {
+    decs[lane] = make_uint2(0u, 0u);
+    return;
+  }
   build_table(tab, lane, c0, c1, wu, wlu, wl, wld, bits);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -182,15 +186,18 @@ __device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* ta
     PHMRF_STEP(0) PHMRF_STEP(1) PHMRF_STEP(2) PHMRF_STEP(3) PHMRF_STEP(4) PHMRF_STEP(5)
 #undef PHMRF_STEP
   }
+  decs[lane] = make_uint2(dlo, dhi);
   __builtin_amdgcn_wave_barrier();
 }
 
 // Backtrack of pass P on scalars: x_t = bit q of the state, then the state gets back the bit of cell t-6.
 template <int P>
-__device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, unsigned int dlo, unsigned int dhi,
+__device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, const float* tab, int lane,
                                                unsigned int& xsel) {
   xsel = 0u;
   if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
+  const uint2 dd = (reinterpret_cast<const uint2*>(tab + 64 * TAB) + P * 64)[lane];
+  const unsigned int dlo = dd.x, dhi = dd.y;
   int tb0 = t_lo - P * 64;
   tb0 = tb0 < 0 ? 0 : tb0 - tb0 % 6;
   int tb1 = t_end - P * 64;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     //      compile-time offsets: the four already-visited in-strip ones give the pair tables, the rim ones are folded
     //      into the unary costs.
     float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
-    int rbits[NPASS], rnode[NPASS];
+    int rbits[NPASS];
     int t_lo = NCELL_MAX, t_hi = -1;
     int* tabi = reinterpret_cast<int*>(tab);
     const int ecells = EH * (ncols + 2);
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
         }
       }
       rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
-      rbits[p] = bits; rnode[p] = node;
+      rbits[p] = bits;
       const unsigned long long swm = __ballot(sw);
       if (swm) {
         const int first = p * 64 + __ffsll((long long)swm) - 1;
@@ -384,12 +391,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     //      parked in lane (t mod 64) of a per-pass register pair.
     float m = lane == 0 ? 0.f : BIG;     // every cell before t_lo keeps its label: profile 000000
     float zz = 0.f;
-    unsigned int dlo[NPASS], dhi[NPASS];
-    dp_pass<0>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
-    dp_pass<1>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
-    dp_pass<2>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
-    dp_pass<3>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
-    dp_pass<4>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
+    dp_pass<0>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
+    dp_pass<1>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
+    dp_pass<2>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
+    dp_pass<3>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
+    dp_pass<4>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
 
     if ((debug & 3) == 2) continue;
     // ---- final state: among the minimisers take the one whose SHIFT-encoded index (newest cell in bit 0, as in the
@@ -414,22 +420,27 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     // ---- backtrack on scalars; the choice of cell t lands in lane (t mod 64) of xsel[pass]
     unsigned int xsel[NPASS];
     s = __builtin_amdgcn_readfirstlane(s);
-    backtrack_pass<4>(s, t_lo, t_end, dlo[4], dhi[4], xsel[4]);
-    backtrack_pass<3>(s, t_lo, t_end, dlo[3], dhi[3], xsel[3]);
-    backtrack_pass<2>(s, t_lo, t_end, dlo[2], dhi[2], xsel[2]);
-    backtrack_pass<1>(s, t_lo, t_end, dlo[1], dhi[1], xsel[1]);
-    backtrack_pass<0>(s, t_lo, t_end, dlo[0], dhi[0], xsel[0]);
+    backtrack_pass<4>(s, t_lo, t_end, tab, lane, xsel[4]);
+    backtrack_pass<3>(s, t_lo, t_end, tab, lane, xsel[3]);
+    backtrack_pass<2>(s, t_lo, t_end, tab, lane, xsel[2]);
+    backtrack_pass<1>(s, t_lo, t_end, tab, lane, xsel[1]);
+    backtrack_pass<0>(s, t_lo, t_end, tab, lane, xsel[0]);
 
     // ---- phase 3: lane <-> cell: apply
+    __builtin_amdgcn_wave_barrier();
     bool moved = false;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      if (xsel[p] && rnode[p] >= 0) {
-        labels[rnode[p]] = prop ? prop[rnode[p]] : (uint8_t)alpha;
-        if (u_cur) u_cur[rnode[p]] = uT[(int64_t)alpha * n + rnode[p]];
+      const int t = p * 64 + lane;
+      if (xsel[p] && t < ncell) {
+        const int cc = t / SH, rr = t - cc * SH;
+        const int node = strip_node(g, rs0 + rr, ca + cc);
+        if (node < 0) continue;
+        labels[node] = prop ? prop[node] : (uint8_t)alpha;
+        if (u_cur) u_cur[node] = uT[(int64_t)alpha * n + node];
         if (stamp) {
-          stamp[rnode[p]] = (uint16_t)tick;
-          const int32_t* nb2 = nbr + (int64_t)rnode[p] * D;
+          stamp[node] = (uint16_t)tick;
+          const int32_t* nb2 = nbr + (int64_t)node * D;
           for (int j = 0; j < D; ++j)
             if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick;
         }
