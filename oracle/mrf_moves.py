@@ -375,7 +375,8 @@ def strip_fusion(g, unary, labels, prop, beta, H, W, diagonal, orient, shift_r, 
             return m[:, pred] + cost
         a0 = total(st >> 1)
         a1 = total((st >> 1) | (1 << h))
-        take1 = a1 < a0
+        # ties keep the predecessor whose leaving bit equals the new cell's bit (the kernel's "self" lane)
+        take1 = np.where(bbit[None, :] == 1, a1 <= a0, a1 < a0)
         m = np.where(take1, a1, a0)
         back[:, t, :] = take1
         done = ncell == t + 1

@@ -58,15 +58,16 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 template <int Q>
 __device__ __forceinline__ float xor_exchange(float v) {
   const int iv = __builtin_bit_cast(int, v);
-  if (Q == 0) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xf, 0xf, false));   // [1,0,3,2]
-  if (Q == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xf, 0xf, false));   // [2,3,0,1]
+  // (old = 0 with bound_ctrl: every lane has a valid source, and the move can be folded into the consuming v_add)
+  if (Q == 0) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, true));   // [1,0,3,2]
+  if (Q == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, true));   // [2,3,0,1]
   if (Q == 2) {  // xor 4 = half_mirror (xor 7) then quad reverse (xor 3)
-    const int a = __builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(a, a, 0x1B, 0xf, 0xf, false));               // [3,2,1,0]
+    const int a = __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, a, 0x1B, 0xf, 0xf, true));               // [3,2,1,0]
   }
   if (Q == 3) {  // xor 8 = row_mirror (xor 15) then half_mirror (xor 7)
-    const int a = __builtin_amdgcn_update_dpp(iv, iv, 0x140, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(a, a, 0x141, 0xf, 0xf, false));
+    const int a = __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, true));
   }
   if (Q == 4) {  // odd rows of vdst <-> even rows of vsrc
     auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
@@ -79,7 +80,8 @@ __device__ __forceinline__ float xor_exchange(float v) {
 // ---- per-cell cost tables (LDS, one pass of 64 cells at a time) ---------------------------------------------------
 // Cell record in LDS (20 floats = 80 B, conflict-free for ds_write_b128 at this stride):
 //   [0..15]  base[b][bu][bl][bld] = c_b + wu*N_u[b][bu] + wl*N_l[b][bl] + wld*N_ld[b][bld]
-//   [16..19] lu[b][d]             = wlu*N_lu[b][d]           (d = choice of the left-up cell leaving the profile)
+//   [16..19] lu[b][self], lu[b][other] = wlu*N_lu[b][d]      (d = choice of the left-up cell leaving the profile:
+//                                                              "self" d == b, "other" d == 1 - b)
 constexpr int TAB = 20;
 // phase-1 staging record per cell (same LDS slab, before the tables are built): the four forward grid weights of the
 // cell (times beta) and its packed labels (l | p << 8 | present << 16); stride 5 words: conflict-free.
@@ -106,8 +108,8 @@ __device__ __forceinline__ void build_table(float* tab, int lane, float c0, floa
     }
     dst[g4] = make_float4(v[0], v[1], v[2], v[3]);
   }
-  dst[4] = make_float4(((bits >> 4) & 1) ? wlu : 0.f, ((bits >> 5) & 1) ? wlu : 0.f, ((bits >> 6) & 1) ? wlu : 0.f,
-                       ((bits >> 7) & 1) ? wlu : 0.f);
+  dst[4] = make_float4(((bits >> 4) & 1) ? wlu : 0.f, ((bits >> 5) & 1) ? wlu : 0.f, ((bits >> 7) & 1) ? wlu : 0.f,
+                       ((bits >> 6) & 1) ? wlu : 0.f);
 }
 
 // One cell step of the profile DP.  The profile is kept in ROTATING positions: cell t owns bit (t mod 6) of the state
@@ -124,20 +126,18 @@ __device__ __forceinline__ int tab_offset(int lane) {   // byte offsets of this 
 }
 
 template <int Q>
-__device__ __forceinline__ void dp_step(float& m, float& zz, int lane, float base, float lu0, float lu1,
+__device__ __forceinline__ void dp_step(float& m, float& zz, float base, float lu_self, float lu_other,
                                         unsigned long long* decision) {
   // zz: in lane 0 (state 000000) the cost of the path on which NO cell switches, accumulated with the very operations
   // the DP uses for that path, so that "the optimum is the current labelling" can be tested bit-exactly afterwards
-  zz = base + (zz + lu0);
-  const int b = (lane >> Q) & 1;
-  const float other = xor_exchange<Q>(m);
-  const float o0 = b ? other : m;      // old value of the state whose bit q (cell t-6) is 0
-  const float o1 = b ? m : other;      //                                              is 1
-  const float e0 = o0 + lu0;
-  const float e1 = o1 + lu1;
-  const bool take1 = e1 < e0;
-  m = base + (take1 ? e1 : e0);
-  *decision = __ballot(take1);
+  zz = base + (zz + lu_self);
+  // the two predecessors of state s differ in bit q (the choice d of cell t-6, which leaves the profile): "self" is this
+  // lane's own value (d equal to the new cell's bit b), "other" the value of lane s ^ (1 << q).  Ties keep "self".
+  const float e_self = m + lu_self;
+  const float e_other = xor_exchange<Q>(m) + lu_other;
+  const bool take_other = e_other < e_self;
+  m = base + (take_other ? e_other : e_self);
+  *decision = __ballot(take_other);
 }
 
 #define PHMRF_RL(x, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l))
@@ -148,14 +148,14 @@ __device__ __forceinline__ void write_lane(unsigned int& dst, unsigned int value
 }
 
 // All steps of pass P (cells t = 64 P + tt): the pass's 64 cell tables are built into the wave's LDS slab, then walked.
-template <int P>
+template <int P, bool RECORD>
 __device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
                                         float wld, int bits, int t_lo, int t_end) {
   // decision ballots of the pass: lane tt keeps the ballot of step tt; parked in LDS behind the tables at the end
   unsigned int dlo = 0u, dhi = 0u;
   uint2* decs = reinterpret_cast<uint2*>(tab + 64 * TAB) + P * 64;
   if (P * 64 > t_end || P * 64 + 63 < t_lo) {
-    decs[lane] = make_uint2(0u, 0u);
+    if (RECORD) decs[lane] = make_uint2(0u, 0u);
     return;
   }
   build_table(tab, lane, c0, c1, wu, wlu, wl, wld, bits);
@@ -178,15 +178,17 @@ __device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* ta
       const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(lane));                                 \
       const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((lane >> Q) & 1) * 8);                          \
       unsigned long long dec;                                                                                        \
-      dp_step<Q>(m, zz, lane, base, lu.x, lu.y, &dec);                                                                  \
-      write_lane(dlo, (unsigned int)(dec & 0xffffffffull), tt);                                                      \
-      write_lane(dhi, (unsigned int)(dec >> 32), tt);                                                                \
+      dp_step<Q>(m, zz, base, lu.x, lu.y, &dec);                                                                     \
+      if (RECORD) {                                                                                                  \
+        write_lane(dlo, (unsigned int)(dec & 0xffffffffull), tt);                                                    \
+        write_lane(dhi, (unsigned int)(dec >> 32), tt);                                                              \
+      }                                                                                                              \
     }                                                                                                                \
   }
     PHMRF_STEP(0) PHMRF_STEP(1) PHMRF_STEP(2) PHMRF_STEP(3) PHMRF_STEP(4) PHMRF_STEP(5)
 #undef PHMRF_STEP
   }
-  decs[lane] = make_uint2(dlo, dhi);
+  if (RECORD) decs[lane] = make_uint2(dlo, dhi);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -212,7 +214,7 @@ __device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, cons
       const unsigned long long dec = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, tt) << 32) | \
                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, tt);      \
       const int x = (s >> Q) & 1;                                                                                    \
-      const int d = (int)((dec >> s) & 1ull);                                                                        \
+      const int d = x ^ (int)((dec >> s) & 1ull);     /* the ballot says "took the OTHER predecessor" */             \
       s = (s & ~(1 << Q)) | (d << Q);                                                                                \
       write_lane(xsel, (unsigned int)x, tt);                                                                         \
     }                                                                                                                \
@@ -305,7 +307,9 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int t = p * 64 + lane;
+      int t = p * 64 + lane;
+      asm volatile("" : "+v"(t));     // not loop-invariant for the compiler: hoisting the per-pass cell coordinates
+                                      // out of the strip loop would pin ~20 VGPRs for the whole kernel
       bool sw = false;
       float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
       int bits = 0, node = -1;
@@ -349,6 +353,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
               if (l != lj) a0 += w;
               if (pl != lj) a1 += w;
             }
+            if (d & 1) __builtin_amdgcn_sched_barrier(0);   // two directions in flight at a time: registers, not latency
           }
           c0 = u0 + a0;
           c1 = can ? u1 + a1 : BIG;
@@ -391,11 +396,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     //      parked in lane (t mod 64) of a per-pass register pair.
     float m = lane == 0 ? 0.f : BIG;     // every cell before t_lo keeps its label: profile 000000
     float zz = 0.f;
-    dp_pass<0>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
-    dp_pass<1>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
-    dp_pass<2>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
-    dp_pass<3>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
-    dp_pass<4>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
+    dp_pass<0, false>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
+    dp_pass<1, false>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
+    dp_pass<2, false>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
+    dp_pass<3, false>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
+    dp_pass<4, false>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
 
     if ((debug & 3) == 2) continue;
     // ---- final state: among the minimisers take the one whose SHIFT-encoded index (newest cell in bit 0, as in the
@@ -413,6 +418,14 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
       }
     }
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 104, 1ull);   // DPs that found a move
+    // a move exists (about 3 strips in 1000): walk the DP again, this time recording the decision ballots
+    m = lane == 0 ? 0.f : BIG;
+    zz = 0.f;
+    dp_pass<0, true>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
+    dp_pass<1, true>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
+    dp_pass<2, true>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
+    dp_pass<3, true>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
+    dp_pass<4, true>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
     const float cand = (m == mmin) ? (float)sidx : 127.f;
     const float best = wave_min_f32(cand);
     int s = __ffsll((long long)__ballot(cand == best)) - 1;
