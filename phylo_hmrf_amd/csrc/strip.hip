@@ -15,6 +15,7 @@
 // the pass never raises the energy.   (Model: oracle/mrf_moves.strip_fusion.)
 
 #include <cstdlib>
+#include <utility>
 
 #include "common.h"
 
@@ -126,11 +127,8 @@ __device__ __forceinline__ int tab_offset(int lane) {   // byte offsets of this 
 }
 
 template <int Q>
-__device__ __forceinline__ void dp_step(float& m, float& zz, float base, float lu_self, float lu_other,
+__device__ __forceinline__ void dp_step(float& m, unsigned long long& took, float base, float lu_self, float lu_other,
                                         unsigned long long* decision) {
-  // zz: in lane 0 (state 000000) the cost of the path on which NO cell switches, accumulated with the very operations
-  // the DP uses for that path, so that "the optimum is the current labelling" can be tested bit-exactly afterwards
-  zz = base + (zz + lu_self);
   // the two predecessors of state s differ in bit q (the choice d of cell t-6, which leaves the profile): "self" is this
   // lane's own value (d equal to the new cell's bit b), "other" the value of lane s ^ (1 << q).  Ties keep "self".
   const float e_self = m + lu_self;
@@ -138,6 +136,9 @@ __device__ __forceinline__ void dp_step(float& m, float& zz, float base, float l
   const bool take_other = e_other < e_self;
   m = base + (take_other ? e_other : e_self);
   *decision = __ballot(take_other);
+  // took bit 0: state 000000 was once reached more cheaply from a state with a switched cell than along the all-keep
+  // path.  Both continue identically with "keep", so this happens iff a strictly improving move exists (a scalar OR).
+  took |= *decision;
 }
 
 #define PHMRF_RL(x, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l))
@@ -147,9 +148,26 @@ __device__ __forceinline__ void write_lane(unsigned int& dst, unsigned int value
   dst = ((int)(threadIdx.x & 63) == lane_sel) ? value : dst;
 }
 
+// One step at a compile-time position: the table addresses are a per-lane register plus an immediate offset.
+template <int P, int TT>
+__device__ __forceinline__ void dp_step_at(float& m, unsigned long long& took, int lane, const char* tabc) {
+  constexpr int Q = (4 * P + TT) % 6;
+  const char* rec = tabc + TT * (TAB * 4);
+  const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(lane));
+  const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((lane >> Q) & 1) * 8);
+  unsigned long long dec;
+  dp_step<Q>(m, took, base, lu.x, lu.y, &dec);
+}
+
+template <int P, int... TT>
+__device__ __forceinline__ void dp_steps_unrolled(float& m, unsigned long long& took, int lane, const char* tabc,
+                                                  std::integer_sequence<int, TT...>) {
+  (dp_step_at<P, TT>(m, took, lane, tabc), ...);
+}
+
 // All steps of pass P (cells t = 64 P + tt): the pass's 64 cell tables are built into the wave's LDS slab, then walked.
 template <int P, bool RECORD>
-__device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
+__device__ __forceinline__ void dp_pass(float& m, unsigned long long& took, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
                                         float wld, int bits, int t_lo, int t_end) {
   // decision ballots of the pass: lane tt keeps the ballot of step tt; parked in LDS behind the tables at the end
   unsigned int dlo = 0u, dhi = 0u;
@@ -168,6 +186,13 @@ __device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* ta
   int tb1 = t_end - P * 64;
   tb1 = tb1 > 63 ? 63 : tb1;
   const char* tabc = reinterpret_cast<const char*>(tab);
+  if (!RECORD) {
+    // the common walk (no decisions kept): all 64 steps of the pass as straight-line code, so that no address
+    // arithmetic is left in a step (cells outside [t_lo, t_end] are pinned or absent: visiting them changes nothing)
+    dp_steps_unrolled<P>(m, took, lane, tabc, std::make_integer_sequence<int, 64>{});
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
   for (int tb = tb0; tb <= tb1; tb += 6) {   // rotating position q = t mod 6 = (4 P + tt) mod 6: static in the 6-unroll
 #define PHMRF_STEP(J)                                                                                                \
   {                                                                                                                  \
@@ -178,7 +203,7 @@ __device__ __forceinline__ void dp_pass(float& m, float& zz, int lane, float* ta
       const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(lane));                                 \
       const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((lane >> Q) & 1) * 8);                          \
       unsigned long long dec;                                                                                        \
-      dp_step<Q>(m, zz, base, lu.x, lu.y, &dec);                                                                     \
+      dp_step<Q>(m, took, base, lu.x, lu.y, &dec);                                                                   \
       if (RECORD) {                                                                                                  \
         write_lane(dlo, (unsigned int)(dec & 0xffffffffull), tt);                                                    \
         write_lane(dhi, (unsigned int)(dec >> 32), tt);                                                              \
@@ -395,12 +420,12 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     // ---- phase 2: lane <-> state.  Records are broadcast with v_readlane, decisions are one 64-bit ballot per step
     //      parked in lane (t mod 64) of a per-pass register pair.
     float m = lane == 0 ? 0.f : BIG;     // every cell before t_lo keeps its label: profile 000000
-    float zz = 0.f;
-    dp_pass<0, false>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
-    dp_pass<1, false>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
-    dp_pass<2, false>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
-    dp_pass<3, false>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
-    dp_pass<4, false>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
+    unsigned long long took = 0ull;
+    dp_pass<0, false>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
+    dp_pass<1, false>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
+    dp_pass<2, false>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
+    dp_pass<3, false>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
+    dp_pass<4, false>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
 
     if ((debug & 3) == 2) continue;
     // ---- final state: among the minimisers take the one whose SHIFT-encoded index (newest cell in bit 0, as in the
@@ -410,22 +435,19 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
 #pragma unroll
     for (int j = 0; j < 6; ++j) sidx |= ((lane >> ((q_end - j + 6) % 6)) & 1) << j;
     const float mmin = wave_min_f32(m);
-    {   // the no-change path is optimal (bit-exactly, see dp_step): nothing to backtrack or apply
-      const float m0 = PHMRF_RL(m, 0), z0 = PHMRF_RL(zz, 0);
-      if (m0 == mmin && z0 == m0) {
-        if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
-        continue;
-      }
+    // the all-keep path is optimal (see dp_step): nothing to backtrack or apply -- the case of ~997 strips in 1000
+    if (!(took & 1ull) && PHMRF_RL(m, 0) == mmin) {
+      if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+      continue;
     }
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 104, 1ull);   // DPs that found a move
     // a move exists (about 3 strips in 1000): walk the DP again, this time recording the decision ballots
     m = lane == 0 ? 0.f : BIG;
-    zz = 0.f;
-    dp_pass<0, true>(m, zz, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
-    dp_pass<1, true>(m, zz, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
-    dp_pass<2, true>(m, zz, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
-    dp_pass<3, true>(m, zz, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
-    dp_pass<4, true>(m, zz, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
+    dp_pass<0, true>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
+    dp_pass<1, true>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
+    dp_pass<2, true>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
+    dp_pass<3, true>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
+    dp_pass<4, true>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
     const float cand = (m == mmin) ? (float)sidx : 127.f;
     const float best = wave_min_f32(cand);
     int s = __ffsll((long long)__ballot(cand == best)) - 1;
