@@ -360,6 +360,8 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->memo);
   dev_free(b->strip_newest);
   dev_free(b->strip_mask);
+  dev_free(b->work_list);
+  dev_free(b->work_count);
   dev_free(b->fwd_w);
   dev_free(b->uT);
   dev_free(b->u_cur);
@@ -902,6 +904,9 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       dev_free(b->memo);
       dev_free(b->strip_newest);
       dev_free(b->strip_mask);
+      dev_free(b->work_list);
+      if (!b->work_count) PHMRF_TRY(dev_alloc(&b->work_count, (size_t)64));
+      PHMRF_TRY(dev_alloc(&b->work_list, (size_t)max_strips * K));
       PHMRF_TRY(dev_alloc(&b->memo, (size_t)6 * max_strips * (K + 1)));
       PHMRF_TRY(dev_alloc(&b->strip_newest, (size_t)max_strips));
       PHMRF_TRY(dev_alloc(&b->strip_mask, (size_t)max_strips));
@@ -956,7 +961,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           if (any) {
             tic(b);
             PHMRF_TRY(launch_alpha_mask(b, bf));    // which labels can still pay off where (fresh per orientation)
-            PHMRF_TRY(launch_strip_scan(b, orient, GEOM_R[geom], GEOM_C[geom]));
+            PHMRF_TRY(launch_strip_scan(b, orient, GEOM_R[geom], GEOM_C[geom], geom));
             toc(b, KC_PROPOSE, 2);
           }
           for (int a = 0; a < K; ++a)

@@ -100,6 +100,9 @@ struct phmrf_block {
   bool uT_valid = false;                    //   ... current with logprob
   float* u_cur = nullptr;                   // device [n]: -logprob[i][l_i], kept current during the expansions of a round
   unsigned long long* strip_mask = nullptr; // device [memo_strips]: OR of alpha_mask over a strip's cells (current cut)
+  int32_t* work_list = nullptr;             // device [K][memo_strips]: strips queued for the expansion of each label
+  int32_t* work_count = nullptr;            // device [64]: their number
+  int scan_geom = 0;                        // which fixed cut launch_strip_scan is building the tables for
   // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS
   // (0 = not since the solve began);
   // memo[orient][geom][strip][alpha] = tick of the last strip alpha-expansion of that strip that found nothing to do.
@@ -153,7 +156,7 @@ int launch_propose(const phmrf_block* b, float beta);  // best alternative label
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
                       int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
 int launch_alpha_mask(phmrf_block* b, float beta);
-int launch_strip_scan(const phmrf_block* b, int orient, int shift_r, int shift_c);   // -> strip_newest, strip_mask
+int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int geom);   // -> strip_newest, strip_mask
 int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
 

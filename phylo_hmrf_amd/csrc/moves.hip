@@ -58,14 +58,20 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
   unsigned int my_changed = 0;
   const int KV = K / VEC;
 
-  for (int seg0 = blockIdx.x * WPB; seg0 < nseg; seg0 += gridDim.x * WPB) {  // uniform trip count per block
-    const int seg = seg0 + wave;
-    const bool active = seg < nseg;
-    const int p0 = active ? seg_start[seg] : 0;
-    int len = active ? seg_len[seg] : 0;
+  // waves are independent (each has its own LDS tile): wave-level fences only, no block barrier
+#define PHMRF_WAVE_SYNC()                                   \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+  } while (0)
+  for (int seg = blockIdx.x * WPB + wave; seg < nseg; seg += gridDim.x * WPB) {
+    const bool active = true;
+    const int p0 = seg_start[seg];
+    int len = seg_len[seg];
     // memo: a segment none of whose nodes (nor their neighbours: the stamps are dilated) changed since its last run
-    // that found nothing to do sees identical inputs and is skipped.  (The barriers below stay wave-uniform.)
-    if (memo && active) {
+    // that found nothing to do sees identical inputs and is skipped.
+    if (memo) {
       const int last_quiet = memo[seg];
       int st = (lane < len) ? (int)stamp[order[p0 + lane]] : 0;
 #pragma unroll
@@ -73,11 +79,12 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
         const int o2 = __shfl_xor(st, off, 64);
         st = o2 > st ? o2 : st;
       }
-      if (last_quiet && st < last_quiet) len = 0;
+      if (last_quiet && st < last_quiet) continue;
     }
     const bool ran = len > 0;
+    (void)active;
     // phase 1a: theta rows <- -logprob rows (K/VEC lanes per row, coalesced)
-    for (int q = lane; q < len * KV; q += 64) {
+    for (int q = lane; q < (debug == 4 ? 0 : len * KV); q += 64) {
       const int r = q / KV;
       const int c = (q - r * KV) * VEC;
       const float* src = logprob + (int64_t)order[p0 + r] * K + c;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
         dst[0] = -src[0];
       }
     }
-    __syncthreads();
+    PHMRF_WAVE_SYNC();
     // phase 1b: lane t subtracts beta*w for every neighbour outside the segment-chain (fixed labels);
     //           the edge to the chain successor becomes the link weight
     const int node = lane < len ? order[p0 + lane] : -1;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
     if (lane >= len - 1) nx = -1;
     float link = 0.f;
     int old = 0;
-    if (lane < len) {
+    if (lane < len && debug != 3) {
       float* row = tile + lane * Kp;
       const int32_t* nb = nbr + (int64_t)node * D;
       const float* wg = wgt + (int64_t)node * D;
@@ -123,9 +130,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
       }
       old = labels[node];
     }
-    __syncthreads();
+    PHMRF_WAVE_SYNC();
     // phase 2: forward pass, lane <-> label
-    const int len2 = debug == 1 ? 0 : len;
+    const int len2 = (debug == 1 || debug == 3 || debug == 4) ? 0 : len;
     float m = (lane < K && len > 0) ? tile[lane] : BIG;
     unsigned int jm_lo = 0, jm_hi = 0, am_v = 0;  // lane t holds the decisions of step t
     for (int t = 1; t < len2; ++t) {
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
       }
       ++my_changed;
     }
-    __syncthreads();
+    PHMRF_WAVE_SYNC();
   }
   unsigned int s = my_changed;
 #pragma unroll
@@ -428,7 +435,7 @@ int ensure(T** p, size_t count) {
 
 }  // namespace
 
-static int chain_debug() {   // timing experiments only (PHMRF_CHAIN_DEBUG=1: phase 1 only, 2: no backtrack)
+static int chain_debug() {   // timing experiments only (PHMRF_CHAIN_DEBUG=1: phase 1 only, 2: no backtrack, 3: phase 1a only, 4: 1b only)
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PHMRF_CHAIN_DEBUG");

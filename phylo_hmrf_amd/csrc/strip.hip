@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
                                                     int alpha, float beta, unsigned long long* __restrict__ changed,
                                                     const unsigned long long* __restrict__ strip_mask, int debug,
                                                     uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
-                                                    uint16_t* __restrict__ newest, int tick) {
+                                                    uint16_t* __restrict__ newest, int tick,
+                                                    const int32_t* __restrict__ work_list,
+                                                    const int32_t* __restrict__ work_count) {
   __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];   // one 9.1 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -270,7 +272,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
   float* tab = tabs + wave * SLAB;
   unsigned int my_changed = 0;
 
-  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {   // waves are independent
+  // waves are independent.  Expansions inside a solve walk the dense work list of their label (strip_scan_kernel),
+  // everything else all strips of the cut.
+  const int n_work = work_list ? *work_count : nstrips;
+  for (int wi = blockIdx.x * WPB + wave; wi < n_work; wi += gridDim.x * WPB) {
+    const int strip = work_list ? work_list[wi] : wi;
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
     const int rs0 = bnd * (SH + 1) - g.shift_r;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     }
 
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
+    if (debug == 16) continue;           // timing experiments: launch + memo + mask only
     // ---- phase 1.  Step A: the strip's rectangle PLUS its fixed rim (7 x (ncols + 2) cells, lane <-> cell) is staged
     //      in LDS: per cell the four forward grid weights (times beta) and the packed labels -- 1 + 16 coalesced bytes
     //      per cell, each grid edge weight read once, by its upper/left end.  Step B: lane <-> strip cell
@@ -310,26 +317,46 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     int t_lo = NCELL_MAX, t_hi = -1;
     int* tabi = reinterpret_cast<int*>(tab);
     const int ecells = EH * (ncols + 2);
-    for (int e = lane; e < ecells; e += 64) {
-      const int ec = e / EH, er = e - ec * EH;
-      const int node = strip_node(g, rs0 - 1 + er, ca - 1 + ec);
-      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-      int lw = 0;
-      if (node >= 0) {
-        const int l = labels[node];
-        const int pl = prop ? (int)prop[node] : alpha;
-        f = fwd_w[node];
-        f.x *= beta; f.y *= beta; f.z *= beta; f.w *= beta;
-        lw = l | (pl << 8);
+    {
+      constexpr int NEP = (ECELLS + 63) / 64;       // 8 lane-passes over the staged rectangle
+      int enode[NEP];
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {               // all addresses first ...
+        int e = q * 64 + lane;
+        asm volatile("" : "+v"(e));                 // (kept out of the loop-invariant set, see step B)
+        const int ec = e / EH, er = e - ec * EH;
+        enode[q] = e < ecells ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
       }
-      tab[e * REC + 0] = f.x;
-      tab[e * REC + 1] = f.y;
-      tab[e * REC + 2] = f.z;
-      tab[e * REC + 3] = f.w;
-      tabi[e * REC + 4] = lw;
+      int elab[NEP], epl[NEP];
+      float4 ef[NEP];
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {               // ... then every load of the wave in flight at once
+        const int node = enode[q];
+        elab[q] = 0;
+        epl[q] = alpha;
+        ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node >= 0) {
+          elab[q] = labels[node];
+          if (prop) epl[q] = prop[node];
+          ef[q] = fwd_w[node];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {
+        const int e = q * 64 + lane;
+        if (e < ecells) {
+          const bool present = enode[q] >= 0;
+          tab[e * REC + 0] = ef[q].x * beta;
+          tab[e * REC + 1] = ef[q].y * beta;
+          tab[e * REC + 2] = ef[q].z * beta;
+          tab[e * REC + 3] = ef[q].w * beta;
+          tabi[e * REC + 4] = present ? (elab[q] | (epl[q] << 8)) : 0;
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (debug == 8) continue;            // timing experiments: step A only
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       int t = p * 64 + lane;
@@ -502,7 +529,10 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
 __global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, const uint16_t* __restrict__ stamp,
                                                          const unsigned long long* __restrict__ node_mask,
                                                          uint16_t* __restrict__ newest,
-                                                         unsigned long long* __restrict__ smask) {
+                                                         unsigned long long* __restrict__ smask,
+                                                         const uint16_t* __restrict__ memo, int K,
+                                                         int32_t* __restrict__ work_list, int32_t* __restrict__ work_count,
+                                                         int64_t list_stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
@@ -541,9 +571,20 @@ __global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, const uint
       mlo |= (unsigned int)__shfl_xor((int)mlo, off, 64);
       mhi |= (unsigned int)__shfl_xor((int)mhi, off, 64);
     }
+    const unsigned long long sm = ((unsigned long long)mhi << 32) | mlo;
     if (lane == 0) {
       newest[strip] = (uint16_t)nw;
-      smask[strip] = ((unsigned long long)mhi << 32) | mlo;
+      smask[strip] = sm;
+    }
+    // work lists of the expansions (lane <-> label): the strip is queued for label a when some cell could profit from a
+    // and something changed since the strip was last found quiet for a.  The expansion launches then walk dense lists
+    // instead of testing (and mostly skipping) every strip.
+    if (work_list && lane < K && ((sm >> lane) & 1ull)) {
+      const int last_quiet = memo[(int64_t)strip * (K + 1) + lane];
+      if (!(last_quiet && nw < last_quiet)) {
+        const int idx = atomicAdd(work_count + lane, 1);
+        work_list[(int64_t)lane * list_stride + idx] = strip;
+      }
     }
   }
 }
@@ -754,14 +795,18 @@ int launch_unary_planes(phmrf_block* b) {
 }
 
 // per-strip tables of the cut (orient, shift_r, shift_c): newest stamp and OR of the alpha masks (inside a solve)
-int launch_strip_scan(const phmrf_block* b, int orient, int shift_r, int shift_c) {
+int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int geom) {
+  b->scan_geom = geom;
   const StripGeom g = make_geom(b, orient, shift_r, shift_c);
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0 || !b->tick || (int64_t)nstrips > b->memo_strips) return PHMRF_OK;
   int grid = (nstrips + 3) / 4;
   if (grid > 256 * 32) grid = 256 * 32;
+  PHMRF_HIP(hipMemsetAsync(b->work_count, 0, 64 * sizeof(int32_t), b->stream));
+  const int geom_id = b->scan_geom;
   hipLaunchKernelGGL(strip_scan_kernel, dim3(grid), dim3(256), 0, b->stream, g, b->stamp, b->alpha_mask, b->strip_newest,
-                     b->strip_mask);
+                     b->strip_mask, b->memo + ((int64_t)(orient * 3 + geom_id) * b->memo_strips) * (b->K + 1), b->K,
+                     b->work_list, b->work_count, b->memo_strips);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
@@ -780,6 +825,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   if (grid > 256 * 32) grid = 256 * 32;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
   const bool masks = use_mask && use_memo && alpha >= 0;
+  if (masks && grid > 1024) grid = 1024;     // list-driven: one resident set of waves strides over the work list
 #define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
   hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
                      masks ? b->u_cur : nullptr, b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta,          \
@@ -787,7 +833,8 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
                      (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3),               \
                      b->tick ? b->stamp : nullptr,                                                                     \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
-                     use_memo ? b->strip_newest : nullptr, b->tick)
+                     use_memo ? b->strip_newest : nullptr, b->tick,                                                     \
+                     masks ? b->work_list + (int64_t)alpha * b->memo_strips : nullptr, masks ? b->work_count + alpha : nullptr)
   if (orient) PHMRF_LAUNCH_STRIP(1);
   else PHMRF_LAUNCH_STRIP(0);
 #undef PHMRF_LAUNCH_STRIP
