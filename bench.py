@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not record HIP events around the kernel launches (no per-kernel breakdown / roofline)")
     ap.add_argument("--cpu-sample", type=int, default=360, help="side N of the diagonal block used for the CPU baseline")
     ap.add_argument("--no-expansion", action="store_true")
     ap.add_argument("--energy-tol-ppb", type=int, default=1000,
@@ -190,7 +192,7 @@ def main():
     for _ in range(a.warmup):
         em_step()
     for b in blocks:
-        b.enable_timing(True)
+        b.enable_timing(not a.no_kernel_timing)
         b.reset_timing()
     del t_e[:], t_m[:]
     barrier()

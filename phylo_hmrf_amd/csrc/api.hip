@@ -737,12 +737,12 @@ static int icm_sweep_nocount(phmrf_block_t b, float beta) {
   return PHMRF_OK;
 }
 
-static int chain_sweep_nocount(phmrf_block_t b, float beta, int family, int phase) {
+static int chain_sweep_nocount(phmrf_block_t b, float beta, int family, int phase, bool timed = true) {
   const ChainFamily& f = b->families[family];
   if (b->tick) ++b->tick;
-  tic(b);
+  if (timed) tic(b);
   for (int c = 0; c < f.n_colours; ++c) PHMRF_TRY(launch_chain_colour(b, beta, family, c, phase));
-  toc(b, KC_CHAIN, f.n_colours);
+  if (timed) toc(b, KC_CHAIN, f.n_colours);
   return PHMRF_OK;
 }
 
@@ -804,7 +804,7 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
 }
 
 static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask = false,
-                              int geom = -1) {
+                              int geom = -1, bool timed = true) {
   if (alpha < 0) {
     tic(b);
     PHMRF_TRY(launch_propose(b, beta));
@@ -815,10 +815,10 @@ static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift
     PHMRF_TRY(launch_unary_planes(b));
     toc(b, KC_PROPOSE, 1);
   }
-  tic(b);
+  if (timed) tic(b);
   if (b->tick) ++b->tick;
   PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, use_mask, geom));
-  toc(b, KC_STRIP, 1);
+  if (timed) toc(b, KC_STRIP, 1);
   return PHMRF_OK;
 }
 
@@ -932,11 +932,17 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   while (rounds < o.max_rounds) {
     const int r = rounds;
     PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
-    for (int f = 0; f < n_fam; ++f)
-      if (active[72 + f]) {
-        b->counter_slot = 72 + f;
-        PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1));
-      }
+    {
+      int n_chain = 0;
+      tic(b);
+      for (int f = 0; f < n_fam; ++f)
+        if (active[72 + f]) {
+          b->counter_slot = 72 + f;
+          PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1, false));
+          n_chain += b->families[f].n_colours;
+        }
+      toc(b, KC_CHAIN, n_chain);
+    }
     if (active[76]) {
       b->counter_slot = 76;
       PHMRF_TRY(icm_sweep_nocount(b, bf));
@@ -964,11 +970,15 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
             PHMRF_TRY(launch_strip_scan(b, orient, GEOM_R[geom], GEOM_C[geom], geom));
             toc(b, KC_PROPOSE, 2);
           }
+          int n_exp = 0;                            // one timed interval for the label loop (events cost, too)
+          if (any) tic(b);
           for (int a = 0; a < K; ++a)
             if (active[8 + a]) {
               b->counter_slot = 8 + a;
-              PHMRF_TRY(strip_pass_nocount(b, bf, orient, GEOM_R[geom], GEOM_C[geom], a, true, geom));
+              PHMRF_TRY(strip_pass_nocount(b, bf, orient, GEOM_R[geom], GEOM_C[geom], a, true, geom, false));
+              ++n_exp;
             }
+          if (any) toc(b, KC_STRIP, n_exp);
         }
       }
     }

@@ -292,14 +292,15 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     //      last found quiet for this move, its inputs are identical -> nothing to do.
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 100, 1ull);   // strips seen (expansion slots only)
     uint16_t* my_memo = memo ? memo + (int64_t)strip * (K + 1) + (alpha >= 0 ? alpha : K) : nullptr;
-    if (my_memo) {
+    // (a listed strip has passed both tests in strip_scan_kernel already: no dependent loads in front of the work)
+    if (my_memo && !work_list) {
       const int last_quiet = *my_memo;
       if (last_quiet && (int)newest[strip] < last_quiet) continue;
     }
 
     // ---- phase 0 (expansions): strip_mask[strip] has bit a set when some cell of the strip could possibly profit from
     //      label a (alpha_mask_kernel, OR-ed per strip by strip_scan_kernel).  Otherwise: one 8-byte load and out.
-    if (strip_mask && alpha >= 0 && !((strip_mask[strip] >> alpha) & 1ull)) {
+    if (strip_mask && !work_list && alpha >= 0 && !((strip_mask[strip] >> alpha) & 1ull)) {
       if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
       continue;
     }
@@ -405,7 +406,6 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
               if (l != lj) a0 += w;
               if (pl != lj) a1 += w;
             }
-            if (d & 1) __builtin_amdgcn_sched_barrier(0);   // two directions in flight at a time: registers, not latency
           }
           c0 = u0 + a0;
           c1 = can ? u1 + a1 : BIG;
