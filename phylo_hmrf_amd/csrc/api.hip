@@ -880,6 +880,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   std::vector<char> active(128, 0);
   for (int sl : slots) active[sl] = 1;
   bool all_active = true;
+  bool verifying = false;
   // change stamps + per-strip memo of quiet expansions (exact skip of strips whose inputs did not change)
   static const int GEOM_R[3] = {0, 2, 4}, GEOM_C[3] = {0, 21, 42};
   if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
@@ -923,8 +924,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   } scope{b};
   // One round runs every ACTIVE move type: chain families, ICM, component moves, strip fusion per orientation, strip
   // alpha-expansion per label.  A type stays active while it still changes labels.  When a round is quiet (at most
-  // `min_changed` labels changed, or the energy did not go down) a VERIFICATION round with every type active decides:
-  // quiet again -> done.  (The energy test also ends the alternation between two labellings of exactly equal energy
+  // `min_changed` labels changed, or the energy did not go down) a VERIFICATION round with every type active (and the
+  // chain segments cut at their other set of separators) decides: quiet again -> done.  (The energy test also ends the alternation between two labellings of exactly equal energy
   // that different move types prefer; gco stops on the same criterion, GCoptimization.cpp:1298.)
   double e_prev_u = 0, e_prev_p = 0;
   PHMRF_TRY(energy_now(b, beta, &e_prev_u, &e_prev_p));
@@ -938,7 +939,9 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       for (int f = 0; f < n_fam; ++f)
         if (active[72 + f]) {
           b->counter_slot = 72 + f;
-          PHMRF_TRY(chain_sweep_nocount(b, bf, f, r & 1, false));
+          // cut phase 0 in ordinary rounds (so the segment memo applies from the second round on); the other set of
+          // separators is used by the verification rounds
+          PHMRF_TRY(chain_sweep_nocount(b, bf, f, verifying ? 1 : 0, false));
           n_chain += b->families[f].n_colours;
         }
       toc(b, KC_CHAIN, n_chain);
@@ -1025,14 +1028,16 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     const bool quiet = ch <= tol || !improved;
     if (quiet) {
-      if (all_active) {
+      if (all_active && verifying) {
         converged = 1;
         break;
       }
       for (int sl : slots) active[sl] = 1;           // verification round
       all_active = true;
+      verifying = true;
       continue;
     }
+    verifying = false;
     int n_act = 0;
     for (int sl : slots) {
       active[sl] = b->counters_host[sl] > 0 ? 1 : 0;
