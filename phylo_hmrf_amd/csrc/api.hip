@@ -886,6 +886,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
   PHMRF_HIP(hipMemsetAsync(b->stamp, 0, (size_t)b->n * sizeof(uint16_t), b->stream));
   b->tick = 1;
+  b->mask_tick = -1;
+  b->prop_tick = -1;
   if (chains)
     for (auto& f : b->families)
       for (int p = 0; p < 2; ++p)
@@ -920,6 +922,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     ~SolveScope() {
       blk->tick = 0;
       blk->counter_slot = 0;
+      blk->mask_tick = -1;
+      blk->prop_tick = -1;
     }
   } scope{b};
   // One round runs every ACTIVE move type: chain families, ICM, component moves, strip fusion per orientation, strip
@@ -1038,9 +1042,15 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       continue;
     }
     verifying = false;
+    // A type stays active while it changes labels.  With an energy tolerance, "changes labels" means: enough of them
+    // that, at this round's average gain per changed label, its share of the tolerance is exceeded (a type whose last
+    // run was worth less than tol / #types is rested until the verification round).
+    double min_labels = 0.0;
+    if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0)
+      min_labels = 1e-9 * o.energy_tol_ppb * std::fabs(e_prev) / (double)slots.size() / (gain / (double)ch);
     int n_act = 0;
     for (int sl : slots) {
-      active[sl] = b->counters_host[sl] > 0 ? 1 : 0;
+      active[sl] = (double)b->counters_host[sl] > min_labels ? 1 : 0;
       n_act += active[sl];
     }
     all_active = n_act == (int)slots.size();

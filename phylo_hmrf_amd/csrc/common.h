@@ -102,6 +102,7 @@ struct phmrf_block {
   unsigned long long* strip_mask = nullptr; // device [memo_strips]: OR of alpha_mask over a strip's cells (current cut)
   int32_t* work_list = nullptr;             // device [K][memo_strips]: strips queued for the expansion of each label
   int32_t* work_count = nullptr;            // device [64]: their number
+  int mask_tick = -1, prop_tick = -1;       // tick of the last alpha-mask / proposal launch of this solve (-1: none)
   int scan_geom = 0;                        // which fixed cut launch_strip_scan is building the tables for
   // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS
   // (0 = not since the solve began);
@@ -152,7 +153,7 @@ int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, 
 int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase);
 int launch_component_pass(phmrf_block* b, float beta);
 int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, double beta1);
-int launch_propose(const phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
+int launch_propose(phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
                       int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
 int launch_alpha_mask(phmrf_block* b, float beta);

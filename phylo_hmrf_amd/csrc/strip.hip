@@ -526,6 +526,8 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
 
 // One wave per strip of the current cut: newest[strip] = max dilated change stamp over the strip's cells (memo test),
 // smask[strip] = OR of the cells' alpha masks (phase 0 of the expansions).
+constexpr int SCAN_BATCH = 8;   // strips per wave between two rounds of work-list atomics
+
 __global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, const uint16_t* __restrict__ stamp,
                                                          const unsigned long long* __restrict__ node_mask,
                                                          uint16_t* __restrict__ newest,
@@ -533,58 +535,64 @@ __global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, const uint
                                                          const uint16_t* __restrict__ memo, int K,
                                                          int32_t* __restrict__ work_list, int32_t* __restrict__ work_count,
                                                          int64_t list_stride) {
+  __shared__ int32_t pend[4][SCAN_BATCH][64];   // per wave: the strips each lane (= label) is about to queue
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
-  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
-    const int bnd = strip / g.nsegs;
-    const int seg = strip - bnd * g.nsegs;
-    const int rs0 = bnd * (SH + 1) - g.shift_r;
-    const int cs0 = seg * 64 - g.shift_c;
-    const int ca = cs0 > 0 ? cs0 : 0;
-    const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
-    const int ncols = cb > ca ? cb - ca : 0;
-    int nw = 0;
-    unsigned int mlo = 0u, mhi = 0u;
-    for (int e = lane; e < SH * ncols; e += 64) {
-      // consecutive lanes along the memory-contiguous axis: strip columns for orient 0, strip rows for orient 1
-      int rr, cc;
-      if (g.orient) { cc = e / SH; rr = e - cc * SH; }
-      else { rr = e / ncols; cc = e - rr * ncols; }
-      const int node = strip_node(g, rs0 + rr, ca + cc);
-      if (node >= 0) {
-        if (stamp) {
-          const int st = stamp[node];
-          nw = st > nw ? st : nw;
-        }
-        if (node_mask) {
-          const unsigned long long m = node_mask[node];
-          mlo |= (unsigned int)m;
-          mhi |= (unsigned int)(m >> 32);
+  for (int s0 = (blockIdx.x * WPB + wave) * SCAN_BATCH; s0 < nstrips; s0 += gridDim.x * WPB * SCAN_BATCH) {
+    int npend = 0;
+    for (int k = 0; k < SCAN_BATCH && s0 + k < nstrips; ++k) {
+      const int strip = s0 + k;
+      const int bnd = strip / g.nsegs;
+      const int seg = strip - bnd * g.nsegs;
+      const int rs0 = bnd * (SH + 1) - g.shift_r;
+      const int cs0 = seg * 64 - g.shift_c;
+      const int ca = cs0 > 0 ? cs0 : 0;
+      const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
+      const int ncols = cb > ca ? cb - ca : 0;
+      int nw = 0;
+      unsigned int mlo = 0u, mhi = 0u;
+      for (int e = lane; e < SH * ncols; e += 64) {
+        // consecutive lanes along the memory-contiguous axis: strip columns for orient 0, strip rows for orient 1
+        int rr, cc;
+        if (g.orient) { cc = e / SH; rr = e - cc * SH; }
+        else { rr = e / ncols; cc = e - rr * ncols; }
+        const int node = strip_node(g, rs0 + rr, ca + cc);
+        if (node >= 0) {
+          if (stamp) {
+            const int st = stamp[node];
+            nw = st > nw ? st : nw;
+          }
+          if (node_mask) {
+            const unsigned long long m = node_mask[node];
+            mlo |= (unsigned int)m;
+            mhi |= (unsigned int)(m >> 32);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const int o2 = __shfl_xor(nw, off, 64);
-      nw = o2 > nw ? o2 : nw;
-      mlo |= (unsigned int)__shfl_xor((int)mlo, off, 64);
-      mhi |= (unsigned int)__shfl_xor((int)mhi, off, 64);
-    }
-    const unsigned long long sm = ((unsigned long long)mhi << 32) | mlo;
-    if (lane == 0) {
-      newest[strip] = (uint16_t)nw;
-      smask[strip] = sm;
-    }
-    // work lists of the expansions (lane <-> label): the strip is queued for label a when some cell could profit from a
-    // and something changed since the strip was last found quiet for a.  The expansion launches then walk dense lists
-    // instead of testing (and mostly skipping) every strip.
-    if (work_list && lane < K && ((sm >> lane) & 1ull)) {
-      const int last_quiet = memo[(int64_t)strip * (K + 1) + lane];
-      if (!(last_quiet && nw < last_quiet)) {
-        const int idx = atomicAdd(work_count + lane, 1);
-        work_list[(int64_t)lane * list_stride + idx] = strip;
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o2 = __shfl_xor(nw, off, 64);
+        nw = o2 > nw ? o2 : nw;
+        mlo |= (unsigned int)__shfl_xor((int)mlo, off, 64);
+        mhi |= (unsigned int)__shfl_xor((int)mhi, off, 64);
       }
+      const unsigned long long sm = ((unsigned long long)mhi << 32) | mlo;
+      if (lane == 0) {
+        newest[strip] = (uint16_t)nw;
+        smask[strip] = sm;
+      }
+      // work lists of the expansions (lane <-> label): the strip is queued for label a when some cell could profit from
+      // a and something changed since the strip was last found quiet for a.  The expansion launches then walk dense
+      // lists instead of testing (and mostly skipping) every strip.
+      if (work_list && lane < K && ((sm >> lane) & 1ull)) {
+        const int last_quiet = memo[(int64_t)strip * (K + 1) + lane];
+        if (!(last_quiet && nw < last_quiet)) pend[wave][npend++][lane] = strip;
+      }
+    }
+    if (npend > 0) {       // one atomic per (wave, label) for the whole batch; list order does not matter
+      const int base = atomicAdd(work_count + lane, npend);
+      for (int q = 0; q < npend; ++q) work_list[(int64_t)lane * list_stride + base + q] = pend[wave][q][lane];
     }
   }
 }
@@ -613,13 +621,17 @@ template <int VEC>
 __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp, int D,
                                                       const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                       const uint8_t* __restrict__ labels, float beta,
-                                                      uint8_t* __restrict__ prop) {
+                                                      uint8_t* __restrict__ prop, const uint16_t* __restrict__ stamp,
+                                                      int since) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   const int KV = K / VEC;
   for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
     const int64_t rem = n - base;
     const int rows = rem < TB ? (int)rem : TB;
+    // since >= 0: the proposals of the previous launch are still in `prop`; a node's proposal depends on its own and
+    // its neighbours' labels only, so a tile none of whose (dilated) stamps is newer than that launch is left alone
+    if (since >= 0 && !__syncthreads_or((int)threadIdx.x < rows && (int)stamp[base + threadIdx.x] > since)) continue;
     for (int q = threadIdx.x; q < rows * KV; q += TB) {
       const int r = q / KV;
       const int c = (q - r * KV) * VEC;
@@ -666,13 +678,16 @@ template <int VEC>
 __global__ __launch_bounds__(256) void alpha_mask_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp, int D,
                                                          const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                          const uint8_t* __restrict__ labels, float beta,
-                                                         unsigned long long* __restrict__ mask, float* __restrict__ u_cur) {
+                                                         unsigned long long* __restrict__ mask, float* __restrict__ u_cur,
+                                                         const uint16_t* __restrict__ stamp, int since) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   const int KV = K / VEC;
   for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
     const int64_t rem = n - base;
     const int rows = rem < TB ? (int)rem : TB;
+    // since >= 0: masks and running unaries of the previous launch are still valid wherever no (dilated) stamp is newer
+    if (since >= 0 && !__syncthreads_or((int)threadIdx.x < rows && (int)stamp[base + threadIdx.x] > since)) continue;
     for (int q = threadIdx.x; q < rows * KV; q += TB) {
       const int r = q / KV;
       const int c = (q - r * KV) * VEC;
@@ -720,6 +735,8 @@ inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 }  // namespace
 
 int launch_alpha_mask(phmrf_block* b, float beta) {
+  // inside a solve the previous masks stay valid where nothing changed (b->mask_tick: tick of the previous launch)
+  const int since = (b->tick && b->alpha_mask && b->u_cur) ? b->mask_tick : -1;
   if (!b->alpha_mask) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->alpha_mask), (size_t)b->n * sizeof(unsigned long long)));
   if (!b->u_cur) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->u_cur), (size_t)b->n * sizeof(float)));
   const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
@@ -728,7 +745,7 @@ int launch_alpha_mask(phmrf_block* b, float beta) {
   const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
 #define PHMRF_LAUNCH_AM(VEC_)                                                                                          \
   hipLaunchKernelGGL((alpha_mask_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
-                     b->wgt, b->labels, beta, b->alpha_mask, b->u_cur)
+                     b->wgt, b->labels, beta, b->alpha_mask, b->u_cur, b->stamp, since)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_AM(4); break;
     case 2: PHMRF_LAUNCH_AM(2); break;
@@ -736,17 +753,19 @@ int launch_alpha_mask(phmrf_block* b, float beta) {
   }
 #undef PHMRF_LAUNCH_AM
   PHMRF_HIP(hipGetLastError());
+  b->mask_tick = b->tick ? b->tick : -1;
   return PHMRF_OK;
 }
 
-int launch_propose(const phmrf_block* b, float beta) {
+int launch_propose(phmrf_block* b, float beta) {
+  const int since = b->tick ? b->prop_tick : -1;
   const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
   const size_t lds = (size_t)TB * Kp * sizeof(float);
   int64_t g64 = (b->n + TB - 1) / TB;
   const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
 #define PHMRF_LAUNCH_PROP(VEC_)                                                                                     \
   hipLaunchKernelGGL((propose_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
-                     b->wgt, b->labels, beta, b->labels_tmp)
+                     b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_PROP(4); break;
     case 2: PHMRF_LAUNCH_PROP(2); break;
@@ -754,6 +773,7 @@ int launch_propose(const phmrf_block* b, float beta) {
   }
 #undef PHMRF_LAUNCH_PROP
   PHMRF_HIP(hipGetLastError());
+  b->prop_tick = b->tick ? b->tick : -1;
   return PHMRF_OK;
 }
 
@@ -800,7 +820,7 @@ int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int 
   const StripGeom g = make_geom(b, orient, shift_r, shift_c);
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0 || !b->tick || (int64_t)nstrips > b->memo_strips) return PHMRF_OK;
-  int grid = (nstrips + 3) / 4;
+  int grid = (nstrips + 4 * SCAN_BATCH - 1) / (4 * SCAN_BATCH);
   if (grid > 256 * 32) grid = 256 * 32;
   PHMRF_HIP(hipMemsetAsync(b->work_count, 0, 64 * sizeof(int32_t), b->stream));
   const int geom_id = b->scan_geom;
