@@ -1,0 +1,56 @@
+/* phmrf_host.h -- host-only helper of the EM loop (libphmrf_host.so, plain C ABI, no HIP dependency).
+ *
+ * The M-step of Phylo-HMRF fits, per hidden state, the 3B+2 Ornstein-Uhlenbeck parameters of the species tree to the
+ * sufficient statistics the GPU E-step produced (reference: phylo_hmrf.py:1500-1528 `_do_mstep`, :1327-1403
+ * `_ou_optimize2`, objective :1038-1138 `_ou_lik_varied_constraint`).  It is O(K) work independent of the number of
+ * nodes, so it stays on the host (SciPy SLSQP, as in the reference); but once the E-step takes milliseconds the K x ~200
+ * objective evaluations in NumPy cap the EM rate.  This entry point evaluates the objective and its analytic gradient
+ * natively; phylo_hmrf_amd/mstep.py binds it with ctypes and keeps the NumPy version for the ill-conditioned fall-back
+ * and as the test oracle of this function.
+ */
+#ifndef PHMRF_HOST_H
+#define PHMRF_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHMRF_HOST_API __attribute__((visibility("default")))
+
+#define PHMRF_HOST_OK 0
+#define PHMRF_HOST_ERR_INVALID 1   /* bad argument                                                            */
+#define PHMRF_HOST_ILL_CONDITIONED 2 /* V stayed ill-conditioned after 10 x min_covar (phylo_hmrf.py:1108-1133):
+                                        the caller takes the pseudo-inverse path                               */
+
+/* Species-tree tables (phylo_hmrf.py:715-919), all indices 0-based:
+ *   N nodes, parent[N] (-1 for a root), order[n_order] = the non-root nodes root-first,
+ *   leaf_vec[S] = leaf node of feature column s, n_pairs = S(S-1)/2 leaf pairs (pair_a < pair_b, indices into leaf_vec)
+ *   with their most recent common ancestor pair_anc and the 0/1 branch-path matrix A2[n_pairs, N].              */
+typedef struct phmrf_tree_tables {
+  int32_t N, S, n_pairs, n_order;
+  const int32_t* parent;
+  const int32_t* order;
+  const int32_t* leaf_vec;
+  const int32_t* pair_a;
+  const int32_t* pair_b;
+  const int32_t* pair_anc;
+  const double* A2;
+} phmrf_tree_tables;
+
+/* f(p) = post * log(det V + 1e-16) / n + tr(V^-1 S_w) / n + reg * |p|^2        (phylo_hmrf.py:1093-1113)
+ *   V = cov_OU(p) + min_covar * I (+ min_covar * I while ill-conditioned, at most 10 times),
+ *   S_w = oo - obs mu^T - mu obs^T + post * mu mu^T,  mu = OU leaf means,
+ *   p = [ root variance | beta_1..B | lambda_1..B | theta_0..B ],  B = N - 1.
+ * grad (3B+2 doubles) may be NULL; V_out (S*S) and mu_out (S) may be NULL.                                     */
+PHMRF_HOST_API int phmrf_ou_objective(const phmrf_tree_tables* tree, const double* p, double post, const double* obs,
+                                      const double* oo, double n_samples, double reg, double min_covar, double* f_out,
+                                      double* grad, double* V_out, double* mu_out);
+
+PHMRF_HOST_API int phmrf_host_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,14 +11,59 @@ Semantics of the reference (phylo_hmrf.py:1500-1528 `_do_mstep`, :1327-1403 `_ou
 
 What differs from the reference is speed only (once the E-step takes milliseconds the K
 SLSQP runs cap the EM rate): the objective comes with its ANALYTIC gradient (reverse sweep over the tree), the
-box is passed as `bounds`, and the K independent states are solved in a fork pool.
+box is passed as `bounds`, the K independent states are solved in a fork pool, and value + gradient are evaluated by
+the native host helper `libphmrf_host.so` (include/phmrf_host.h, csrc/ou_host.cpp; ~70x faster per evaluation).
+The NumPy implementation below stays as the fall-back for an ill-conditioned V (pseudo-inverse branch of the
+reference) and as the oracle of the native one (tests/test_mstep.py).
 """
+import ctypes
 import multiprocessing as mp
 import os
 import warnings
 
 import numpy as np
 from scipy.optimize import minimize
+
+_HOST_LIB = None
+
+
+class _TreeTables(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("S", ctypes.c_int32), ("n_pairs", ctypes.c_int32), ("n_order", ctypes.c_int32),
+                ("parent", ctypes.POINTER(ctypes.c_int32)), ("order", ctypes.POINTER(ctypes.c_int32)),
+                ("leaf_vec", ctypes.POINTER(ctypes.c_int32)), ("pair_a", ctypes.POINTER(ctypes.c_int32)),
+                ("pair_b", ctypes.POINTER(ctypes.c_int32)), ("pair_anc", ctypes.POINTER(ctypes.c_int32)),
+                ("A2", ctypes.POINTER(ctypes.c_double))]
+
+
+def host_lib():
+    """libphmrf_host.so (built by csrc/Makefile / __graft_entry__.build()); raises if it is missing."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libphmrf_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libphmrf_host.so is missing: run `make -C phylo_hmrf_amd/csrc` (or __graft_entry__.build())")
+        L = ctypes.CDLL(path)
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.phmrf_ou_objective.argtypes = [ctypes.POINTER(_TreeTables), dp, ctypes.c_double, dp, dp, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_double, dp, dp, dp, dp]
+        L.phmrf_ou_objective.restype = ctypes.c_int
+        L.phmrf_host_version.restype = ctypes.c_int
+        _HOST_LIB = L
+    return _HOST_LIB
+
+
+class NativeTree(object):
+    """The tree tables in the layout of `phmrf_tree_tables` (keeps the arrays alive)."""
+
+    def __init__(self, tree):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        self._arr = [i32(tree.parent), i32(tree.order), i32(tree.leaf_vec), i32(tree.pair_a), i32(tree.pair_b),
+                     i32(tree.pair_anc), np.ascontiguousarray(tree.A2, dtype=np.float64)]
+        ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        a = self._arr
+        self.tables = _TreeTables(tree.node_num, tree.n_features, len(tree.pair_a), len(tree.order), ip(a[0]), ip(a[1]),
+                                  ip(a[2]), ip(a[3]), ip(a[4]), ip(a[5]),
+                                  a[6].ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
 
 SMALL_EPS = 1e-16          # phylo_hmrf.py:49
 LOWER, UPPER = SMALL_EPS, 100.0
@@ -44,7 +89,9 @@ def _well_conditioned(V):
 class OUObjective(object):
     """f(p) and its gradient for one state.  post: N_c; obs: [S]; obsobsT: [S,S]."""
 
-    def __init__(self, tree, post, obs, obsobsT, n_samples, lambda_0, min_covar=1e-3):
+    def __init__(self, tree, post, obs, obsobsT, n_samples, lambda_0, min_covar=1e-3, native=True):
+        self.native = NativeTree(tree) if native else None
+        self._nbuf = None
         self.t = tree
         self.post = float(post)
         self.obs = np.asarray(obs, dtype=np.float64)
@@ -74,6 +121,37 @@ class OUObjective(object):
         return self.value_and_grad(p, want_grad=False)[0]
 
     def value_and_grad(self, p, want_grad=True):
+        if self.native is not None:
+            out = self._native_value_and_grad(p, want_grad)
+            if out is not None:
+                return out
+        return self._numpy_value_and_grad(p, want_grad)
+
+    def _native_value_and_grad(self, p, want_grad):
+        """libphmrf_host.so; None when V stays ill-conditioned (the NumPy path then takes the pseudo-inverse)."""
+        nb = self._nbuf
+        if nb is None:                      # buffers and pointers once per objective: the call itself is ~5 us
+            t = self.t
+            S = t.n_features
+            dp = ctypes.POINTER(ctypes.c_double)
+            nb = self._nbuf = {
+                "fn": host_lib().phmrf_ou_objective, "tab": ctypes.byref(self.native.tables),
+                "p": np.zeros(t.n_params), "g": np.zeros(t.n_params), "V": np.zeros((S, S)), "mu": np.zeros(S),
+                "obs": np.ascontiguousarray(self.obs), "oo": np.ascontiguousarray(self.oo), "f": ctypes.c_double(0.0)}
+            for k in ("p", "g", "V", "mu", "obs", "oo"):
+                nb[k + "_ptr"] = nb[k].ctypes.data_as(dp)
+            nb["f_ref"] = ctypes.byref(nb["f"])
+        nb["p"][:] = p
+        st = nb["fn"](nb["tab"], nb["p_ptr"], self.post, nb["obs_ptr"], nb["oo_ptr"], self.n, self.reg, self.min_covar,
+                      nb["f_ref"], nb["g_ptr"] if want_grad else None, nb["V_ptr"], nb["mu_ptr"])
+        if st == 2:
+            return None
+        if st != 0:
+            raise RuntimeError("phmrf_ou_objective failed with status %d" % st)
+        self.last_V, self.last_mean = nb["V"].copy(), nb["mu"].copy()
+        return nb["f"].value, (nb["g"].copy() if want_grad else None)
+
+    def _numpy_value_and_grad(self, p, want_grad=True):
         t = self.t
         p = np.asarray(p, dtype=np.float64)
         S = t.n_features

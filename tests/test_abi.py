@@ -78,3 +78,17 @@ def test_emission_pack_is_host_only_and_matches_oracle():
     bad = cov.copy()
     bad[1] = -np.eye(S)
     assert L.phmrf_emission_pack(S, K, _lib.ptr_d(mu), _lib.ptr_d(bad), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) == 6
+
+
+HOST_HEADER = os.path.join(ROOT, "include", "phmrf_host.h")
+HOST_LIB = os.path.join(ROOT, "phylo_hmrf_amd", "libphmrf_host.so")
+
+
+@pytest.mark.skipif(not os.path.exists(HOST_LIB), reason="libphmrf_host.so not built (run __graft_entry__.build())")
+def test_host_library_exports_every_declared_symbol():
+    syms = sorted(set(re.findall(r"PHMRF_HOST_API\s+[\w\s\*]+?\b(phmrf_\w+)\s*\(", open(HOST_HEADER).read())))
+    assert syms == ["phmrf_host_version", "phmrf_ou_objective"]
+    L = ctypes.CDLL(HOST_LIB)
+    assert not [s for s in syms if not hasattr(L, s)]
+    L.phmrf_host_version.restype = ctypes.c_int
+    assert L.phmrf_host_version() >= 1

@@ -87,3 +87,38 @@ def test_do_mstep_improves_the_objective_and_respects_the_box():
     p2, _, _, lik2 = mstep.do_mstep(t, stats, cur, cur, 5000, 1.0, 1, 0.3, 0.1, 1.0, np.random.default_rng(1), workers=2)
     assert np.all(np.isfinite(lik2)) and p2.shape == cur.shape
     mstep.close_pool()
+
+
+@pytest.mark.parametrize("tag", ["t4", "t8"])
+def test_native_objective_matches_numpy(tag):
+    """libphmrf_host.so (include/phmrf_host.h) against the NumPy objective it restates: value, gradient, V, mu."""
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "mstep_objective.npz"))
+    t = PhyloTree(g1[tag + "_edge_list"])
+    rng = np.random.default_rng(7)
+    for c in range(g[tag + "_post"].shape[0]):
+        args = (t, g[tag + "_post"][c], g[tag + "_obs"][c], g[tag + "_obsobsT"][c], 5000, 1.0)
+        nat, ref = mstep.OUObjective(*args), mstep.OUObjective(*args, native=False)
+        pts = list(g[tag + "_params"]) + [rng.uniform(1e-3, 3.0, t.n_params) for _ in range(20)]
+        pts.append(np.full(t.n_params, 1e-16))            # lower corner of the box: beta <= 1e-7 branch
+        for p in pts:
+            f1, g1_ = nat.value_and_grad(p)
+            f0, g0 = ref.value_and_grad(p)
+            np.testing.assert_allclose(f1, f0, rtol=1e-11, atol=1e-13)
+            np.testing.assert_allclose(g1_, g0, rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(nat.last_V, ref.last_V, rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(nat.last_mean, ref.last_mean, rtol=1e-13, atol=1e-15)
+
+
+def test_native_objective_hands_ill_conditioned_cases_to_numpy():
+    """V singular even after 10 x min_covar (min_covar = 0 here): status 2 -> the pseudo-inverse branch runs in NumPy."""
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "mstep_objective.npz"))
+    t = PhyloTree(g1["t4_edge_list"])
+    args = (t, g["t4_post"][0], g["t4_obs"][0], g["t4_obsobsT"][0], 5000, 1.0)
+    nat, ref = mstep.OUObjective(*args, min_covar=0.0), mstep.OUObjective(*args, min_covar=0.0, native=False)
+    p = np.full(t.n_params, 1e-16)                        # every variance 0 -> V = 0
+    assert nat._native_value_and_grad(p, True) is None
+    f1, _ = nat.value_and_grad(p, want_grad=False)
+    f0, _ = ref.value_and_grad(p, want_grad=False)
+    assert np.isfinite(f0) and f1 == f0
