@@ -238,13 +238,26 @@ __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, co
     const int l = labels[i];
     const int32_t* nb = nbr + i * D;
     bool linked = false;
-    int last = -1;
+    int last = -1, n_above = 0;
     for (int j = 0; j < D; ++j) {
       const int c = nb[j];
       if (c >= 0 && c == (int)i - 1) linked = labels[c] == l;
-      if (c >= 0 && c < (int)i - 1) last = j;      // rows are ascending: the largest smaller neighbour below i-1
+      if (c >= 0 && c < (int)i - 1) {              // rows are ascending: the largest smaller neighbour below i-1
+        last = j;
+        ++n_above;
+      }
     }
     const bool only_last = grid && linked;
+    if (only_last && grid == 8) {
+      // 8-neighbour stencil: `last` is my up-right cell when the entry before it is its left neighbour (my up cell),
+      // otherwise it IS my up cell (no up-right at the right border).  My up cell is also the up-right cell of my left
+      // run-mate: if it carries the label, the mate (or, by induction, an earlier cell of the run) already joins the
+      // run to that upper run, and my up-right cell then belongs to the same upper run.  So a linked cell only has
+      // to act where an upper run STARTS at its up-right cell.
+      // (a linked cell always has its up-left and up cells above it; a third one is the up-right cell)
+      if (n_above < 3) continue;
+      if (labels[nb[last - 1]] == l) continue;
+    }
     int ri = -1;
     for (int j = only_last ? (last < 0 ? D : last) : 0; j < D; ++j) {
       const int c = nb[j];
@@ -479,7 +492,7 @@ int launch_component_pass(phmrf_block* b, float beta) {
   hipStream_t st = b->stream;
   const int g = grid1d(n);
   hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels);
-  hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? 1 : 0);
+  hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0);
   hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n);
   PHMRF_HIP(hipMemsetAsync(b->comp_tab, 0, (size_t)n * K * sizeof(float), st));
   PHMRF_HIP(hipMemsetAsync(b->comp_move, 0, (size_t)n, st));
