@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--block-threads", type=int, default=8,
+                    help="host threads driving blocks concurrently, each block on its own HIP stream (1 = sequential)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not record HIP events around the kernel launches (no per-kernel breakdown / roofline)")
     ap.add_argument("--cpu-sample", type=int, default=360, help="side N of the diagonal block used for the CPU baseline")
@@ -145,15 +147,24 @@ def main():
     n_global = n_total * world
     t_e, t_m = [], []
 
+    # The blocks are independent (the reference forks one process per block, base.py:357-362): a few host threads
+    # drive them concurrently, each block on its own HIP stream, largest first, so the latency-bound launches of the
+    # small blocks fill the GPU next to the large ones.  ctypes drops the GIL for the duration of a library call.
+    from phylo_hmrf_amd.concurrent import BlockRunner
+    runner = BlockRunner(a.block_threads, local_rank)
+    order = sorted(range(len(blocks)), key=lambda i: -blocks[i].n)
+
+    def estep_block(i):
+        b = blocks[i]
+        b.restore_labels(SLOT_LOCAL)                           # init_labels = labels_local (phylo_hmrf.py:479)
+        b.emission(state["means"], state["covars"])
+        b.solve_fast(a.beta, **solver)
+        b.posterior_stats_dev(a.beta, 3, stats_dev[i].data_ptr())
+        b.sync()
+
     def em_step():
         t0 = time.time()
-        for i, b in enumerate(blocks):
-            b.restore_labels(SLOT_LOCAL)                       # init_labels = labels_local (phylo_hmrf.py:479)
-            b.emission(state["means"], state["covars"])
-            b.solve_fast(a.beta, **solver)
-            b.posterior_stats_dev(a.beta, 3, stats_dev[i].data_ptr())
-        for b in blocks:
-            b.sync()
+        runner.map(estep_block, order)
         tot = stats_dev.sum(dim=0)
         if use_dist:
             dist.all_reduce(tot)                               # RCCL: K(1+S+S^2)+4 doubles
@@ -207,26 +218,43 @@ def main():
         elapsed = float(t.item())
 
     # ---- per-kernel-class device time (HIP events recorded on the blocks' streams during the timed region) ----
-    agg = {}
-    for b in blocks:
-        for name, (ms, ln) in b.timing().items():
-            d = agg.setdefault(name, [0.0, 0, 0.0])
-            d[0] += ms
-            d[1] += ln
-            kb = kernel_bytes(name, b.n, K, S)
-            if kb is not None:
-                d[2] += kb * ln
-    dom = max(agg.items(), key=lambda kv: kv[1][0])
-    dom_name, (dom_ms, dom_launches, dom_bytes) = dom
-    roofline = None
-    if dom_launches and dom_ms > 0 and dom_bytes > 0:
+    def collect():
+        agg = {}
+        for b in blocks:
+            for name, (ms, ln) in b.timing().items():
+                d = agg.setdefault(name, [0.0, 0, 0.0])
+                d[0] += ms
+                d[1] += ln
+                kb = kernel_bytes(name, b.n, K, S)
+                if kb is not None:
+                    d[2] += kb * ln
+        return agg
+
+    def roofline_of(agg, dom_name):
+        dom_ms, dom_launches, dom_bytes = agg[dom_name]
+        if not (dom_launches and dom_ms > 0 and dom_bytes > 0):
+            return None
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a.workload, dom_name),
-                    "avg_launch_us": round(dom_ms * 1e3 / dom_launches, 2), "launches": int(dom_launches),
-                    "algorithmic_bytes_per_launch": int(dom_bytes / dom_launches)}
+        return {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a.workload, dom_name),
+                "avg_launch_us": round(dom_ms * 1e3 / dom_launches, 2), "launches": int(dom_launches),
+                "algorithmic_bytes_per_launch": int(dom_bytes / dom_launches)}
+
+    agg = collect()
+    dom_name = max(agg.items(), key=lambda kv: kv[1][0])[0]
+    roofline = roofline_of(agg, dom_name)
     kernels = {k: {"ms": round(v[0], 3), "launches": int(v[1]),
                    "GBps": (round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[2] > 0 else None)} for k, v in agg.items()}
+    # With several blocks in flight the event intervals above contain the kernels of OTHER streams sharing the GPU:
+    # they are what the timed region saw, but not a kernel's own duration.  One extra E-step, blocks one after the
+    # other, gives the uncontended figure of the same kernel (outside the timed region, not part of `value`).
+    roofline_isolated = None
+    if roofline is not None and runner.n_threads > 1 and len(blocks) > 1 and not a.no_kernel_timing:
+        for b in blocks:
+            b.reset_timing()
+        for i in order:
+            estep_block(i)
+        roofline_isolated = roofline_of(collect(), dom_name)
 
     if rank == 0:
         value = n_global * a.steps / elapsed
@@ -240,10 +268,12 @@ def main():
                        "mrf_solver": solver},
             "estep_ms": float(np.mean(t_e) * 1e3), "mstep_ms": float(np.mean(t_m) * 1e3),
             "value_estep_only": n_global * a.steps / float(np.sum(t_e)),
-            "setup_s": setup_s, "kernels": kernels, "roofline": roofline,
+            "setup_s": setup_s, "block_threads": runner.n_threads, "kernels": kernels, "roofline": roofline,
+            "roofline_isolated": roofline_isolated,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, S, K, nn)
+    runner.close()
     for b in blocks:
         b.close()
     mstep.close_pool()

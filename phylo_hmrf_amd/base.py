@@ -115,8 +115,10 @@ class _BaseGraph(object):
             start = time.time()
             # E-step of the regions this rank owns; un-normalised cost sums travel with the statistics
             local = np.zeros(K * (1 + S + S * S) + 5)
-            for region_id in self.my_regions:
-                st, costs = self._estep_region(region_id)
+            by_size = sorted(self.my_regions, key=lambda r: -int(len_vec[r][0]))          # largest block first
+            done = dict(zip(by_size, self.runner.map(self._estep_region, by_size)))       # concurrent streams
+            for region_id in self.my_regions:                                             # fixed summation order
+                st, costs = done[region_id]
                 local[:-5] += pack_stats(st)
                 local[-5:-1] += costs
                 local[-1] += int(len_vec[region_id][0])

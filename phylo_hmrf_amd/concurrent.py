@@ -1,0 +1,35 @@
+"""Concurrent E-step over independent blocks.
+
+The reference runs the E-step of every syntenic block in its own forked process (base.py:357-362).  Here every block
+owns a HIP stream (`phmrf_block_create`), and a small pool of host threads drives several blocks at once: the library
+calls release the GIL (ctypes), the per-round host synchronisations of one solve overlap with the kernels of the
+others, and the launch-latency-bound kernels of small blocks run next to those of large ones.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+
+class BlockRunner(object):
+    def __init__(self, n_threads, device=None):
+        """device: HIP device the worker threads select (None: leave it alone -- CPU test doubles)."""
+        self.n_threads = max(1, int(n_threads))
+        self.device = None if device is None else int(device)
+        self._pool = None
+        if self.n_threads > 1:
+            self._pool = ThreadPoolExecutor(max_workers=self.n_threads, initializer=self._init_thread)
+
+    def _init_thread(self):
+        if self.device is None:
+            return
+        from . import _lib
+        _lib.check(_lib.load().phmrf_set_device(self.device))      # the current device is per host thread
+
+    def map(self, fn, items):
+        """fn(item) for every item (in order of submission when sequential); exceptions propagate."""
+        if self._pool is None:
+            return [fn(it) for it in items]
+        return list(self._pool.map(fn, items))
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None

@@ -31,7 +31,7 @@ class phyloHMRF(_BaseGraph):
                  means_prior=0, means_weight=0, covars_prior=1e-2, covars_weight=1, algorithm="viterbi",
                  random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
                  learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
-                 solver_opts=None, mstep_workers=None, quiet=False, device_graph=False):
+                 solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=8):
         _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
                             startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
                             random_state=random_state, n_iter=n_iter, tol=tol, params=params, verbose=verbose,
@@ -83,6 +83,20 @@ class phyloHMRF(_BaseGraph):
         sizes = [lv[0] for lv in self.len_vec]
         self.owner = lpt_assign(sizes, self.world)
         self.my_regions = [r for r in range(len(self.len_vec)) if self.owner[r] == self.rank]
+
+        # one process per GPU: this rank's device is LOCAL_RANK (blocks, their streams and the worker threads use it)
+        device = None
+        if block_factory is None:
+            from . import _lib
+            _, _, device = env_rank_world()
+            _lib.require_gpu()
+            _lib.check(_lib.load().phmrf_set_device(device))
+            if self.world > 1:
+                import torch
+                torch.cuda.set_device(device)
+        # independent blocks run concurrently, each on its own stream (the reference: one process per block, base.py:357)
+        from .concurrent import BlockRunner
+        self.runner = BlockRunner(min(int(block_threads), max(1, len(self.my_regions))), device)
 
         # device-resident blocks (the reference's _edge_weight_undirected_vec, :567-598, happens here once)
         factory = block_factory or Block
@@ -272,6 +286,7 @@ class phyloHMRF(_BaseGraph):
         self._covars_ = packed[K * P + K * S:].reshape(K, S, S).copy()
 
     def close(self):
+        self.runner.close()
         for b in self.blocks.values():
             b.close()
         self.blocks = {}
