@@ -99,7 +99,7 @@ void free_family(ChainFamily& f) {
     for (int c = 0; c < 3; ++c) {
       dev_free(f.seg_start[p][c]);
       dev_free(f.seg_len[p][c]);
-      dev_free(f.memo[p][c]);
+      f.memo[p][c] = nullptr;          // slices of phmrf_block::chain_memo
     }
 }
 
@@ -358,6 +358,7 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->alpha_mask);
   dev_free(b->stamp);
   dev_free(b->memo);
+  dev_free(b->chain_memo);
   dev_free(b->strip_newest);
   dev_free(b->strip_mask);
   dev_free(b->work_list);
@@ -888,14 +889,25 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   b->tick = 1;
   b->mask_tick = -1;
   b->prop_tick = -1;
-  if (chains)
+  if (chains) {                       // segment memos of all families: one buffer, one memset
+    size_t total = 0;
     for (auto& f : b->families)
       for (int p = 0; p < 2; ++p)
-        for (int c = 0; c < f.n_colours; ++c)
-          if (f.nseg[p][c] > 0) {
-            if (!f.memo[p][c]) PHMRF_TRY(dev_alloc(&f.memo[p][c], (size_t)f.nseg[p][c]));
-            PHMRF_HIP(hipMemsetAsync(f.memo[p][c], 0, (size_t)f.nseg[p][c] * sizeof(uint16_t), b->stream));
-          }
+        for (int c = 0; c < f.n_colours; ++c) total += (size_t)f.nseg[p][c];
+    if (!b->chain_memo || b->chain_memo_count != total) {
+      dev_free(b->chain_memo);
+      PHMRF_TRY(dev_alloc(&b->chain_memo, total));
+      b->chain_memo_count = total;
+    }
+    size_t off = 0;
+    for (auto& f : b->families)
+      for (int p = 0; p < 2; ++p)
+        for (int c = 0; c < f.n_colours; ++c) {
+          f.memo[p][c] = f.nseg[p][c] > 0 ? b->chain_memo + off : nullptr;
+          off += (size_t)f.nseg[p][c];
+        }
+    PHMRF_HIP(hipMemsetAsync(b->chain_memo, 0, (total ? total : 1) * sizeof(uint16_t), b->stream));
+  }
   if (expansions) {
     int64_t max_strips = 0;
     for (int orient = 0; orient < 2; ++orient) {

@@ -45,6 +45,7 @@ struct ChainFamily {
   int32_t* seg_start[2][3] = {};       // device [nseg]: position in `nodes` of the segment's first node
   int32_t* seg_len[2][3] = {};         // device [nseg]: 1..63
   uint16_t* memo[2][3] = {};           // device [nseg]: tick of the segment's last quiet run (0 = none), per solve
+                                       //   (slices of phmrf_block::chain_memo, set up by phmrf_mrf_solve)
   int nseg[2][3] = {};
   int n_chains = 0;
   int n_colours = 0;
@@ -110,6 +111,8 @@ struct phmrf_block {
   // A strip whose cells and border have no stamp newer than its memo would see identical inputs: skipped.
   uint16_t* stamp = nullptr;                // device [n]
   uint16_t* memo = nullptr;                 // device [2][3][memo_strips][K+1]  (slot K: the fusion pass)
+  uint16_t* chain_memo = nullptr;           // device: the chain families' segment memos (ChainFamily::memo slices)
+  size_t chain_memo_count = 0;
   uint16_t* strip_newest = nullptr;         // device [memo_strips]: newest stamp among a strip's cells (current cut)
   int64_t memo_strips = 0;
   int tick = 0;                             // host launch counter inside one solve (0 = stamping off)

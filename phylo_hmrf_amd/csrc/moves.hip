@@ -279,7 +279,10 @@ __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, co
   }
 }
 
-__global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n) {
+// flatten, and clear what the table / decide / block kernels accumulate into: only the ROOT rows of the move table are
+// ever used, so only those are zeroed (instead of a memset of n*K floats per pass)
+__global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n, float* __restrict__ tab, int K,
+                                  uint8_t* __restrict__ move) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int c = comp[i];
     int p = comp[c];
@@ -288,6 +291,11 @@ __global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n) {
       p = comp[c];
     }
     comp[i] = c;
+    move[i] = 0;
+    if (c == (int)i) {
+      float* row = tab + i * K;
+      for (int k = 0; k < K; ++k) row[k] = 0.f;
+    }
   }
 }
 
@@ -493,9 +501,7 @@ int launch_component_pass(phmrf_block* b, float beta) {
   const int g = grid1d(n);
   hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels);
   hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0);
-  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n);
-  PHMRF_HIP(hipMemsetAsync(b->comp_tab, 0, (size_t)n * K * sizeof(float), st));
-  PHMRF_HIP(hipMemsetAsync(b->comp_move, 0, (size_t)n, st));
+  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move);
   {
     const int TB = tile_threads(K);
     const size_t lds = (size_t)TB * Kp * sizeof(float) + (size_t)TB * sizeof(int32_t);
