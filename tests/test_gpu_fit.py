@@ -72,3 +72,37 @@ def test_fit_surface_and_predict_shapes():
     with pytest.raises(ValueError):
         cut_general_graph(eid, w, -logprob, np.arange(16.0).reshape(4, 4))
     m.close()
+
+
+def test_blocks_in_flight_give_the_sequential_result():
+    """Three independent blocks: the E-steps driven concurrently (one HIP stream per block, host thread pool) must
+    produce the statistics, costs and labels of the one-block-at-a-time run."""
+    import phylo_hmrf as cli
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    Xs, lens, edges, tree, off = [], [], [], None, 0
+    for N, seed in ((40, 1), (57, 2), (33, 3)):
+        X, lv, ev, tree = cli.synthetic_cache(N, 4, 4, 8, seed)
+        n = X.shape[0]
+        row = list(lv[0])
+        row[1], row[2] = off, off + n
+        Xs.append(X)
+        lens.append(row)
+        edges.append(ev[0])
+        off += n
+    X = np.concatenate(Xs)
+
+    def fit(threads):
+        m = phyloHMRF(n_components=4, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree,
+                      len_vec=lens, type_id=1, branch_list=[1.0] * 7, edge_list_1=edges, cons_param=1.0, beta=1.0,
+                      beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0,
+                      learning_rate=0.001, estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, random_state=5,
+                      quiet=True, mstep_workers=1, block_threads=threads)
+        res = m.fit_accumulate_test(X, lens, 1e-3, "t", 4)
+        m.close()
+        return res
+
+    a, b = fit(1), fit(3)
+    # (not bit-for-bit by contract: the component move table is summed with float atomics in either mode)
+    np.testing.assert_allclose(a[5], b[5], rtol=1e-6)     # cost_vec: every iteration's costs
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-4, atol=1e-6)
+    assert np.mean(a[6] == b[6]) > 0.999                  # labels
