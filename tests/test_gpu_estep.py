@@ -312,7 +312,8 @@ def test_energy_parity_with_reference_gco_golden(tag, H, W, diagonal):
 
 
 @pytest.mark.parametrize("tol_ppb", [0, 1000])
-@pytest.mark.parametrize("seed,N,K,diagonal,perturb", [(0, 150, 10, False, 0.0), (1, 160, 20, True, 0.0), (3, 120, 20, False, 0.3)])
+@pytest.mark.parametrize("seed,N,K,diagonal,perturb", [(0, 150, 10, False, 0.0), (1, 160, 20, True, 0.0), (3, 120, 20, False, 0.3),
+                                                       (5, 220, 20, True, 0.15), (7, 140, 30, False, 0.1)])
 def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, perturb, tol_ppb):
     """Same claim on larger seeded synthetic Hi-C blocks, gco run live (oracle/_ref travels with the repo)."""
     from oracle import gco_ref
