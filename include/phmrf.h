@@ -164,6 +164,15 @@ PHMRF_API int phmrf_posterior_stats(phmrf_block_t b, double beta, int estimate_t
  * all-reduce on the caller's stream; no host synchronisation. */
 PHMRF_API int phmrf_posterior_stats_dev(phmrf_block_t b, double beta, int estimate_type, double* out_dev);
 
+/* ---- initialisation --------------------------------------------------------- */
+/* One Lloyd step of k-means on the block's device-resident observations.  The reference initialises the states
+ * with sklearn's MiniBatchKMeans on the host (phylo_hmrf.py:234-238); this keeps X where it is.  Every node goes to
+ * its nearest centre (squared Euclidean distance, lowest index on ties).
+ *   out[0 .. K*S)        per-cluster sums of x        out[K*S .. K*S+K)  cluster sizes        out[K*S+K]  inertia
+ * write_labels != 0: the assignment becomes the block's labels (the reference's init_label, :241-244).            */
+PHMRF_API int phmrf_kmeans_step(phmrf_block_t b, const double* centers /* [K,S] */, int write_labels,
+                                double* out /* [K*S + K + 1] */);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
  * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip, 7 propose. */

@@ -347,3 +347,17 @@ def grid_edges(X, H, W, diagonal, num_neighbor=8):
     e = np.concatenate(out, axis=0)
     order = np.lexsort((e[:, 1], e[:, 0]))
     return e[order]
+
+
+def kmeans_step(X, centers):
+    """One Lloyd step (model of csrc/init.hip; the reference's own initialiser is sklearn MiniBatchKMeans,
+    phylo_hmrf.py:234-238, third-party and unpinned): nearest centre by squared Euclidean distance, lowest index on
+    ties -> (labels[n], sums[K,S], counts[K], inertia)."""
+    X = np.asarray(X, dtype=np.float64)
+    centers = np.asarray(centers, dtype=np.float64)
+    d2 = ((X[:, None, :] - centers[None, :, :]) ** 2).sum(axis=2)
+    lab = np.argmin(d2, axis=1)
+    K = centers.shape[0]
+    sums = np.zeros_like(centers)
+    np.add.at(sums, lab, X)
+    return lab, sums, np.bincount(lab, minlength=K).astype(np.float64), float(d2[np.arange(X.shape[0]), lab].sum())

@@ -67,6 +67,8 @@ def parse_args(argv=None):
                                                         "write it in the reference's cache format")
     parser.add_option("--seed", default="", help="random seed (default: non-deterministic like the reference)")
     parser.add_option("--quiet", default="0", help="1: suppress the per-iteration prints")
+    parser.add_option("--init", default="sklearn", help="initial clustering: 'sklearn' = MiniBatchKMeans on the host as in "
+                      "the reference (phylo_hmrf.py:234-238); 'device' = k-means on the GPU (whole-genome inputs)")
     parser.add_option("-h", "--help", action="help")
     opts, _ = parser.parse_args(argv)
     return opts
@@ -121,7 +123,8 @@ def synthetic_cache(N, S, K, num_neighbor, seed):
 def run(num_states, chromvec, root_path, multiple, species_name, sort_states, run_id1, cons_param, method_mode,
         initial_mode, initial_weight, initial_weight1, initial_magnitude, position1, position2, filter_sigma, beta,
         beta1, num_neighbor, filter_mode, conv_threshold, estimate_type, simu_version, annotation, reload_mode,
-        diagonal_type, m_iter, resolution, quantile, ref_species, output_path, synthetic="0", seed="", quiet="0"):
+        diagonal_type, m_iter, resolution, quantile, ref_species, output_path, synthetic="0", seed="", quiet="0",
+        init_method="sklearn"):
     run_id = int(run_id1)
     n_components1 = int(num_states)
     cons_param = float(cons_param)
@@ -175,7 +178,7 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
                           beta=beta, beta1=beta1, initial_mode=initial_mode, initial_weight=initial_weight,
                           initial_weight1=initial_weight1, initial_magnitude=initial_magnitude, learning_rate=0.001,
                           estimate_type=estimate_type, max_iter=100, n_iter=5000, tol=1e-7, num_neighbor=num_neighbor,
-                          random_state=seed, quiet=bool(int(quiet)))
+                          random_state=seed, quiet=bool(int(quiet)), init_method=init_method)
         print("fitting...")
         lambda_0 = cons_param
         filename = "%s/estimate_ou_%d_%.2f_%d_%s" % (output_path, run_id, lambda_0, n_components1, annotation)
@@ -202,4 +205,4 @@ if __name__ == "__main__":
         opts.initial_magnitude, opts.position1, opts.position2, opts.filter_sigma, opts.beta, opts.beta1,
         opts.num_neighbor, opts.filter_mode, opts.threshold, opts.estimate_type, opts.simu_version, opts.annotation,
         opts.reload, opts.dtype, opts.miter, opts.resolution, opts.quantile, opts.ref_species, opts.output,
-        synthetic=opts.synthetic, seed=opts.seed, quiet=opts.quiet)
+        synthetic=opts.synthetic, seed=opts.seed, quiet=opts.quiet, init_method=opts.init)

@@ -166,6 +166,16 @@ class Block(object):
     def posterior_stats_dev(self, beta, estimate_type, out_dev_ptr):
         check(self._L.phmrf_posterior_stats_dev(self._h, float(beta), int(estimate_type), ctypes.c_void_p(out_dev_ptr)))
 
+    # -- initialisation ---------------------------------------------------------------------------
+    def kmeans_step(self, centers, write_labels=False):
+        """One Lloyd step on the device: -> (sums[K,S], counts[K], inertia)."""
+        c = as_f64(centers)
+        assert c.shape == (self.K, self.S)
+        out = np.zeros(self.K * self.S + self.K + 1)
+        check(self._L.phmrf_kmeans_step(self._h, ptr_d(c), int(bool(write_labels)), ptr_d(out)))
+        KS = self.K * self.S
+        return out[:KS].reshape(self.K, self.S), out[KS:KS + self.K], float(out[KS + self.K])
+
     # -- timing -----------------------------------------------------------------------------------
     def enable_timing(self, on=True):
         check(self._L.phmrf_block_enable_timing(self._h, int(on)))

@@ -161,6 +161,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
                       int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
 int launch_alpha_mask(phmrf_block* b, float beta);
 int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int geom);   // -> strip_newest, strip_mask
+int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev);
 int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
 

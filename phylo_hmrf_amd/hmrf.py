@@ -31,7 +31,8 @@ class phyloHMRF(_BaseGraph):
                  means_prior=0, means_weight=0, covars_prior=1e-2, covars_weight=1, algorithm="viterbi",
                  random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
                  learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
-                 solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=8):
+                 solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=8,
+                 init_method="sklearn"):
         _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
                             startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
                             random_state=random_state, n_iter=n_iter, tol=tol, params=params, verbose=verbose,
@@ -58,6 +59,9 @@ class phyloHMRF(_BaseGraph):
         if solver_opts:
             self.solver_opts.update(solver_opts)
         self.mstep_workers = mstep_workers
+        if init_method not in ("sklearn", "device"):
+            raise ValueError("init_method must be 'sklearn' (the reference's MiniBatchKMeans) or 'device'")
+        self.init_method = init_method
 
         # species tree tables (phylo_hmrf.py:103-143)
         self.tree = PhyloTree(edge_list)
@@ -156,15 +160,26 @@ class phyloHMRF(_BaseGraph):
     # ---- initialisation (phylo_hmrf.py:205-264) --------------------------------------------------
     def _init(self, X, lengths=None):
         super(phyloHMRF, self)._init(X, lengths=lengths)
-        from sklearn import cluster
         X = np.asarray(X)
         n_samples, n_features = X.shape
         seed = None if self.random_state is None else int(self.random_state)
-        kmeans = cluster.MiniBatchKMeans(n_clusters=self.n_components, random_state=seed, batch_size=2000,
-                                         max_iter=1000, n_init=10)              # :234-236
-        kmeans.fit(X)
-        self.means_ = kmeans.cluster_centers_
-        init_label = kmeans.labels_
+        if self.init_method == "device":
+            # k-means on the GPU where X already lives (kmeans.py); every rank draws the same host sample for seeding
+            from .kmeans import device_kmeans
+            srng = np.random.default_rng(seed)
+            rows = srng.choice(n_samples, size=min(n_samples, 50000), replace=False)
+            centers, _ = device_kmeans([self.blocks[r] for r in self.my_regions], X[np.sort(rows)], self.n_components,
+                                       srng, reducer=self.reducer if self.world > 1 else None)
+            self.means_ = centers
+            self._snapshot_labels(SLOT_LOCAL)
+            init_label = np.int64(self._gather_labels(SLOT_LOCAL))
+        else:
+            from sklearn import cluster
+            kmeans = cluster.MiniBatchKMeans(n_clusters=self.n_components, random_state=seed, batch_size=2000,
+                                             max_iter=1000, n_init=10)          # :234-236
+            kmeans.fit(X)
+            self.means_ = kmeans.cluster_centers_
+            init_label = kmeans.labels_
         self._log("initialize parameters...")
         self.init_ou_params = _mstep.init_ou_params(self.tree, X, init_label, self.means_, self.params_vec1,
                                                     self.initial_w2, self.rng, workers=self.mstep_workers)   # :246

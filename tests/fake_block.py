@@ -35,6 +35,13 @@ class FakeBlock(object):
     def set_labels(self, labels):
         self.labels = np.asarray(labels).astype(np.int64)
 
+    def kmeans_step(self, centers, write_labels=False):
+        from oracle import ref_numpy as R
+        lab, sums, counts, inertia = R.kmeans_step(self.X, centers)
+        if write_labels:
+            self.labels = lab.astype(np.int64)
+        return sums, counts, inertia
+
     def get_labels(self):
         return self.labels.astype(np.int32)
 

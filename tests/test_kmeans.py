@@ -1,0 +1,92 @@
+"""k-means initialisation: the Lloyd driver on CPU test doubles, the device step against NumPy."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import ref_numpy as R
+from phylo_hmrf_amd import kmeans
+
+
+def _blobs(rng, K, S, n_per):
+    centers = rng.uniform(0, 10, (K, S))
+    X = np.concatenate([c + 0.15 * rng.standard_normal((n_per, S)) for c in centers])
+    lab = np.repeat(np.arange(K), n_per)
+    p = rng.permutation(X.shape[0])
+    return X[p], lab[p], centers
+
+
+def test_lloyd_driver_recovers_separated_blobs_over_several_blocks():
+    from fake_block import FakeBlock
+    rng = np.random.default_rng(0)
+    K, S = 6, 4
+    X, truth, centers = _blobs(rng, K, S, 400)
+    cuts = [0, 700, 1500, X.shape[0]]                        # three "blocks"
+    blocks = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        blk = FakeBlock(b - a, S, K)
+        blk.set_observations(X[a:b])
+        blocks.append(blk)
+    got, inertia = kmeans.device_kmeans(blocks, X[::3], K, np.random.default_rng(1))
+    # every true centre has a fitted centre within a few standard errors, and the partition equals the truth
+    d = np.sqrt(((centers[:, None, :] - got[None, :, :]) ** 2).sum(-1))
+    assert np.all(d.min(axis=1) < 0.05)
+    lab = np.concatenate([blk.get_labels() for blk in blocks])
+    perm = d.argmin(axis=1)                                   # truth k -> fitted index
+    assert np.array_equal(perm[truth], lab)
+    assert inertia == pytest.approx(R.kmeans_step(X, got)[3], rel=1e-9)
+
+
+def test_empty_clusters_are_reseeded():
+    from fake_block import FakeBlock
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((300, 2))
+    blk = FakeBlock(300, 2, 5)
+    blk.set_observations(X)
+    got, _ = kmeans.device_kmeans([blk], X, 5, np.random.default_rng(4), n_init=1)
+    assert np.all(np.isfinite(got)) and len(np.unique(blk.get_labels())) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,K,n", [(4, 20, 70001), (8, 30, 5000), (3, 7, 999), (1, 2, 5)])
+def test_device_step_matches_numpy(S, K, n):
+    from phylo_hmrf_amd import Block
+    rng = np.random.default_rng(S * 100 + K)
+    X = rng.uniform(0, 4, (n, S)).astype(np.float32).astype(np.float64)
+    C = rng.uniform(0, 4, (K, S)).astype(np.float32).astype(np.float64)
+    b = Block(n, S, K)
+    b.set_observations(X)
+    sums, counts, inertia = b.kmeans_step(C, write_labels=True)
+    lab = b.get_labels()
+    ref_lab, ref_sums, ref_counts, ref_inertia = R.kmeans_step(X, C)
+    # f32 distances: a node may go to another centre only when the two distances tie within rounding
+    d2 = ((X[:, None, :] - C[None, :, :]) ** 2).sum(axis=2)
+    diff = np.flatnonzero(lab != ref_lab)
+    assert np.all(np.abs(d2[diff, lab[diff]] - d2[diff, ref_lab[diff]]) <= 1e-5 * (1 + d2[diff, ref_lab[diff]]))
+    assert diff.size <= max(2, n // 2000)
+    if diff.size == 0:
+        assert np.array_equal(counts, ref_counts)
+        np.testing.assert_allclose(sums, ref_sums, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(inertia, ref_inertia, rtol=2e-5)
+    assert counts.sum() == n
+    b.close()
+
+
+@pytest.mark.gpu
+def test_fit_with_device_initialisation():
+    import phylo_hmrf as cli
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    X, len_vec, edge_list_vec, tree = cli.synthetic_cache(60, 4, 4, 8, 21)
+    n = X.shape[0]
+    m = phyloHMRF(n_components=4, run_id=0, n_samples=n, n_features=4, observation=X, edge_list=tree, len_vec=len_vec,
+                  type_id=1, branch_list=[1.0] * 7, edge_list_1=edge_list_vec, cons_param=1.0, beta=1.0, beta1=0.5,
+                  initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, learning_rate=0.001,
+                  estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, random_state=5, quiet=True, mstep_workers=1,
+                  init_method="device")
+    res = m.fit_accumulate_test(X, len_vec, 1e-3, "t", 3)
+    assert res[5].shape[1] == 4 and np.all(np.isfinite(res[5]))
+    assert len(np.unique(m.init_label)) == 4
+    m.close()
