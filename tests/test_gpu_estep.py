@@ -551,3 +551,41 @@ def test_full_size_cfg2_properties():
     np.testing.assert_allclose(costs[0], 2.0 * e_pw, rtol=1e-5)    # pairwise cost counts every edge from both ends
     np.testing.assert_allclose(costs[3], costs[1] + costs[2], rtol=1e-12)
     b.close()
+
+
+@pytest.mark.parametrize("H,W,K,diagonal", [(48, 48, 6, True), (20, 130, 4, False)])
+def test_four_neighbour_grid_moves_and_solver(H, W, K, diagonal):
+    """num_neighbor = 4 (the reference's other stencil, utility.py:1917-1920): the grid-native strip inputs carry zero
+    diagonal weights; strip passes equal the move model, every move is energy-non-increasing, the solver converges."""
+    rng = np.random.default_rng(H + W)
+    n = H * (H + 1) // 2 if diagonal else H * W
+    X = rng.uniform(0.5, 2, (n, 2))
+    e = R.grid_edges(X, H, W, diagonal, 4)
+    eid = np.int64(e[:, :2])
+    w = rng.integers(1, 9, len(eid)) / 8.0
+    un = rng.integers(0, 12, (n, K)).astype(np.float64) * 0.5
+    lp = -un
+    init = rng.integers(0, K, n)
+    g = M.Graph(n, eid, w)
+    b = _block(n, 2, K)
+    b.set_graph(eid, w)
+    b.set_grid(H, W, diagonal, 4)
+    b.set_logprob(lp)
+    b.set_labels(init)
+    lab = init.astype(np.int64).copy()
+    for orient, sr, sc, alpha in [(0, 0, 0, -1), (1, 2, 9, 1), (0, 4, 33, 0), (1, 1, 0, -1)]:
+        prop = M.best_alternative(g, -lp, lab, 1.0) if alpha < 0 else np.full(n, alpha)
+        ch_ref = M.strip_fusion(g, -lp, lab, prop, 1.0, H, W, diagonal, orient, sr, sc)
+        ch = b.strip_pass(1.0, orient, sr, sc, alpha)
+        got = b.get_labels().astype(np.int64)
+        assert np.array_equal(got, lab) and ch == ch_ref, (orient, alpha, int((got != lab).sum()))
+    prev = b.energy(1.0)[0]
+    for fam in range(2):
+        b.chain_sweep(1.0, fam)
+        en = b.energy(1.0)[0]
+        assert en <= prev + 1e-9
+        prev = en
+    res = b.solve(1.0)
+    assert res["converged"] and res["energy"] <= prev + 1e-9
+    assert abs(res["energy"] - M.energy(g, -lp, b.get_labels().astype(np.int64), 1.0)[0]) < 1e-6
+    b.close()
