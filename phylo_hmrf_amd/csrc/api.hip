@@ -1012,7 +1012,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     total += ch;
     ++rounds;
     const bool improved = e_now < e_prev - 1e-11 * std::fabs(e_prev);
-    if (getenv("PHMRF_SOLVE_TRACE")) {
+    static const bool trace = getenv("PHMRF_SOLVE_TRACE") != nullptr;   // development aid (one block at a time)
+    if (trace) {
       int n_active = 0;
       for (int sl : slots) n_active += active[sl];
       fprintf(stderr, "[phmrf solve] round %d active %d/%d changed %lld energy %.6f delta %.3e\n", r, n_active,
