@@ -964,7 +964,9 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         }
       toc(b, KC_CHAIN, n_chain);
     }
-    if (active[76]) {
+    // single-site ICM: every strip cell and every chain node is already optimal given the rest, so ICM only earns its
+    // launches on the fixed separator cells; it runs in verification rounds and on graphs without grid moves
+    if (active[76] && (verifying || !(chains || strips))) {
       b->counter_slot = 76;
       PHMRF_TRY(icm_sweep_nocount(b, bf));
     }
