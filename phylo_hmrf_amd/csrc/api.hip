@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <numeric>
 
 #include "common.h"
@@ -943,9 +944,9 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   // `min_changed` labels changed, or the energy did not go down) a VERIFICATION round with every type active (and the
   // chain segments cut at their other set of separators) decides: quiet again -> done.  (The energy test also ends the alternation between two labellings of exactly equal energy
   // that different move types prefer; gco stops on the same criterion, GCoptimization.cpp:1298.)
-  double e_prev_u = 0, e_prev_p = 0;
-  PHMRF_TRY(energy_now(b, beta, &e_prev_u, &e_prev_p));
-  double e_prev = e_prev_u + e_prev_p;
+  // the energy before the first round (only needed when the caller asked for it: the first round of a solve that
+  // changes labels always improves, and the tolerance refers to the energy after the round)
+  double e_prev = res ? eu0 + ep0 : std::numeric_limits<double>::infinity();
   while (rounds < o.max_rounds) {
     const int r = rounds;
     PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
@@ -1015,7 +1016,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     for (int sl : slots) ch += (int64_t)b->counters_host[sl];
     total += ch;
     ++rounds;
-    const bool improved = e_now < e_prev - 1e-11 * std::fabs(e_prev);
+    const bool improved = std::isinf(e_prev) ? ch > 0 : e_now < e_prev - 1e-11 * std::fabs(e_prev);
     static const bool trace = getenv("PHMRF_SOLVE_TRACE") != nullptr;   // development aid (one block at a time)
     if (trace) {
       int n_active = 0;
