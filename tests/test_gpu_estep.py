@@ -589,3 +589,33 @@ def test_four_neighbour_grid_moves_and_solver(H, W, K, diagonal):
     assert res["converged"] and res["energy"] <= prev + 1e-9
     assert abs(res["energy"] - M.energy(g, -lp, b.get_labels().astype(np.int64), 1.0)[0]) < 1e-6
     b.close()
+
+
+@pytest.mark.parametrize("H,W,diagonal,K,nn", [(1, 1, False, 3, 8), (2, 2, True, 2, 8), (3, 3, True, 1, 8), (1, 7, False, 4, 8),
+                                              (7, 1, False, 4, 8), (5, 5, True, 64, 8), (12, 70, False, 64, 8),
+                                              (6, 6, False, 40, 4), (64, 64, True, 2, 8), (65, 129, False, 3, 8)])
+def test_degenerate_sizes(H, W, diagonal, K, nn):
+    """A single node, one label, the maximum number of labels, one-row / one-column grids, strips narrower than a
+    segment: the solver converges, never raises the energy, and reports the energy of the labels it returns."""
+    rng = np.random.default_rng(H * 1000 + W + K)
+    n = H * (H + 1) // 2 if diagonal else H * W
+    X = rng.uniform(0.5, 2, (n, 2))
+    e = R.grid_edges(X, H, W, diagonal, nn)
+    eid = np.int64(e[:, :2]) if len(e) else np.zeros((0, 2), np.int64)
+    w = rng.integers(1, 9, len(eid)) / 8.0
+    b = _block(n, 2, K)
+    b.set_observations(X)
+    b.set_graph(eid, w)
+    b.set_grid(H, W, diagonal, nn)
+    lp = -rng.integers(0, 12, (n, K)).astype(np.float64) * 0.5
+    b.set_logprob(lp)
+    b.set_labels(rng.integers(0, K, n))
+    e0 = b.energy(1.0)[0]
+    res = b.solve(1.0)
+    lab = b.get_labels().astype(np.int64)
+    host = float((-lp)[np.arange(n), lab].sum())
+    if len(eid):
+        host = M.energy(M.Graph(n, eid, w), -lp, lab, 1.0)[0]
+    assert res["converged"] and res["energy"] <= e0 + 1e-9
+    assert abs(res["energy"] - host) <= 1e-6 * max(1.0, abs(host))
+    b.close()
