@@ -40,6 +40,9 @@ extern "C" {
 #define PHMRF_ERR_NOT_PD 6       /* a state covariance is not positive definite (sklearn raises
                                     ValueError at the same point)                                  */
 
+/* Threading: every block owns a HIP stream.  Calls on DIFFERENT blocks may be made concurrently from different host
+ * threads (each thread selects the device with phmrf_set_device first: the current device is per thread); calls on
+ * the SAME block must be serialised by the caller.  phmrf_last_error() is per thread. */
 typedef struct phmrf_block* phmrf_block_t;
 
 /* ---- library ---------------------------------------------------------------------------------- */
