@@ -55,26 +55,34 @@ __device__ __forceinline__ float wave_min_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// lane <-> lane ^ (1 << Q) exchange without LDS: DPP for 1,2,4,8; row / half swaps for 16, 32
+// State <-> lane.  The DP exchanges values between the two states that differ in ONE profile bit q.  DPP offers xor 1
+// and xor 2 (quad_perm), xor 7 (row_half_mirror) and xor 15 (row_mirror) as single moves, v_permlane16/32_swap give
+// xor 16 / xor 32 -- but not xor 4 or xor 8.  So the state is not the lane id: lane = s0*1 ^ s1*2 ^ s2*7 ^ s3*15 ^
+// s4*16 ^ s5*32 (an invertible GF(2) map), which makes "flip bit q" one of those six lane permutations for every q.
+__device__ __forceinline__ int state_of_lane(int lane) {
+  const int l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1;
+  return ((lane ^ l2) & 1) | ((((lane >> 1) ^ l2) & 1) << 1) | ((l2 ^ l3) << 2) | (lane & 0x38);
+}
+__device__ __forceinline__ int lane_of_state(int st) {
+  const int s2 = (st >> 2) & 1, s3 = (st >> 3) & 1;
+  const int l2 = s2 ^ s3;
+  return ((st ^ l2) & 1) | ((((st >> 1) ^ l2) & 1) << 1) | (l2 << 2) | (st & 0x38);
+}
+
+// value of the state that differs from mine in bit Q
 template <int Q>
 __device__ __forceinline__ float xor_exchange(float v) {
   const int iv = __builtin_bit_cast(int, v);
   // (old = 0 with bound_ctrl: every lane has a valid source, and the move can be folded into the consuming v_add)
-  if (Q == 0) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, true));   // [1,0,3,2]
-  if (Q == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, true));   // [2,3,0,1]
-  if (Q == 2) {  // xor 4 = half_mirror (xor 7) then quad reverse (xor 3)
-    const int a = __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xf, 0xf, true);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, a, 0x1B, 0xf, 0xf, true));               // [3,2,1,0]
-  }
-  if (Q == 3) {  // xor 8 = row_mirror (xor 15) then half_mirror (xor 7)
-    const int a = __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xf, 0xf, true);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, true));
-  }
-  if (Q == 4) {  // odd rows of vdst <-> even rows of vsrc
+  if (Q == 0) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, true));    // lane ^ 1
+  if (Q == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, true));    // lane ^ 2
+  if (Q == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xf, 0xf, true));   // lane ^ 7
+  if (Q == 3) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xf, 0xf, true));   // lane ^ 15
+  if (Q == 4) {  // lane ^ 16: odd rows of vdst <-> even rows of vsrc
     auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
     return __builtin_bit_cast(float, (int)((threadIdx.x & 16) ? r[0] : r[1]));
   }
-  auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);   // lanes 32..63 of vdst <-> lanes 0..31 of vsrc
+  auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);   // lane ^ 32
   return __builtin_bit_cast(float, (int)((threadIdx.x & 32) ? r[0] : r[1]));
 }
 
@@ -120,9 +128,9 @@ __device__ __forceinline__ void build_table(float* tab, int lane, float c0, floa
 // q+1, left-down = t-4 at q+2; the lane's table index (b, bu, bl, bld) is therefore a compile-time function of
 // (lane, q).  base / lu come from two LDS reads that do not depend on the DP state (issued one step ahead).
 template <int Q>
-__device__ __forceinline__ int tab_offset(int lane) {   // byte offsets of this lane's entries for position Q
+__device__ __forceinline__ int tab_offset(int st) {   // byte offsets of this state's entries for position Q
   constexpr int QU = (Q + 5) % 6, QL = (Q + 1) % 6, QLD = (Q + 2) % 6;
-  const int b = (lane >> Q) & 1, bu = (lane >> QU) & 1, bl = (lane >> QL) & 1, bld = (lane >> QLD) & 1;
+  const int b = (st >> Q) & 1, bu = (st >> QU) & 1, bl = (st >> QL) & 1, bld = (st >> QLD) & 1;
   return (b * 8 + bu * 4 + bl * 2 + bld) * 4;
 }
 
@@ -153,8 +161,9 @@ template <int P, int TT>
 __device__ __forceinline__ void dp_step_at(float& m, unsigned long long& took, int lane, const char* tabc) {
   constexpr int Q = (4 * P + TT) % 6;
   const char* rec = tabc + TT * (TAB * 4);
-  const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(lane));
-  const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((lane >> Q) & 1) * 8);
+  const int st = state_of_lane(lane);
+  const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(st));
+  const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((st >> Q) & 1) * 8);
   unsigned long long dec;
   dp_step<Q>(m, took, base, lu.x, lu.y, &dec);
 }
@@ -200,8 +209,8 @@ __device__ __forceinline__ void dp_pass(float& m, unsigned long long& took, int 
     if (J < 4 || tt < 64) {                                                                                          \
       constexpr int Q = (4 * P + J) % 6;                                                                             \
       const char* rec = tabc + tt * (TAB * 4);                                                                       \
-      const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(lane));                                 \
-      const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((lane >> Q) & 1) * 8);                          \
+      const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(state_of_lane(lane)));                  \
+      const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((state_of_lane(lane) >> Q) & 1) * 8);           \
       unsigned long long dec;                                                                                        \
       dp_step<Q>(m, took, base, lu.x, lu.y, &dec);                                                                   \
       if (RECORD) {                                                                                                  \
@@ -239,7 +248,7 @@ __device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, cons
       const unsigned long long dec = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, tt) << 32) | \
                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, tt);      \
       const int x = (s >> Q) & 1;                                                                                    \
-      const int d = x ^ (int)((dec >> s) & 1ull);     /* the ballot says "took the OTHER predecessor" */             \
+      const int d = x ^ (int)((dec >> lane_of_state(s)) & 1ull);     /* ballot: "took the OTHER predecessor" */      \
       s = (s & ~(1 << Q)) | (d << Q);                                                                                \
       write_lane(xsel, (unsigned int)x, tt);                                                                         \
     }                                                                                                                \
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     const int q_end = t_end % 6;
     int sidx = 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) sidx |= ((lane >> ((q_end - j + 6) % 6)) & 1) << j;
+    for (int j = 0; j < 6; ++j) sidx |= ((state_of_lane(lane) >> ((q_end - j + 6) % 6)) & 1) << j;
     const float mmin = wave_min_f32(m);
     // the all-keep path is optimal (see dp_step): nothing to backtrack or apply -- the case of ~997 strips in 1000
     if (!(took & 1ull) && PHMRF_RL(m, 0) == mmin) {
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     dp_pass<4, true>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
     const float cand = (m == mmin) ? (float)sidx : 127.f;
     const float best = wave_min_f32(cand);
-    int s = __ffsll((long long)__ballot(cand == best)) - 1;
+    int s = state_of_lane(__ffsll((long long)__ballot(cand == best)) - 1);
 
     // ---- backtrack on scalars; the choice of cell t lands in lane (t mod 64) of xsel[pass]
     unsigned int xsel[NPASS];
