@@ -87,38 +87,41 @@ __device__ __forceinline__ float xor_exchange(float v) {
 }
 
 // ---- per-cell cost tables (LDS, one pass of 64 cells at a time) ---------------------------------------------------
-// Cell record in LDS (20 floats = 80 B, conflict-free for ds_write_b128 at this stride):
-//   [0..15]  base[b][bu][bl][bld] = c_b + wu*N_u[b][bu] + wl*N_l[b][bl] + wld*N_ld[b][bld]
-//   [16..19] lu[b][self], lu[b][other] = wlu*N_lu[b][d]      (d = choice of the left-up cell leaving the profile:
-//                                                              "self" d == b, "other" d == 1 - b)
-constexpr int TAB = 20;
+// Cell record in LDS: for each of the 16 combinations (own bit b, up bu, left bl, left-down bld) the pair
+//   { cost + lu[b][self], cost + lu[b][other] },   cost = c_b + wu*N_u[b][bu] + wl*N_l[b][bl] + wld*N_ld[b][bld],
+//   lu[b][d] = wlu*N_lu[b][d]  (d = choice of the left-up cell leaving the profile; "self" d == b, "other" d == 1-b)
+// = 32 floats, padded to a stride of 36 words (conflict-free for ds_write_b128).  A DP step reads ONE float2.
+constexpr int TAB = 36;
 // phase-1 staging record per cell (same LDS slab, before the tables are built): the four forward grid weights of the
 // cell (times beta) and its packed labels (l | p << 8 | present << 16); stride 5 words: conflict-free.
 constexpr int REC = 5;
 constexpr int EH = 7;                   // rows of the staged rectangle: the strip's 5 plus the fixed row above and below
 constexpr int ECELLS = EH * (63 + 2);   // ... times its columns plus the fixed column left and right
-constexpr int SLAB = (ECELLS * REC + 3) / 4 * 4;   // floats per wave (9.1 KB, 16-byte multiple) >= 64 * TAB
+constexpr int SLAB = 64 * TAB;           // floats per wave (9216 B): the tables of one pass; >= the staging area
+static_assert(SLAB >= ECELLS * REC && SLAB % 4 == 0, "LDS slab too small");
 
 __device__ __forceinline__ void build_table(float* tab, int lane, float c0, float c1, float wu, float wlu, float wl,
                                             float wld, int bits) {
   float4* dst = reinterpret_cast<float4*>(tab + lane * TAB);
+  // lu[b][self], lu[b][other]
+  const float lu0s = ((bits >> 4) & 1) ? wlu : 0.f, lu0o = ((bits >> 5) & 1) ? wlu : 0.f;
+  const float lu1s = ((bits >> 7) & 1) ? wlu : 0.f, lu1o = ((bits >> 6) & 1) ? wlu : 0.f;
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
+  for (int g2 = 0; g2 < 8; ++g2) {       // two combinations per 16-byte store
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = g4 * 4 + e;
+    for (int e = 0; e < 2; ++e) {
+      const int idx = g2 * 2 + e;
       const int b = idx >> 3, bu = (idx >> 2) & 1, bl = (idx >> 1) & 1, bld = idx & 1;
       float x = b ? c1 : c0;
       if ((bits >> (0 + b * 2 + bu)) & 1) x += wu;
       if ((bits >> (8 + b * 2 + bl)) & 1) x += wl;
       if ((bits >> (12 + b * 2 + bld)) & 1) x += wld;
-      v[e] = x;
+      v[2 * e] = x + (b ? lu1s : lu0s);
+      v[2 * e + 1] = x + (b ? lu1o : lu0o);
     }
-    dst[g4] = make_float4(v[0], v[1], v[2], v[3]);
+    dst[g2] = make_float4(v[0], v[1], v[2], v[3]);
   }
-  dst[4] = make_float4(((bits >> 4) & 1) ? wlu : 0.f, ((bits >> 5) & 1) ? wlu : 0.f, ((bits >> 7) & 1) ? wlu : 0.f,
-                       ((bits >> 6) & 1) ? wlu : 0.f);
 }
 
 // One cell step of the profile DP.  The profile is kept in ROTATING positions: cell t owns bit (t mod 6) of the state
@@ -131,18 +134,19 @@ template <int Q>
 __device__ __forceinline__ int tab_offset(int st) {   // byte offsets of this state's entries for position Q
   constexpr int QU = (Q + 5) % 6, QL = (Q + 1) % 6, QLD = (Q + 2) % 6;
   const int b = (st >> Q) & 1, bu = (st >> QU) & 1, bl = (st >> QL) & 1, bld = (st >> QLD) & 1;
-  return (b * 8 + bu * 4 + bl * 2 + bld) * 4;
+  return (b * 8 + bu * 4 + bl * 2 + bld) * 8;
 }
 
 template <int Q>
-__device__ __forceinline__ void dp_step(float& m, unsigned long long& took, float base, float lu_self, float lu_other,
+__device__ __forceinline__ void dp_step(float& m, unsigned long long& took, float t_self, float t_other,
                                         unsigned long long* decision) {
   // the two predecessors of state s differ in bit q (the choice d of cell t-6, which leaves the profile): "self" is this
-  // lane's own value (d equal to the new cell's bit b), "other" the value of lane s ^ (1 << q).  Ties keep "self".
-  const float e_self = m + lu_self;
-  const float e_other = xor_exchange<Q>(m) + lu_other;
+  // lane's own value (d equal to the new cell's bit b), "other" the value of the state with bit q flipped; the table
+  // entries already hold the cell's cost plus the left-up term of either case.  Ties keep "self".
+  const float e_self = m + t_self;
+  const float e_other = xor_exchange<Q>(m) + t_other;
   const bool take_other = e_other < e_self;
-  m = base + (take_other ? e_other : e_self);
+  m = take_other ? e_other : e_self;
   *decision = __ballot(take_other);
   // took bit 0: state 000000 was once reached more cheaply from a state with a switched cell than along the all-keep
   // path.  Both continue identically with "keep", so this happens iff a strictly improving move exists (a scalar OR).
@@ -161,11 +165,9 @@ template <int P, int TT>
 __device__ __forceinline__ void dp_step_at(float& m, unsigned long long& took, int lane, const char* tabc) {
   constexpr int Q = (4 * P + TT) % 6;
   const char* rec = tabc + TT * (TAB * 4);
-  const int st = state_of_lane(lane);
-  const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(st));
-  const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((st >> Q) & 1) * 8);
+  const float2 tv = *reinterpret_cast<const float2*>(rec + tab_offset<Q>(state_of_lane(lane)));
   unsigned long long dec;
-  dp_step<Q>(m, took, base, lu.x, lu.y, &dec);
+  dp_step<Q>(m, took, tv.x, tv.y, &dec);
 }
 
 template <int P, int... TT>
@@ -177,14 +179,11 @@ __device__ __forceinline__ void dp_steps_unrolled(float& m, unsigned long long& 
 // All steps of pass P (cells t = 64 P + tt): the pass's 64 cell tables are built into the wave's LDS slab, then walked.
 template <int P, bool RECORD>
 __device__ __forceinline__ void dp_pass(float& m, unsigned long long& took, int lane, float* tab, float c0, float c1, float wu, float wlu, float wl,
-                                        float wld, int bits, int t_lo, int t_end) {
-  // decision ballots of the pass: lane tt keeps the ballot of step tt; parked in LDS behind the tables at the end
-  unsigned int dlo = 0u, dhi = 0u;
-  uint2* decs = reinterpret_cast<uint2*>(tab + 64 * TAB) + P * 64;
-  if (P * 64 > t_end || P * 64 + 63 < t_lo) {
-    if (RECORD) decs[lane] = make_uint2(0u, 0u);
-    return;
-  }
+                                        float wld, int bits, int t_lo, int t_end, unsigned int& dlo, unsigned int& dhi) {
+  // RECORD: the decision ballots of the pass stay in registers, lane tt keeps the ballot of step tt
+  dlo = 0u;
+  dhi = 0u;
+  if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
   build_table(tab, lane, c0, c1, wu, wlu, wl, wld, bits);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -209,10 +208,9 @@ __device__ __forceinline__ void dp_pass(float& m, unsigned long long& took, int 
     if (J < 4 || tt < 64) {                                                                                          \
       constexpr int Q = (4 * P + J) % 6;                                                                             \
       const char* rec = tabc + tt * (TAB * 4);                                                                       \
-      const float base = *reinterpret_cast<const float*>(rec + tab_offset<Q>(state_of_lane(lane)));                  \
-      const float2 lu = *reinterpret_cast<const float2*>(rec + 64 + ((state_of_lane(lane) >> Q) & 1) * 8);           \
+      const float2 tv = *reinterpret_cast<const float2*>(rec + tab_offset<Q>(state_of_lane(lane)));                  \
       unsigned long long dec;                                                                                        \
-      dp_step<Q>(m, took, base, lu.x, lu.y, &dec);                                                                   \
+      dp_step<Q>(m, took, tv.x, tv.y, &dec);                                                                         \
       if (RECORD) {                                                                                                  \
         write_lane(dlo, (unsigned int)(dec & 0xffffffffull), tt);                                                    \
         write_lane(dhi, (unsigned int)(dec >> 32), tt);                                                              \
@@ -222,18 +220,15 @@ __device__ __forceinline__ void dp_pass(float& m, unsigned long long& took, int 
     PHMRF_STEP(0) PHMRF_STEP(1) PHMRF_STEP(2) PHMRF_STEP(3) PHMRF_STEP(4) PHMRF_STEP(5)
 #undef PHMRF_STEP
   }
-  if (RECORD) decs[lane] = make_uint2(dlo, dhi);
   __builtin_amdgcn_wave_barrier();
 }
 
 // Backtrack of pass P on scalars: x_t = bit q of the state, then the state gets back the bit of cell t-6.
 template <int P>
-__device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, const float* tab, int lane,
+__device__ __forceinline__ void backtrack_pass(int& s, int t_lo, int t_end, unsigned int dlo, unsigned int dhi,
                                                unsigned int& xsel) {
   xsel = 0u;
   if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
-  const uint2 dd = (reinterpret_cast<const uint2*>(tab + 64 * TAB) + P * 64)[lane];
-  const unsigned int dlo = dd.x, dhi = dd.y;
   int tb0 = t_lo - P * 64;
   tb0 = tb0 < 0 ? 0 : tb0 - tb0 % 6;
   int tb1 = t_end - P * 64;
@@ -457,11 +452,12 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     //      parked in lane (t mod 64) of a per-pass register pair.
     float m = lane == 0 ? 0.f : BIG;     // every cell before t_lo keeps its label: profile 000000
     unsigned long long took = 0ull;
-    dp_pass<0, false>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
-    dp_pass<1, false>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
-    dp_pass<2, false>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
-    dp_pass<3, false>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
-    dp_pass<4, false>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
+    unsigned int dlo[NPASS], dhi[NPASS];
+    dp_pass<0, false>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
+    dp_pass<1, false>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
+    dp_pass<2, false>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
+    dp_pass<3, false>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
+    dp_pass<4, false>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
 
     if ((debug & 3) == 2) continue;
     // ---- final state: among the minimisers take the one whose SHIFT-encoded index (newest cell in bit 0, as in the
@@ -479,11 +475,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 104, 1ull);   // DPs that found a move
     // a move exists (about 3 strips in 1000): walk the DP again, this time recording the decision ballots
     m = lane == 0 ? 0.f : BIG;
-    dp_pass<0, true>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end);
-    dp_pass<1, true>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end);
-    dp_pass<2, true>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end);
-    dp_pass<3, true>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end);
-    dp_pass<4, true>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end);
+    dp_pass<0, true>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
+    dp_pass<1, true>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
+    dp_pass<2, true>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
+    dp_pass<3, true>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
+    dp_pass<4, true>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
     const float cand = (m == mmin) ? (float)sidx : 127.f;
     const float best = wave_min_f32(cand);
     int s = state_of_lane(__ffsll((long long)__ballot(cand == best)) - 1);
@@ -491,11 +487,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     // ---- backtrack on scalars; the choice of cell t lands in lane (t mod 64) of xsel[pass]
     unsigned int xsel[NPASS];
     s = __builtin_amdgcn_readfirstlane(s);
-    backtrack_pass<4>(s, t_lo, t_end, tab, lane, xsel[4]);
-    backtrack_pass<3>(s, t_lo, t_end, tab, lane, xsel[3]);
-    backtrack_pass<2>(s, t_lo, t_end, tab, lane, xsel[2]);
-    backtrack_pass<1>(s, t_lo, t_end, tab, lane, xsel[1]);
-    backtrack_pass<0>(s, t_lo, t_end, tab, lane, xsel[0]);
+    backtrack_pass<4>(s, t_lo, t_end, dlo[4], dhi[4], xsel[4]);
+    backtrack_pass<3>(s, t_lo, t_end, dlo[3], dhi[3], xsel[3]);
+    backtrack_pass<2>(s, t_lo, t_end, dlo[2], dhi[2], xsel[2]);
+    backtrack_pass<1>(s, t_lo, t_end, dlo[1], dhi[1], xsel[1]);
+    backtrack_pass<0>(s, t_lo, t_end, dlo[0], dhi[0], xsel[0]);
 
     // ---- phase 3: lane <-> cell: apply
     __builtin_amdgcn_wave_barrier();
