@@ -146,7 +146,7 @@ __device__ __forceinline__ void dp_step(float& m, unsigned long long& took, floa
   const float e_self = m + t_self;
   const float e_other = xor_exchange<Q>(m) + t_other;
   const bool take_other = e_other < e_self;
-  m = take_other ? e_other : e_self;
+  m = __builtin_fminf(e_self, e_other);          // off the compare: the dependent chain is exchange -> add -> min
   *decision = __ballot(take_other);
   // took bit 0: state 000000 was once reached more cheaply from a state with a switched cell than along the all-keep
   // path.  Both continue identically with "keep", so this happens iff a strictly improving move exists (a scalar OR).
