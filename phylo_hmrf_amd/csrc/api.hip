@@ -1061,11 +1061,12 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     verifying = false;
     // A type stays active while it changes labels.  With an energy tolerance, "changes labels" means: enough of them
-    // that, at this round's average gain per changed label, its share of the tolerance is exceeded (a type whose last
-    // run was worth less than tol / #types is rested until the verification round).
+    // that, at this round's average gain per changed label, its last run was worth at least a quarter of the stopping
+    // tolerance; otherwise it is rested until the verification round.  (Measured on the whole-genome block: energy
+    // +2..4e-7 relative, i.e. inside the tolerance of 1e-6, for 7 % less E-step time than with tol / #types.)
     double min_labels = 0.0;
     if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0)
-      min_labels = 1e-9 * o.energy_tol_ppb * std::fabs(e_prev) / (double)slots.size() / (gain / (double)ch);
+      min_labels = 1e-9 * o.energy_tol_ppb * std::fabs(e_prev) / 4.0 / (gain / (double)ch);
     int n_act = 0;
     for (int sl : slots) {
       active[sl] = (double)b->counters_host[sl] > min_labels ? 1 : 0;
