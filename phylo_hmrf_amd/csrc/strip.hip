@@ -321,16 +321,30 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     int rbits[NPASS];
     int t_lo = NCELL_MAX, t_hi = -1;
     int* tabi = reinterpret_cast<int*>(tab);
-    const int ecells = EH * (ncols + 2);
     {
       constexpr int NEP = (ECELLS + 63) / 64;       // 8 lane-passes over the staged rectangle
-      int enode[NEP];
+      int enode[NEP], eidx[NEP];
 #pragma unroll
       for (int q = 0; q < NEP; ++q) {               // all addresses first ...
-        int e = q * 64 + lane;
-        asm volatile("" : "+v"(e));                 // (kept out of the loop-invariant set, see step B)
-        const int ec = e / EH, er = e - ec * EH;
-        enode[q] = e < ecells ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
+        int er, ec;
+        if (ORIENT == 0) {
+          // strip columns are contiguous in memory: one staged row per lane-pass (64 consecutive nodes per load
+          // instruction), the 65th column in the last pass
+          int l2 = lane;
+          asm volatile("" : "+v"(l2));              // (kept out of the loop-invariant set, see step B)
+          er = q < EH ? q : l2;
+          ec = q < EH ? l2 : 64;
+          if (q >= EH && l2 >= EH) ec = 1 << 20;    // no cell
+        } else {
+          // strip rows are contiguous in memory: cells in column-major order (runs of 7 consecutive nodes)
+          int e = q * 64 + lane;
+          asm volatile("" : "+v"(e));
+          ec = e / EH;
+          er = e - ec * EH;
+        }
+        const bool have = ec < ncols + 2;
+        eidx[q] = have ? ec * EH + er : -1;
+        enode[q] = have ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
       }
       int elab[NEP], epl[NEP];
       float4 ef[NEP];
@@ -348,8 +362,8 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
       }
 #pragma unroll
       for (int q = 0; q < NEP; ++q) {
-        const int e = q * 64 + lane;
-        if (e < ecells) {
+        const int e = eidx[q];
+        if (e >= 0) {
           const bool present = enode[q] >= 0;
           tab[e * REC + 0] = ef[q].x * beta;
           tab[e * REC + 1] = ef[q].y * beta;
