@@ -55,7 +55,10 @@ class phyloHMRF(_BaseGraph):
         self.num_neighbor = num_neighbor
         self.edge_potential = self._pairwise_potential()
         self.rng = np.random.default_rng(random_state)
-        self.solver_opts = dict(max_rounds=64, use_chains=True, use_components=True, use_strips=True, use_expansion=True)
+        # the label solver stops when a whole round improves the energy by less than 1e-6 of it (energy_tol_ppb = 0:
+        # until a verification round with every move type finds nothing -- both are below the reference's gco result)
+        self.solver_opts = dict(max_rounds=64, use_chains=True, use_components=True, use_strips=True, use_expansion=True,
+                                energy_tol_ppb=1000)
         if solver_opts:
             self.solver_opts.update(solver_opts)
         self.mstep_workers = mstep_workers
