@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--block-threads", type=int, default=8,
+    ap.add_argument("--block-threads", type=int, default=12,
                     help="host threads driving blocks concurrently, each block on its own HIP stream (1 = sequential)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not record HIP events around the kernel launches (no per-kernel breakdown / roofline)")
