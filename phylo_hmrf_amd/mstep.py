@@ -12,7 +12,9 @@ Semantics of the reference (phylo_hmrf.py:1500-1528 `_do_mstep`, :1327-1403 `_ou
 What differs from the reference is speed only (once the E-step takes milliseconds the K
 SLSQP runs cap the EM rate): the objective comes with its ANALYTIC gradient (reverse sweep over the tree), the
 box is passed as `bounds`, the K independent states are solved in a fork pool, and value + gradient are evaluated by
-the native host helper `libphmrf_host.so` (include/phmrf_host.h, csrc/ou_host.cpp; ~70x faster per evaluation).
+the native host helper `libphmrf_host.so` (include/phmrf_host.h, csrc/ou_host.cpp; ~70x faster per evaluation),
+and SciPy's SLSQP core is driven directly (`_slsqp_lean`: same routine and calling sequence as `minimize`, without
+its generic wrappers).
 The NumPy implementation below stays as the fall-back for an ill-conditioned V (pseudo-inverse branch of the
 reference) and as the oracle of the native one (tests/test_mstep.py).
 """
@@ -218,6 +220,52 @@ class OUObjectiveSingle(OUObjective):
         OUObjective.__init__(self, tree, 1.0, X.mean(axis=0), X.T @ X / n, 1.0, 0.0, min_covar)
 
 
+def _slsqp_lean(fun_and_grad, x0, lower, upper, acc=1e-6, maxiter=200):
+    """SciPy's SLSQP core (scipy.optimize._slsqp.slsqp, the routine `minimize(method="SLSQP")` drives) for a problem
+    with bounds only, driven without the generic wrappers (ScalarFunction, bound clipping, constraint plumbing), which
+    cost more than the native objective itself.  Same algorithm, same calling sequence as scipy 1.15
+    `_minimize_slsqp`; returns (x, exit_mode) or None when that private entry point is not available."""
+    try:
+        from scipy.optimize._slsqp import slsqp
+    except Exception:
+        return None
+    n = x0.shape[0]
+    n1 = n + 1
+    m = meq = 0
+    la = 1
+    mineq = m - meq + n1 + n1
+    len_w = ((3 * n1 + m) * (n1 + 1) + (n1 - meq + 1) * (mineq + 2) + 2 * mineq + (n1 + mineq) * (n1 - meq) + 2 * meq + n1
+             + ((n + 1) * n) // 2 + 2 * m + 3 * n + 3 * n1 + 1)
+    w = np.zeros(len_w)
+    jw = np.zeros(mineq)
+    x = np.clip(np.asarray(x0, dtype=float), lower, upper)
+    xl = np.full(n, lower, dtype=float)
+    xu = np.full(n, upper, dtype=float)
+    mode = np.array(0, int)
+    acc_a = np.array(acc, float)
+    majiter = np.array(maxiter, int)
+    st_f = [np.array(0, float) for _ in range(10)]      # alpha f0 gs h1 h2 h3 h4 t t0 tol
+    st_i = [np.array(0, int) for _ in range(8)]         # iexact incons ireset itermx line n1 n2 n3
+    c = np.zeros(la)
+    a = np.zeros((la, n1))
+
+    def evaluate(xx):                                    # gh11403: SLSQP may leave the box by an ulp or two
+        return fun_and_grad(np.clip(xx, lower, upper))
+
+    fx, gr = evaluate(x)
+    g = np.append(gr, 0.0)
+    while True:
+        slsqp(m, meq, x, xl, xu, fx, c, g, a, acc_a, majiter, mode, w, jw, *st_f, *st_i)
+        if mode == 1:
+            fx, gr = evaluate(x)
+        elif mode == -1:
+            _, gr = evaluate(x)
+            g = np.append(gr, 0.0)
+        if abs(mode) != 1:
+            break
+    return x, int(mode)
+
+
 def _solve_state(args):
     tree, post, obs, oo, n_samples, lambda_0, guesses, init_params = args
     obj = OUObjective(tree, post, obs, oo, n_samples, lambda_0)
@@ -228,9 +276,13 @@ def _solve_state(args):
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore", RuntimeWarning)
-                res = minimize(obj.value_and_grad, x0, jac=True, method="SLSQP", bounds=bounds, tol=1e-6,
-                               options={"disp": False, "maxiter": 200})
-            params1 = res.x
+                lean = _slsqp_lean(obj.value_and_grad, x0, LOWER, UPPER, acc=1e-6, maxiter=200)
+                if lean is not None:
+                    params1 = lean[0]
+                else:
+                    res = minimize(obj.value_and_grad, x0, jac=True, method="SLSQP", bounds=bounds, tol=1e-6,
+                                   options={"disp": False, "maxiter": 200})
+                    params1 = res.x
         except Exception:                                                             # (:1386-1392)
             continue
         flag = check_params(tree, params1)

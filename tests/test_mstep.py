@@ -122,3 +122,25 @@ def test_native_objective_hands_ill_conditioned_cases_to_numpy():
     f1, _ = nat.value_and_grad(p, want_grad=False)
     f0, _ = ref.value_and_grad(p, want_grad=False)
     assert np.isfinite(f0) and f1 == f0
+
+
+def test_lean_slsqp_driver_equals_scipy_minimize():
+    """mstep._slsqp_lean drives scipy's SLSQP core without the generic wrappers: same iterates, same optimum."""
+    from scipy.optimize import minimize
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "mstep_objective.npz"))
+    t = PhyloTree(g1["t4_edge_list"])
+    rng = np.random.default_rng(0)
+    for c in range(g["t4_post"].shape[0]):
+        obj = mstep.OUObjective(t, g["t4_post"][c], g["t4_obs"][c], g["t4_obsobsT"][c], 5000, 1.0)
+        x0 = rng.uniform(0.01, 1.0, t.n_params)
+        lean = mstep._slsqp_lean(obj.value_and_grad, x0, mstep.LOWER, mstep.UPPER, acc=1e-6, maxiter=200)
+        if lean is None:
+            pytest.skip("scipy.optimize._slsqp.slsqp is not importable in this SciPy: the driver falls back to minimize()")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            res = minimize(obj.value_and_grad, x0, jac=True, method="SLSQP", bounds=[(mstep.LOWER, mstep.UPPER)] * t.n_params,
+                           tol=1e-6, options={"maxiter": 200})
+        assert lean[1] == res.status
+        np.testing.assert_allclose(lean[0], res.x, rtol=1e-12, atol=1e-14)
