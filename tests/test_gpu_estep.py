@@ -619,3 +619,49 @@ def test_degenerate_sizes(H, W, diagonal, K, nn):
     assert res["converged"] and res["energy"] <= e0 + 1e-9
     assert abs(res["energy"] - host) <= 1e-6 * max(1.0, abs(host))
     b.close()
+
+
+def test_full_size_largest_block_of_the_metric_config():
+    """The largest block of the metric configuration (hg38 chr1 at 50 kb: 4980 x 4980 diagonal block, 12,402,690
+    nodes, S=4, K=20) through properties that need no host copy of the big arrays: the solver lowers the energy and
+    converges; the energy kernel, the solver's own report and the posterior kernel's cost numerators agree (three
+    different kernels); statistics identities against torch reductions of X; a second solve changes (almost) nothing."""
+    import torch
+    from phylo_hmrf_amd import Block, synthetic
+    from phylo_hmrf_amd.tree import PhyloTree
+    N, S, K = 4980, 4, 20
+    n = N * (N + 1) // 2
+    tree = PhyloTree(synthetic.tree_for(S))
+    rng = np.random.default_rng(1)
+    P = synthetic.sample_ou_params(rng, tree, K)
+    mu, cv = tree.mean_cov(P)
+    cv = cv + 1e-3 * np.eye(S)
+    P2 = np.clip(P * (1 + 0.1 * rng.standard_normal(P.shape)), 1e-3, 50)      # fit with slightly wrong parameters
+    mu2, cv2 = tree.mean_cov(P2)
+    cv2 = cv2 + 1e-3 * np.eye(S)
+    dev = torch.device("cuda", 0)
+    Xd = synthetic.device_observations(torch, dev, 9, N, N, True, K, mu, cv)
+    torch.cuda.synchronize()
+    b = Block(n, S, K)
+    b.set_observations_dev(Xd.data_ptr())
+    b.sync()
+    b.build_grid_graph(N, N, True, 8, 0.5)
+    b.emission(mu2, cv2)
+    res = b.solve(1.0, init_mode=1, energy_tol_ppb=1000)
+    assert res["converged"] and res["energy"] < res["energy_init"] and res["rounds"] < 32
+    e_tot, e_un, e_pw = b.energy(1.0)
+    np.testing.assert_allclose(res["energy"], e_tot, rtol=1e-9)
+    stats, costs, _ = b.posterior_stats(1.0, 3)
+    np.testing.assert_allclose(costs[2], e_un, rtol=1e-6)          # unary cost numerator = unary energy
+    np.testing.assert_allclose(costs[0], 2.0 * e_pw, rtol=1e-5)    # pairwise cost counts every edge from both ends
+    np.testing.assert_allclose(costs[3], costs[1] + costs[2], rtol=1e-12)
+    X64 = Xd.double()
+    np.testing.assert_allclose(stats["post"].sum(), n, rtol=1e-6)
+    np.testing.assert_allclose(stats["obs"].sum(axis=0), X64.sum(dim=0).cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(stats["obs*obs.T"].sum(axis=0), (X64.T @ X64).cpu().numpy(), rtol=2e-5)
+    labels = b.get_labels()
+    assert labels.min() >= 0 and labels.max() < K and len(np.unique(labels)) > K // 2
+    res2 = b.solve(1.0, energy_tol_ppb=1000)
+    assert res2["energy"] <= res["energy"] * (1 + 1e-9)
+    assert (res["energy"] - res2["energy"]) <= 1e-5 * abs(res["energy"])     # the first solve had reached the tolerance
+    b.close()
