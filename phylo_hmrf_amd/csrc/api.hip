@@ -947,7 +947,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   // the energy before the first round (only needed when the caller asked for it: the first round of a solve that
   // changes labels always improves, and the tolerance refers to the energy after the round)
   double e_prev = res ? eu0 + ep0 : std::numeric_limits<double>::infinity();
-  while (rounds < o.max_rounds) {
+  while (rounds < o.max_rounds && b->tick < 60000) {      // (the change stamps are 16-bit launch ticks)
     const int r = rounds;
     PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
     {
