@@ -53,7 +53,9 @@ PHMRF_API int phmrf_device_count(int* count);
 PHMRF_API int phmrf_set_device(int device);
 
 /* ---- block lifetime --------------------------------------------------------------------------- */
-/* n nodes (Hi-C bin pairs), S species (leaves), K states.  K <= 64, S <= 16. */
+/* n nodes (Hi-C bin pairs), S species (leaves), K states.  K <= 64, S <= 16, n < 2^31 - 64.
+ * Limits per entry point: the emission (b1) covers S <= 16; phmrf_posterior_stats (b3) covers S <= 8 and
+ * K*(1+S+S*S) <= 4608 and returns PHMRF_ERR_UNSUPPORTED beyond that; node degree <= 64 (phmrf_block_set_graph). */
 PHMRF_API int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out);
 PHMRF_API int phmrf_block_destroy(phmrf_block_t b);
 /* Run this block's kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
@@ -123,7 +125,9 @@ typedef struct phmrf_solve_opts {
                           moves have gone quiet; the solve ends when such a sweep is quiet too                  */
   int min_changed;     /* a round that changes at most this many labels counts as quiet (default 0)             */
   int energy_tol_ppb;  /* > 0: stop as soon as a round lowers the energy by less than this many parts per billion
-                          of |E| (no verification round); 0: run to the exact fixed point                       */
+                          of |E| (no verification round).  Move types whose last runs were, taken together, worth at
+                          most a quarter of that are rested meanwhile, so what a tolerance stop leaves undone in one
+                          round is bounded by 1.25 x the tolerance.  0: run to the exact fixed point              */
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {
@@ -132,7 +136,10 @@ typedef struct phmrf_solve_result {
   double energy_pair;
   double energy_init;   /* same for the starting labels */
   int rounds;           /* rounds executed */
-  int converged;        /* 1 if the last round changed no label */
+  int converged;        /* 1: ended at a fixed point of all move types (a quiet verification round) or inside the energy
+                           tolerance; 0: ended by max_rounds or by the launch budget of one solve (60,000 kernel launches:
+                           the change stamps are 16-bit launch ticks) -- the labels are valid and the energy never
+                           went up, but more rounds could still lower it                                         */
   int64_t changed;      /* total label changes applied */
 } phmrf_solve_result;
 

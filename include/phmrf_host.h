@@ -48,6 +48,15 @@ PHMRF_HOST_API int phmrf_ou_objective(const phmrf_tree_tables* tree, const doubl
                                       const double* oo, double n_samples, double reg, double min_covar, double* f_out,
                                       double* grad, double* V_out, double* mu_out);
 
+/* Pre-processing: the reference's median fill of empty contact-map cells, `near_interpolation1`
+ * (symmetric != 0: square matrix, upper triangle scanned, value mirrored; utility.py:603-631) and
+ * `near_interpolation1a` (symmetric == 0: general matrix; utility.py:633-660).  mtx: C-order float64 [n1,n2], updated
+ * IN PLACE in raster order exactly like the reference's loops: a cell below `threshold` (THRESH1 = 1e-5, :47) takes the
+ * median of its 8 neighbours when that median is above the threshold.  n_low / n_filled (may be NULL) return the
+ * reference's cnt1 / cnt2.                                                                                       */
+PHMRF_HOST_API int phmrf_median_fill(double* mtx, int64_t n1, int64_t n2, int symmetric, double threshold,
+                                     int64_t* n_low, int64_t* n_filled);
+
 PHMRF_HOST_API int phmrf_host_version(void);
 
 #ifdef __cplusplus

@@ -8,9 +8,12 @@ Same flags, same defaults as the reference CODE (which differ from its README: -
 phylo_hmrf.py:1676-1704) and the same output `estimate_ou_<run>_<lambda0>_<K>.mat` with the fields
 state_vec, len_vec, params_vec1, params_vec2, iter_id1, iter_id2, cost_vec (:1743-1748).
 
-Scope: the raw Hi-C pre-processing of utility.py (merge, normalise, median fill, anisotropic diffusion)
-is NOT part of this build; run the reference once to produce the cache (it writes it on every run) and start here
-with --reload 1, or use --synthetic N to generate a seeded multi-species block in the same cache format.
+Raw input (edge.1.txt, branch_length.1.txt, species_name.1.txt, path_list.txt, <ref>.chrom.sizes, chr<c>.synteny.txt and
+the species' chr<c>.<res>K.txt contact files under --root_path, README.md:53-75) is pre-processed on the host by
+phylo_hmrf_amd/preprocess.py, a restatement of utility.load_data_chromosome2 pinned on the reference's own loader
+(tests/test_preprocess.py); --filter_mode 0 uses the build's Perona-Malik restatement of medpy's filter (medpy is not
+installed: parity unpinned for that one function), --filter_mode 1 (skimage bilateral) is not provided.
+--synthetic N instead generates a seeded multi-species block in the same cache format.
 """
 from __future__ import print_function
 
@@ -161,11 +164,33 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
         write_cache(output_path, resolution, run_id, samples, edge_list_vec, len_vec)
     else:
         edge_list, branch_list, species = load_tree_files(data_path)       # phylo_hmrf.py:1607-1631
-        if reload_mode != 1 or not all(os.path.exists(f) for f in cache_names(output_path, resolution, run_id)):
-            raise SystemExit("raw Hi-C pre-processing (utility.load_data_chromosome2, phylo_hmrf.py:1694) is outside this "
-                             "build's scope: produce the cache with the reference (it is written on every run, "
-                             ":1697-1704) and pass --reload 1 --output <dir>, or use --synthetic N")
-        samples, len_vec, edge_list_vec = load_cache(output_path, resolution, run_id)
+        have_cache = all(os.path.exists(f) for f in cache_names(output_path, resolution, run_id))
+        if reload_mode == 1 and not have_cache:
+            print("%s does not exist" % cache_names(output_path, resolution, run_id)[0])   # :1682-1684
+            reload_mode = 0
+        if reload_mode == 1:
+            samples, len_vec, edge_list_vec = load_cache(output_path, resolution, run_id)
+        else:
+            from phylo_hmrf_amd import preprocess
+            with open("%s/path_list.txt" % data_path) as f:                 # :1633-1639
+                filename_list = [line.strip() for line in f if line.strip()]
+            # path_list.txt holds the species' directories, relative to the working directory in the reference's example
+            filename_list = [p if os.path.isabs(p) or os.path.isdir(p) else os.path.join(data_path, p) for p in filename_list]
+            chrom_vec = list(range(1, 23)) if str(chromvec) == "-1" else [int(c) for c in str(chromvec).split(",")]
+            ref_filename = "%s/%s.chrom.sizes" % (data_path, str(ref_species))
+            quantile = int(quantile)
+            qfile = "chrom_quantile_test.txt"                               # :1648-1664
+            if quantile == 0 and os.path.exists(qfile):
+                x_max = float(np.median(np.atleast_2d(np.loadtxt(qfile, delimiter="\t"))[:, 6]))
+            else:
+                m_vec_list = preprocess.quantile_contact_vec(chrom_vec, resolution, ref_filename, filename_list, species)
+                np.savetxt(qfile, m_vec_list, fmt="%.4f", delimiter="\t")
+                x_max = float(np.median(m_vec_list[:, 6]))
+            print(x_max)
+            samples, len_vec, edge_list_vec = preprocess.load_data_chromosome2(
+                chrom_vec, x_max, 0, resolution, num_neighbor, int(filter_mode), float(filter_sigma), int(diagonal_type),
+                ref_filename, filename_list, species, data_path, annotation)
+            write_cache(output_path, resolution, run_id, samples, edge_list_vec, len_vec)     # :1697-1704
     print("use time load data: %s" % (time.time() - start))
     print(samples.shape)
     print(np.asarray(len_vec))

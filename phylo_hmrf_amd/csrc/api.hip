@@ -28,22 +28,29 @@ static hipEvent_t take_event(phmrf_block* b) {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;   // the interval is then dropped (tic / toc), never mis-timed
   return e;
 }
 
 void tic(phmrf_block* b) {
   if (!b->timing) return;
   b->cur_start = take_event(b);
-  (void)hipEventRecord(b->cur_start, b->stream);
+  if (b->cur_start && hipEventRecord(b->cur_start, b->stream) != hipSuccess) {
+    b->free_events.push_back(b->cur_start);
+    b->cur_start = nullptr;
+  }
 }
 
 void toc(phmrf_block* b, int kclass, int n_launches) {
   b->launches[kclass] += n_launches;
   if (!b->timing || !b->cur_start) return;
   hipEvent_t e = take_event(b);
-  (void)hipEventRecord(e, b->stream);
-  b->pending.push_back({kclass, b->cur_start, e});
+  if (e && hipEventRecord(e, b->stream) == hipSuccess) {
+    b->pending.push_back({kclass, b->cur_start, e});
+  } else {                                                  // no event: this interval is not timed
+    if (e) b->free_events.push_back(e);
+    b->free_events.push_back(b->cur_start);
+  }
   b->cur_start = nullptr;
 }
 
@@ -1044,8 +1051,11 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     const double gain = e_prev - e_now;
     if (e_now < e_prev) e_prev = e_now;
-    if (o.energy_tol_ppb > 0 && gain < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
-      converged = 1;                                  // accepted tolerance: the remaining moves are worth less
+    // accepted tolerance: the round (all active types; the rested ones were worth at most a quarter of the tolerance
+    // together, see below) gained less than the tolerance.  A round that RAISED the energy (f32 move arithmetic against
+    // the f64 energy) is not "converged": it is quiet, and the verification round decides.
+    if (o.energy_tol_ppb > 0 && gain >= 0.0 && gain < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
+      converged = 1;
       break;
     }
     const bool quiet = ch <= tol || !improved;
@@ -1060,18 +1070,27 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       continue;
     }
     verifying = false;
-    // A type stays active while it changes labels.  With an energy tolerance, "changes labels" means: enough of them
-    // that, at this round's average gain per changed label, its last run was worth at least a quarter of the stopping
-    // tolerance; otherwise it is rested until the verification round.  (Measured on the whole-genome block: energy
-    // +2..4e-7 relative, i.e. inside the tolerance of 1e-6, for 7 % less E-step time than with tol / #types.)
-    double min_labels = 0.0;
-    if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0)
-      min_labels = 1e-9 * o.energy_tol_ppb * std::fabs(e_prev) / 4.0 / (gain / (double)ch);
+    // A type stays active while it changes labels.  With an energy tolerance the types whose last run changed the
+    // fewest labels are rested until the verification round, as long as ALL rested types together were worth at most a
+    // quarter of the stopping tolerance at this round's average gain per changed label (so the moves a tolerance stop
+    // leaves undone are bounded by 1.25 x the tolerance, however many types there are).
     int n_act = 0;
-    for (int sl : slots) {
-      active[sl] = (double)b->counters_host[sl] > min_labels ? 1 : 0;
-      n_act += active[sl];
+    for (int sl : slots) active[sl] = 1;
+    if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0) {
+      const double budget_labels = 1e-9 * o.energy_tol_ppb * std::fabs(e_prev) / 4.0 / (gain / (double)ch);
+      std::vector<int> by_count(slots);
+      std::sort(by_count.begin(), by_count.end(),
+                [&](int a, int c) { return b->counters_host[a] < b->counters_host[c]; });
+      double used = 0.0;
+      for (int sl : by_count) {
+        used += (double)b->counters_host[sl];
+        if (used > budget_labels) break;
+        active[sl] = 0;
+      }
+    } else {
+      for (int sl : slots) active[sl] = b->counters_host[sl] > 0 ? 1 : 0;
     }
+    for (int sl : slots) n_act += active[sl];
     all_active = n_act == (int)slots.size();
     if (n_act == 0) {
       for (int sl : slots) active[sl] = 1;

@@ -138,7 +138,8 @@ struct phmrf_block {
 
 namespace phmrf {
 
-constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every supported (K,S)
+constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every (K,S) the posterior / statistics kernel supports
+                                     // (K <= 64, S <= 8: 4,688); phmrf_posterior_stats rejects anything larger
 
 // RAII-free helpers for the timers: call tic before the launches of one class, toc after.
 void tic(phmrf_block* b);

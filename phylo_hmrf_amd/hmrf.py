@@ -15,6 +15,7 @@ import numpy as np
 
 from . import mstep as _mstep
 from .base import SLOT_BEST3, SLOT_LOCAL, _BaseGraph
+from ._lib import PhmrfError
 from .block import Block
 from .dist import Reducer, env_rank_world, lpt_assign
 from .tree import PhyloTree
@@ -39,6 +40,10 @@ class phyloHMRF(_BaseGraph):
                             init_params=init_params)
         if covariance_type not in COVARIANCE_TYPES:
             raise ValueError("covariance_type must be one of {0}".format(COVARIANCE_TYPES))
+        if n_features > 8:
+            # the posterior / statistics kernel holds a node's [1 | x | x x^T] features in LDS for S <= 8 (kernels.hip);
+            # the emission kernel alone goes to S = 16 (phmrf_emission_dev)
+            raise ValueError("phyloHMRF on the GPU supports at most 8 species (n_features = %d)" % n_features)
         self.quiet = quiet
         self.covariance_type = covariance_type
         self.min_covar = min_covar
@@ -54,6 +59,23 @@ class phyloHMRF(_BaseGraph):
         self.len_vec = [list(map(int, lv)) for lv in np.asarray(len_vec).tolist()]
         self.num_neighbor = num_neighbor
         self.edge_potential = self._pairwise_potential()
+        # M-step workers are forked ONCE, before this process touches the GPU (a fork after HIP / RCCL / the block threads
+        # are up is unsafe); later requests for fewer workers reuse the same pool, close() ends it
+        self.mstep_workers = mstep_workers
+        env_rank, env_world, _ = env_rank_world()
+        self.world = env_world if world is None else world
+        self.rank = env_rank if rank is None else rank
+        if self.rank == 0 and block_factory is None:
+            import os as _os
+            want = min(n_components, _os.cpu_count() or 1) if mstep_workers is None else int(mstep_workers)
+            _mstep._pool(want)
+        self.reducer = reducer if reducer is not None else Reducer(self.world)
+        if self.world > 1:
+            # every rank must draw the same initial parameters, k-means seed and restarts: rank 0's seed wins
+            # (random_state None: rank 0 draws one)
+            seed0 = float(np.random.SeedSequence().entropy % (2 ** 31)) if random_state is None else float(random_state)
+            random_state = int(self.reducer.broadcast(np.array([seed0]), src=0)[0])
+            self.random_state = random_state
         self.rng = np.random.default_rng(random_state)
         # the label solver stops when a whole round improves the energy by less than 1e-6 of it (energy_tol_ppb = 0:
         # until a verification round with every move type finds nothing -- both are below the reference's gco result)
@@ -61,7 +83,6 @@ class phyloHMRF(_BaseGraph):
                                 energy_tol_ppb=1000)
         if solver_opts:
             self.solver_opts.update(solver_opts)
-        self.mstep_workers = mstep_workers
         if init_method not in ("sklearn", "device"):
             raise ValueError("init_method must be 'sklearn' (the reference's MiniBatchKMeans) or 'device'")
         self.init_method = init_method
@@ -82,11 +103,7 @@ class phyloHMRF(_BaseGraph):
             initial_mode, initial_weight, initial_weight1, initial_magnitude)
         self.stats = dict()
 
-        # ranks and block ownership
-        env_rank, env_world, _ = env_rank_world()
-        self.world = env_world if world is None else world
-        self.rank = env_rank if rank is None else rank
-        self.reducer = reducer if reducer is not None else Reducer(self.world)
+        # block ownership
         sizes = [lv[0] for lv in self.len_vec]
         self.owner = lpt_assign(sizes, self.world)
         self.my_regions = [r for r in range(len(self.len_vec)) if self.owner[r] == self.rank]
@@ -108,6 +125,7 @@ class phyloHMRF(_BaseGraph):
         # device-resident blocks (the reference's _edge_weight_undirected_vec, :567-598, happens here once)
         factory = block_factory or Block
         self.blocks = {}
+        self.general_graph_regions = []      # regions whose edge list is not the grid stencil: no chain / strip moves
         X = np.asarray(observation)
         for r in self.my_regions:
             lv = self.len_vec[r]
@@ -125,8 +143,16 @@ class phyloHMRF(_BaseGraph):
                 if grid_ok:
                     try:
                         b.set_grid(H, W, diag, num_neighbor)
-                    except Exception:
-                        pass       # an edge list that is not the grid stencil: general-graph moves only
+                    except PhmrfError as err:
+                        if err.status != 1:              # PHMRF_ERR_INVALID = "edges do not fit the grid"; anything
+                            raise                        # else (HIP, allocation) is a real failure
+                        grid_ok = False
+                if not grid_ok:
+                    import warnings
+                    warnings.warn("region %d: the edge list / len_vec is not a contact-map grid block (utility.py:1871-"
+                                  "2053); it is labelled with general-graph moves only (ICM + component moves), for "
+                                  "which no energy parity with gco's swap is claimed" % r, RuntimeWarning)
+                    self.general_graph_regions.append(r)
             self.blocks[r] = b
 
     # ---- properties the reference exposes --------------------------------------------------------
@@ -304,6 +330,7 @@ class phyloHMRF(_BaseGraph):
         self._covars_ = packed[K * P + K * S:].reshape(K, S, S).copy()
 
     def close(self):
+        _mstep.close_pool()
         self.runner.close()
         for b in self.blocks.values():
             b.close()

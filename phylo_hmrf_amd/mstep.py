@@ -266,6 +266,9 @@ def _slsqp_lean(fun_and_grad, x0, lower, upper, acc=1e-6, maxiter=200):
     return x, int(mode)
 
 
+_LEAN_OK = [True]      # cleared (per process) the first time the private SLSQP core rejects our call
+
+
 def _solve_state(args):
     tree, post, obs, oo, n_samples, lambda_0, guesses, init_params = args
     obj = OUObjective(tree, post, obs, oo, n_samples, lambda_0)
@@ -276,7 +279,16 @@ def _solve_state(args):
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore", RuntimeWarning)
-                lean = _slsqp_lean(obj.value_and_grad, x0, LOWER, UPPER, acc=1e-6, maxiter=200)
+                lean = None
+                if _LEAN_OK[0]:
+                    try:
+                        lean = _slsqp_lean(obj.value_and_grad, x0, LOWER, UPPER, acc=1e-6, maxiter=200)
+                    except (TypeError, ValueError, AttributeError, SystemError) as err:
+                        # the private SciPy entry point does not have the signature this was written for (SciPy 1.15):
+                        # use the public wrapper from now on instead of failing every retry silently
+                        _LEAN_OK[0] = False
+                        warnings.warn("scipy.optimize._slsqp.slsqp is not callable as expected (%s: %s); the M-step "
+                                      "uses scipy.optimize.minimize from here on" % (type(err).__name__, err))
                 if lean is not None:
                     params1 = lean[0]
                 else:
@@ -303,10 +315,14 @@ def _pool(workers):
     global _POOL, _POOL_SIZE
     if workers <= 1:
         return None
-    if _POOL is None or _POOL_SIZE != workers:
-        if _POOL is not None:
-            _POOL.terminate()
-        _POOL = mp.get_context("fork").Pool(workers)
+    if _POOL is None:
+        # Workers come from a FORK SERVER: a fresh interpreter (started by exec, with this module preloaded) forks them,
+        # so creating the pool is safe whenever it happens -- also after this process has initialised HIP / RCCL or
+        # started its block threads, where a plain fork() of the process itself is not.  Created once, reused for every
+        # later request (fewer tasks than workers leave some idle; more tasks queue); close_pool() ends it.
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(["phylo_hmrf_amd.mstep"])
+        _POOL = ctx.Pool(workers)
         _POOL_SIZE = workers
     return _POOL
 
@@ -315,6 +331,7 @@ def close_pool():
     global _POOL
     if _POOL is not None:
         _POOL.terminate()
+        _POOL.join()
         _POOL = None
 
 

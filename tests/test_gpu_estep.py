@@ -311,11 +311,22 @@ def test_energy_parity_with_reference_gco_golden(tag, H, W, diagonal):
     b.close()
 
 
-@pytest.mark.parametrize("tol_ppb", [0, 1000])
-@pytest.mark.parametrize("seed,N,K,diagonal,perturb", [(0, 150, 10, False, 0.0), (1, 160, 20, True, 0.0), (3, 120, 20, False, 0.3),
-                                                       (5, 220, 20, True, 0.15), (7, 140, 30, False, 0.1)])
-def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, perturb, tol_ppb):
-    """Same claim on larger seeded synthetic Hi-C blocks, gco run live (oracle/_ref travels with the repo)."""
+# Sizes: the small ones from round 1, then BASELINE's own block sizes -- config 1's two blocks (652- and 683-bin diagonal
+# blocks: 212,878 / 233,586 nodes, K=20) and config 2 in full (2000-bin diagonal block, 2,001,000 nodes, K=10).
+LIVE_GCO_CASES = [(0, 150, 10, False, 0.0), (1, 160, 20, True, 0.0), (3, 120, 20, False, 0.3), (5, 220, 20, True, 0.15),
+                  (7, 140, 30, False, 0.1), (11, 652, 20, True, 0.0), (12, 683, 20, True, 0.1), (13, 2000, 10, True, 0.0)]
+
+
+@pytest.mark.parametrize("seed,N,K,diagonal,perturb", LIVE_GCO_CASES)
+def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, perturb):
+    """north_star: "final MRF energy <= the reference's", on seeded synthetic Hi-C blocks up to BASELINE's block sizes,
+    gco run live (oracle/_ref travels with the repo), the solver at its exact fixed point (tol 0) and at the 1e-6
+    relative stopping tolerance the fit driver and the bench use (tol 1000 ppb).
+
+    The reference's result is gco's swap THROUGH PYGCO'S QUANTISATION (phylo_hmrf.py:496-498): the GPU labelling must
+    be at or below it STRICTLY -- both labellings are scored by the same float64 function, no slack.  gco at its finest
+    safe quantisation is not what the reference computes; the gap to it is printed and bounded by 1e-4 (neither local
+    optimum dominates the other in theory: swap moves vs strip-restricted expansion / fusion / chain moves)."""
     from oracle import gco_ref
     if not gco_ref.available():
         pytest.skip("oracle/_ref/libgco_ref.so not present")
@@ -335,12 +346,16 @@ def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, p
     b.set_graph(eid, w)
     b.set_grid(N, N, diagonal, 8)
     b.set_logprob(lp)
-    b.set_labels(init)
-    res = b.solve(1.0, energy_tol_ppb=tol_ppb)       # 0: exact fixed point; 1000: the bench's 1e-6 relative tolerance
-    e_mine = R.mrf_energy(b.get_labels(), lp, eid, w, 1.0)[0]
-    print("tol %d ppb: energy mine %.3f  swap_pygco %.3f  swap_fine %.3f  rounds %d" % (tol_ppb, e_mine, e_ref["pygco"], e_ref["fine"], res["rounds"]))
-    assert e_mine <= e_ref["pygco"] + 1e-6 * abs(e_ref["pygco"])
-    assert e_mine <= e_ref["fine"] * (1 + 2e-4)        # within 0.02 % of (usually below) the fine-quantised swap
+    for tol_ppb in (0, 1000):
+        b.set_labels(init)
+        res = b.solve(1.0, energy_tol_ppb=tol_ppb)
+        e_mine = R.mrf_energy(b.get_labels(), lp, eid, w, 1.0)[0]
+        print("n %d K %d tol %d ppb: energy GPU %.3f  swap via pygco %.3f (GPU %+.2e)  swap fine %.3f (GPU %+.2e)  rounds %d"
+              % (n, K, tol_ppb, e_mine, e_ref["pygco"], (e_mine - e_ref["pygco"]) / abs(e_ref["pygco"]), e_ref["fine"],
+                 (e_mine - e_ref["fine"]) / abs(e_ref["fine"]), res["rounds"]))
+        assert res["converged"]
+        assert e_mine <= e_ref["pygco"], (tol_ppb, e_mine, e_ref)
+        assert e_mine <= e_ref["fine"] + 1e-4 * abs(e_ref["fine"]), (tol_ppb, e_mine, e_ref)
     b.close()
 
 

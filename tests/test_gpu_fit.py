@@ -106,3 +106,95 @@ def test_blocks_in_flight_give_the_sequential_result():
     np.testing.assert_allclose(a[5], b[5], rtol=1e-6)     # cost_vec: every iteration's costs
     np.testing.assert_allclose(a[0], b[0], rtol=1e-4, atol=1e-6)
     assert np.mean(a[6] == b[6]) > 0.999                  # labels
+
+
+@pytest.mark.parametrize("tag", ["diag", "offdiag", "chain"])
+def test_pygco_drop_in_without_geometry_beats_the_reference(tag):
+    """Row b2: the shim called exactly like phylo_hmrf.py:496-498 (no geometry argument) on the graphs whose labelling
+    was recorded through the reference's own predict(): the grid is inferred from the edge list and the float energy is
+    <= the reference's (strictly: same float64 scoring of both labellings)."""
+    import warnings
+    from oracle import ref_numpy as R
+    from phylo_hmrf_amd.pygco_compat import cut_general_graph
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gco_%s.npz" % tag))
+    K, beta = int(g["K"]), float(g["beta"])
+    w, eid = R.edge_weights_from_distance(g["edges"], 0.5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lab = cut_general_graph(eid, w, -g["logprob"], R.potts_matrix(K, beta), n_iter=5000, algorithm="swap",
+                                init_labels=g["init"])
+    e_mine = R.mrf_energy(lab, g["logprob"], eid, w, beta)[0]
+    assert e_mine <= float(g["efloat_swap_pygco"][0])
+    assert e_mine <= float(g["efloat_swap_fine"][0]) + 1e-6 * abs(float(g["efloat_swap_fine"][0]))
+
+
+def test_pygco_drop_in_on_a_graph_that_is_no_grid():
+    """A general graph gets the general-graph moves and says so; strict_grid=True refuses."""
+    from oracle import ref_numpy as R
+    from phylo_hmrf_amd.pygco_compat import cut_general_graph
+    rng = np.random.default_rng(3)
+    n, K = 200, 5
+    eid = np.array([[i, j] for i in range(n) for j in rng.choice(np.arange(i + 1, n), size=min(3, n - 1 - i), replace=False)])
+    w = rng.random(eid.shape[0])
+    unary = rng.random((n, K)) * 3
+    init = rng.integers(0, K, n)
+    V = R.potts_matrix(K, 1.0)
+    with pytest.warns(RuntimeWarning, match="general-graph moves only"):
+        lab = cut_general_graph(eid, w, unary, V, n_iter=5000, algorithm="swap", init_labels=init)
+    assert R.mrf_energy(lab, -unary, eid, w, 1.0)[0] <= R.mrf_energy(init, -unary, eid, w, 1.0)[0]
+    with pytest.raises(ValueError, match="not the stencil"):
+        cut_general_graph(eid, w, unary, V, n_iter=5000, algorithm="swap", init_labels=init, strict_grid=True)
+
+
+def test_fit_warns_when_a_region_is_not_a_grid_block():
+    import phylo_hmrf as cli
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    X, len_vec, edge_list_vec, tree = cli.synthetic_cache(20, 4, 3, 8, 2)
+    bad = [np.vstack([edge_list_vec[0], [[0.0, float(X.shape[0] - 1), 0.3]]])]      # one edge across the whole block
+    with pytest.warns(RuntimeWarning, match="general-graph moves only"):
+        m = phyloHMRF(n_components=3, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree,
+                      len_vec=len_vec, type_id=1, branch_list=[1.0] * 7, edge_list_1=bad, cons_param=1.0, beta=1.0,
+                      beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0,
+                      estimate_type=3, random_state=1, quiet=True, mstep_workers=1)
+    assert m.general_graph_regions == [0]
+    m.close()
+    with pytest.raises(ValueError, match="at most 8 species"):
+        phyloHMRF(n_components=3, run_id=0, n_samples=4, n_features=9, observation=np.zeros((4, 9)), edge_list=tree,
+                  len_vec=[[4, 0, 4, 2, 2, 0, 0, 0, 0, 1]], type_id=1, branch_list=[1.0] * 7, edge_list_1=[np.zeros((0, 3))],
+                  cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1,
+                  initial_magnitude=1.0)
+
+
+def test_cli_runs_from_raw_hic_text(tmp_path):
+    """Row f4: `python phylo_hmrf.py -n 6 --chromvec 22 -p <dir>` on example_input-style raw files (a 120-bin window of
+    the example's chr22 rows, tests/golden/example_loader.npz) -> cache files + the .mat."""
+    import phylo_hmrf as cli
+    from tests.test_preprocess import SPECIES, _write_dir
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_loader.npz"))
+    d, flist = _write_dir(tmp_path, g, "22", int(g["first_bin"]), 120, 0, g["a_synteny"])
+    with open(os.path.join(d, "edge.1.txt"), "w") as f:
+        f.write("0\t1\n1\t2\n1\t3\n3\t4\n4\t5\n4\t6\n3\t7\n")
+    with open(os.path.join(d, "branch_length.1.txt"), "w") as f:
+        f.write("0\t32\t20\t6\t6\t6\t12\n")
+    with open(os.path.join(d, "species_name.1.txt"), "w") as f:
+        f.write("\n".join(SPECIES) + "\n")
+    with open(os.path.join(d, "path_list.txt"), "w") as f:
+        f.write("\n".join("hic_" + s for s in SPECIES) + "\n")
+    out = os.path.join(d, "out")
+    cwd = os.getcwd()
+    os.chdir(d)                                   # chrom_quantile_test.txt goes to the working directory (:1659-1661)
+    try:
+        o = cli.parse_args(["-n", "6", "-r", "1", "--miter", "4", "--chromvec", "22", "-p", d, "--output", out, "-g", "3",
+                            "--seed", "4", "--quiet", "1", "--filter_mode", "0"])
+        mat = cli.run(o.num_states, o.chromvec, o.root_path, o.multiple, o.species_name, o.sort_states, o.run_id,
+                      o.cons_param, o.method_mode, o.initial_mode, o.initial_weight, o.initial_weight1,
+                      o.initial_magnitude, o.position1, o.position2, o.filter_sigma, o.beta, o.beta1, o.num_neighbor,
+                      o.filter_mode, o.threshold, o.estimate_type, o.simu_version, o.annotation, o.reload, o.dtype,
+                      o.miter, o.resolution, o.quantile, o.ref_species, o.output, seed=o.seed, quiet=o.quiet)
+    finally:
+        os.chdir(cwd)
+    samples, len_vec, edge_list_vec = cli.load_cache(out, 50000, 1)
+    assert np.array_equal(samples, g["a_diffusion_samples"]) and np.array_equal(len_vec, g["a_diffusion_lenvec"])
+    assert os.path.exists(os.path.join(d, "chrom_quantile_test.txt"))
+    dm = scipy.io.loadmat(mat)
+    assert dm["state_vec"].size == samples.shape[0] and np.all(np.isfinite(dm["cost_vec"]))
