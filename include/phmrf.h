@@ -124,6 +124,11 @@ typedef struct phmrf_solve_opts {
   int use_expansion;   /* 1: strip alpha-expansion sweeps (one per label and orientation) whenever the cheaper
                           moves have gone quiet; the solve ends when such a sweep is quiet too                  */
   int min_changed;     /* a round that changes at most this many labels counts as quiet (default 0)             */
+  int use_coarse;      /* 1: coarse alpha-expansions (super-cells of 2 x 2, 4 x 4 and 8 x 8 nodes switch to a label as a whole,
+                          solved exactly on 5 x 63 windows of super-cells by the strip kernel; needs the grid).  They
+                          run in verification rounds and while the labelling is still moving at large (the previous
+                          round changed at least 5 % of the labels: cold or far-off starts); a solve that moved that
+                          much does not stop on the tolerance before they have had a last say                     */
   int energy_tol_ppb;  /* > 0: stop as soon as a round lowers the energy by less than this many parts per billion
                           of |E| (no verification round).  Move types whose last runs were, taken together, worth at
                           most a quarter of that are rested meanwhile, so what a tolerance stop leaves undone in one
@@ -157,6 +162,16 @@ PHMRF_API int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* ch
  * alpha (strip alpha-expansion); alpha < 0: every node may keep its label or take its best alternative label. */
 PHMRF_API int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, int alpha,
                                    int64_t* changed);
+/* One coarse alpha-expansion (coarse.hip): super-cells of scale x scale nodes (scale in {2, 4, 8}; super-cell of node
+ * (i, j) = ((i + offset) / scale, (j + offset) / scale), 0 <= offset < scale) keep their labels or switch to alpha as a
+ * whole; the two-label problem of the super-cells is solved by one strip pass per orientation (shift_r, shift_c as in
+ * phmrf_mrf_strip_pass).  Never raises the energy. */
+PHMRF_API int phmrf_mrf_coarse_pass(phmrf_block_t b, double beta, int scale, int offset, int alpha, int shift_r, int shift_c,
+                                    int64_t* changed);
+/* The coarse problem itself (tests): *nc super-cells; D_out[nc] = cost of switching a super-cell alone (beta folded in),
+ * lam_out[nc,4] = weights of its forward pairs (E, SW, S, SE; without beta).  Outputs may be NULL. */
+PHMRF_API int phmrf_block_coarse_problem(phmrf_block_t b, double beta, int scale, int offset, int alpha, int64_t* nc,
+                                         float* D_out, float* lam_out);
 PHMRF_API int phmrf_mrf_energy(phmrf_block_t b, double beta, double* e_total, double* e_unary, double* e_pair);
 
 /* ---- b3: posteriors, costs, sufficient statistics ------------------------------------------- */
@@ -185,11 +200,25 @@ PHMRF_API int phmrf_kmeans_step(phmrf_block_t b, const double* centers /* [K,S] 
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
- * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip, 7 propose. */
-#define PHMRF_NUM_KERNEL_CLASSES 8
+ * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip, 7 propose,
+ * 8 coarse (coarse alpha-expansions: coarsen + strip kernels on the super-cell grid + apply). */
+#define PHMRF_NUM_KERNEL_CLASSES 9
 PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
-PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[8]*/, int64_t* launches /*[8]*/);
+PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[9]*/, int64_t* launches /*[9]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
+/* Work the strip kernels (class 6) actually did since the last reset, counted ON THE DEVICE (a launch inside a solve
+ * walks a work list of the strips whose inputs changed; the rest of the block costs it nothing):
+ *   out[0] strips staged (one unit = one strip under one move: alpha-expansion or fusion)
+ *   out[1] their strip cells (the nodes a unit re-decides: 5 x columns)
+ *   out[2] grid cells staged (strip + fixed rim, 7 x (columns + 2): what a unit reads from HBM)
+ *   out[3] DP steps walked (one 64-state step = one cell of one unit)   out[4] strip launches                      */
+PHMRF_API int phmrf_block_get_work(phmrf_block_t b, int64_t* out /*[5]*/);
+/* The timed intervals of one kernel class on a time base common to all blocks of the calling thread's device
+ * (phmrf_time_base_reset marks t = 0; call it before the timed region): out = [start_ms, end_ms] pairs, at most
+ * `capacity` of them; *count = how many there are.  Blocks run on their own streams, so their intervals overlap:
+ * merging them gives the time during which at least one kernel of the class was running. */
+PHMRF_API int phmrf_time_base_reset(void);
+PHMRF_API int phmrf_block_get_intervals(phmrf_block_t b, int kclass, double* out, int64_t capacity, int64_t* count);
 
 #ifdef __cplusplus
 }

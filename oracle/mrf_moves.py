@@ -392,3 +392,86 @@ def strip_fusion(g, unary, labels, prop, beta, H, W, diagonal, orient, shift_r, 
     ch = int(((newlab != labv) & valid).sum())
     labels[nodes[valid]] = newlab[valid]
     return ch
+
+
+# ------------------------------------------------------------------------------------------------
+# coarse alpha-expansion (model of phylo_hmrf_amd/csrc/coarse.hip)
+# ------------------------------------------------------------------------------------------------
+def coarse_problem(g, unary, labels, beta, H, W, diagonal, s, off, alpha):
+    """Super-cells of s x s nodes (super-cell of node (i, j) = ((i + off) // s, (j + off) // s)) keep their labels or
+    switch to alpha as a whole:  dE(x) = sum_A D_A x_A + beta * sum_AB lam_AB [x_A != x_B].
+    -> (D[nc] with beta folded in, lam[nc,4] forward pair weights E, SW, S, SE (without beta), cnode[n] super-cell of each
+        node, Hc, Wc).  Coarse node ids follow the fine layout (row-major; upper triangle row-major for a diagonal block)."""
+    ii, jj = grid_coords(H, W, diagonal)
+    I, J = (ii + off) // s, (jj + off) // s
+    Hc, Wc = (H - 1 + off) // s + 1, (W - 1 + off) // s + 1
+    cnode = (I * Wc - (I * (I - 1)) // 2 + (J - I)) if diagonal else I * Wc + J
+    nc = Hc * (Hc + 1) // 2 if diagonal else Hc * Wc
+    lab = np.asarray(labels, dtype=np.int64)
+    n = g.n
+    D = np.bincount(cnode, weights=unary[np.arange(n), alpha] - unary[np.arange(n), lab], minlength=nc)
+    a, b = g.edge_ids[:, 0], g.edge_ids[:, 1]
+    la, lb = lab[a], lab[b]
+    t00, t01, t10 = g.w * (la != lb), g.w * (la != alpha), g.w * (alpha != lb)
+    ca, cb = cnode[a], cnode[b]
+    same = ca == cb
+    D -= beta * np.bincount(ca[same], weights=t00[same], minlength=nc)
+    x = ~same
+    lv = 0.5 * (t10[x] + t01[x] - t00[x])
+    D += beta * (np.bincount(ca[x], weights=t10[x] - t00[x] - lv, minlength=nc) +
+                 np.bincount(cb[x], weights=t01[x] - t00[x] - lv, minlength=nc))
+    lam = np.zeros((nc, 4))
+    dI, dJ = I[b[x]] - I[a[x]], J[b[x]] - J[a[x]]
+    # the pair's slot belongs to the upper / left super-cell: E (0,1) -> 0, SW (1,-1) -> 1, S (1,0) -> 2, SE (1,1) -> 3;
+    # a fine edge whose far end lies in the previous coarse column of the same coarse row is the E pair of that one
+    fwd = ~((dI == 0) & (dJ == -1))
+    slot = np.where(dI == 0, 0, 2 + dJ)
+    np.add.at(lam, (ca[x][fwd], slot[fwd]), lv[fwd])
+    np.add.at(lam, (cb[x][~fwd], 0), lv[~fwd])
+    return D, lam, cnode, Hc, Wc
+
+
+def coarse_cross_weight(g, H, W, diagonal, s, off):
+    """Total weight of the fine edges that leave each super-cell: a super-cell with D > beta * this is in no optimal switch
+    set (lambda <= w on every cross edge), the kernel pins it."""
+    ii, jj = grid_coords(H, W, diagonal)
+    I, J = (ii + off) // s, (jj + off) // s
+    Wc = (W - 1 + off) // s + 1
+    Hc = (H - 1 + off) // s + 1
+    cnode = (I * Wc - (I * (I - 1)) // 2 + (J - I)) if diagonal else I * Wc + J
+    nc = Hc * (Hc + 1) // 2 if diagonal else Hc * Wc
+    a, b = g.edge_ids[:, 0], g.edge_ids[:, 1]
+    x = cnode[a] != cnode[b]
+    return np.bincount(cnode[a][x], weights=g.w[x], minlength=nc) + np.bincount(cnode[b][x], weights=g.w[x], minlength=nc)
+
+
+def coarse_expansion(g, unary, labels, beta, H, W, diagonal, s, off, alpha, shift_r=0, shift_c=0):
+    """One coarse alpha-expansion: the super-cell problem solved by one strip pass per orientation (strip_fusion on the
+    coarse grid, all super-cells start at 'keep'), then applied.  In place; returns the number of changed nodes."""
+    D, lam, cnode, Hc, Wc = coarse_problem(g, unary, labels, beta, H, W, diagonal, s, off, alpha)
+    nc = D.shape[0]
+    ci, cj = grid_coords(Hc, Wc, diagonal)
+    if diagonal:
+        idmap = -np.ones((Hc, Wc), dtype=np.int64)
+        idmap[ci, cj] = np.arange(nc)
+    else:
+        idmap = np.arange(nc).reshape(Hc, Wc)
+    e, w = [], []
+    for q, (di, dj) in enumerate(((0, 1), (1, -1), (1, 0), (1, 1))):
+        i2, j2 = ci + di, cj + dj
+        ok = (i2 < Hc) & (j2 >= 0) & (j2 < Wc)
+        ok[ok] &= idmap[i2[ok], j2[ok]] >= 0
+        src = np.flatnonzero(ok)
+        e.append(np.stack([src, idmap[i2[src], j2[src]]], 1))
+        w.append(lam[src, q])
+    e, w = np.concatenate(e), np.concatenate(w)
+    keep = w != 0
+    gc = Graph(nc, e[keep], w[keep])
+    uc = np.stack([np.zeros(nc), D], 1)
+    xl = np.zeros(nc, dtype=np.int64)
+    strip_fusion(gc, uc, xl, np.ones(nc, dtype=np.int64), beta, Hc, Wc, diagonal, 0, shift_r % 6, shift_c % 64)
+    strip_fusion(gc, uc, xl, np.ones(nc, dtype=np.int64), beta, Hc, Wc, diagonal, 1, (shift_r + 3) % 6, (shift_c + 31) % 64)
+    lab = np.asarray(labels)
+    sel = (xl[cnode] == 1) & (lab != alpha)
+    labels[sel] = alpha
+    return int(sel.sum())

@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
-NUM_KERNEL_CLASSES = 8
-KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose")
+NUM_KERNEL_CLASSES = 9
+KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose", "coarse")
 
 
 class PhmrfError(RuntimeError):
@@ -22,7 +22,7 @@ class PhmrfError(RuntimeError):
 class SolveOpts(ctypes.Structure):
     _fields_ = [("max_rounds", ctypes.c_int), ("use_chains", ctypes.c_int), ("use_components", ctypes.c_int),
                 ("init_mode", ctypes.c_int), ("use_strips", ctypes.c_int), ("use_expansion", ctypes.c_int),
-                ("min_changed", ctypes.c_int), ("energy_tol_ppb", ctypes.c_int)]
+                ("min_changed", ctypes.c_int), ("use_coarse", ctypes.c_int), ("energy_tol_ppb", ctypes.c_int)]
 
 
 class SolveResult(ctypes.Structure):
@@ -76,12 +76,17 @@ SIGNATURES = {
     "phmrf_mrf_component_pass": [_vp, _d, _lp],
     "phmrf_mrf_strip_pass": [_vp, _d, _i, _i, _i, _i, _lp],
     "phmrf_mrf_energy": [_vp, _d, _dp, _dp, _dp],
+    "phmrf_mrf_coarse_pass": [_vp, _d, _i, _i, _i, _i, _i, _lp],
+    "phmrf_block_coarse_problem": [_vp, _d, _i, _i, _i, _lp, _fp, _fp],
     "phmrf_posterior_stats": [_vp, _d, _i, _dp, _dp, _dp],
     "phmrf_posterior_stats_dev": [_vp, _d, _i, _vp],
     "phmrf_kmeans_step": [_vp, _dp, _i, _dp],
     "phmrf_block_enable_timing": [_vp, _i],
     "phmrf_block_get_timing": [_vp, _dp, _lp],
     "phmrf_block_reset_timing": [_vp],
+    "phmrf_block_get_work": [_vp, _lp],
+    "phmrf_time_base_reset": [],
+    "phmrf_block_get_intervals": [_vp, _i, _dp, _i64, _lp],
 }
 _RESTYPES = {"phmrf_last_error": ctypes.c_char_p, "phmrf_status_string": ctypes.c_char_p}
 

@@ -108,19 +108,19 @@ class Block(object):
 
     # -- b2 ---------------------------------------------------------------------------------------
     def solve(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
-              use_expansion=True, min_changed=0, energy_tol_ppb=0):
+              use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True):
         o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
-                      int(use_expansion), int(min_changed), int(energy_tol_ppb))
+                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb))
         r = SolveResult()
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), ctypes.byref(r)))
         return dict(energy=r.energy, energy_unary=r.energy_unary, energy_pair=r.energy_pair,
                     energy_init=r.energy_init, rounds=r.rounds, converged=bool(r.converged), changed=r.changed)
 
     def solve_fast(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
-                   use_expansion=True, min_changed=0, energy_tol_ppb=0):
+                   use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True):
         """Same without the two energy evaluations."""
         o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
-                      int(use_expansion), int(min_changed), int(energy_tol_ppb))
+                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb))
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), None))
 
     def icm_sweep(self, beta):
@@ -143,6 +143,24 @@ class Block(object):
         check(self._L.phmrf_mrf_strip_pass(self._h, float(beta), int(orient), int(shift_r), int(shift_c), int(alpha),
                                            ctypes.byref(c)))
         return c.value
+
+    def coarse_pass(self, beta, scale, offset, alpha, shift_r=0, shift_c=0):
+        c = ctypes.c_int64(0)
+        check(self._L.phmrf_mrf_coarse_pass(self._h, float(beta), int(scale), int(offset), int(alpha), int(shift_r),
+                                            int(shift_c), ctypes.byref(c)))
+        return c.value
+
+    def coarse_problem(self, beta, scale, offset, alpha):
+        """-> (D[nc], lam[nc,4]) of the super-cell problem (tests)."""
+        nc = ctypes.c_int64(0)
+        check(self._L.phmrf_block_coarse_problem(self._h, float(beta), int(scale), int(offset), int(alpha), ctypes.byref(nc),
+                                                 None, None))
+        D = np.zeros(nc.value, dtype=np.float32)
+        lam = np.zeros((nc.value, 4), dtype=np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        check(self._L.phmrf_block_coarse_problem(self._h, float(beta), int(scale), int(offset), int(alpha), ctypes.byref(nc),
+                                                 D.ctypes.data_as(fp), lam.ctypes.data_as(fp)))
+        return D, lam
 
     def energy(self, beta):
         e, eu, ep = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
@@ -188,6 +206,27 @@ class Block(object):
         ln = (ctypes.c_int64 * _lib.NUM_KERNEL_CLASSES)()
         check(self._L.phmrf_block_get_timing(self._h, ms, ln))
         return {name: (ms[i], ln[i]) for i, name in enumerate(_lib.KERNEL_CLASSES)}
+
+    def work(self):
+        """Device-counted work of the strip kernels since reset_timing."""
+        out = (ctypes.c_int64 * 5)()
+        check(self._L.phmrf_block_get_work(self._h, out))
+        return dict(units=out[0], cells=out[1], staged_cells=out[2], dp_steps=out[3], launches=out[4])
+
+    def intervals(self, kernel_class):
+        """[start_ms, end_ms] of every timed interval of the class, on the device's common time base -> array [m,2]."""
+        k = _lib.KERNEL_CLASSES.index(kernel_class)
+        cnt = ctypes.c_int64(0)
+        check(self._L.phmrf_block_get_intervals(self._h, k, None, 0, ctypes.byref(cnt)))
+        out = np.zeros((cnt.value, 2), dtype=np.float64)
+        if cnt.value:
+            check(self._L.phmrf_block_get_intervals(self._h, k, ptr_d(out), cnt.value, ctypes.byref(cnt)))
+        return out
+
+
+def time_base_reset():
+    """t = 0 of the interval time line of the current device (all blocks)."""
+    check(_lib.load().phmrf_time_base_reset())
 
 
 def unpack_stats(vec, K, S):

@@ -54,12 +54,21 @@ void toc(phmrf_block* b, int kclass, int n_launches) {
   b->cur_start = nullptr;
 }
 
+// One time base per device for all blocks: intervals of different blocks (streams) can be laid on one time line
+// (bench.py merges them: the time during which AT LEAST ONE kernel of a class was running).
+static hipEvent_t g_time_base[64] = {};
+
 static void resolve_timing(phmrf_block* b) {
   if (b->pending.empty()) return;
   (void)hipStreamSynchronize(b->stream);
+  hipEvent_t base = (b->device >= 0 && b->device < 64) ? g_time_base[b->device] : nullptr;
   for (auto& p : b->pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) b->ms[p.kclass] += ms;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      b->ms[p.kclass] += ms;
+      float t0 = 0.f;
+      if (base && hipEventElapsedTime(&t0, base, p.a) == hipSuccess) b->intervals.push_back({p.kclass, t0, t0 + ms});
+    }
     b->free_events.push_back(p.a);
     b->free_events.push_back(p.b);
   }
@@ -327,6 +336,11 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
   if (st == PHMRF_OK) guard(dev_alloc(&b->labels_tmp, (size_t)n));
   if (st == PHMRF_OK) guard(dev_alloc(&b->accum, (size_t)ACCUM_DOUBLES));
   if (st == PHMRF_OK) guard(dev_alloc(&b->counters, (size_t)128));
+  if (st == PHMRF_OK) guard(dev_alloc(&b->work_acc, (size_t)WORK_BANKS * 4));
+  if (st == PHMRF_OK && hipMemsetAsync(b->work_acc, 0, WORK_BANKS * 4 * sizeof(unsigned long long), b->own_stream) != hipSuccess)
+    guard(fail(PHMRF_ERR_HIP, "hipMemset failed"));
+  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->work_host), WORK_BANKS * 4 * sizeof(unsigned long long)) != hipSuccess)
+    guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
   if (st == PHMRF_OK) guard(dev_alloc(&b->emis_params, (size_t)K * (S + S * (S + 1) / 2 + 1)));
   if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->accum_host), ACCUM_DOUBLES * sizeof(double)) != hipSuccess)
     guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
@@ -349,6 +363,12 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
 int phmrf_block_destroy(phmrf_block_t b) {
   if (!b) return PHMRF_OK;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
+  for (int lv = 0; lv < 3; ++lv)
+    if (b->coarse[lv]) {
+      b->coarse[lv]->stream = b->coarse[lv]->own_stream;
+      phmrf_block_destroy(b->coarse[lv]);
+      b->coarse[lv] = nullptr;
+    }
   dev_free(b->X);
   dev_free(b->logprob);
   dev_free(b->labels);
@@ -378,6 +398,8 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->posteriors);
   dev_free(b->accum);
   dev_free(b->counters);
+  dev_free(b->work_acc);
+  if (b->work_host) (void)hipHostFree(b->work_host);
   if (b->accum_host) (void)hipHostFree(b->accum_host);
   if (b->counters_host) (void)hipHostFree(b->counters_host);
   for (auto& p : b->pending) {
@@ -397,6 +419,8 @@ int phmrf_block_set_stream(phmrf_block_t b, void* hip_stream) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   PHMRF_HIP(hipStreamSynchronize(b->stream));
   b->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : b->own_stream;
+  for (int lv = 0; lv < 3; ++lv)
+    if (b->coarse[lv]) b->coarse[lv]->stream = b->stream;
   return PHMRF_OK;
 }
 
@@ -731,6 +755,17 @@ static int zero_counter(phmrf_block_t b) {
   return PHMRF_OK;
 }
 
+// strip-kernel work counters: device banks -> host totals (the stream must be synchronised by the caller afterwards)
+static int work_fetch_async(phmrf_block_t b) {
+  PHMRF_HIP(hipMemcpyAsync(b->work_host, b->work_acc, WORK_BANKS * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * 4 * sizeof(unsigned long long), b->stream));
+  return PHMRF_OK;
+}
+static void work_fold(phmrf_block_t b) {
+  for (int k = 0; k < WORK_BANKS; ++k)
+    for (int q = 0; q < 4; ++q) b->work[q] += (int64_t)b->work_host[k * 4 + q];
+}
+
 static int check_solvable(phmrf_block_t b) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   PHMRF_CHECK(b->has_graph, PHMRF_ERR_STATE, "graph not set");
@@ -827,6 +862,7 @@ static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift
   if (timed) tic(b);
   if (b->tick) ++b->tick;
   PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, use_mask, geom));
+  b->work[4] += 1;
   if (timed) toc(b, KC_STRIP, 1);
   return PHMRF_OK;
 }
@@ -840,9 +876,98 @@ int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, 
   PHMRF_CHECK(alpha < b->K, PHMRF_ERR_INVALID, "alpha must be < K");
   PHMRF_TRY(zero_counter(b));
   PHMRF_TRY(strip_pass_nocount(b, (float)beta, orient, shift_r, shift_c, alpha));
+  PHMRF_TRY(work_fetch_async(b));
+  int64_t ch = 0;
+  PHMRF_TRY(read_counter(b, &ch));
+  work_fold(b);
+  if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
+// ---- coarse alpha-expansions (coarse.hip) ----------------------------------------------------------------------
+static const int N_COARSE = 3;
+static const int COARSE_SCALE[N_COARSE] = {2, 4, 8};
+static const int64_t COARSE_ON_DIV = 20;      // "moving at large": a round / a solve changed >= 1/20 of the labels
+
+static int coarse_child(phmrf_block_t b, int level, phmrf_block** out) {
+  if (!b->coarse[level]) {
+    const int s = COARSE_SCALE[level];
+    const int64_t nmax = coarse_nodes(b, s, s - 1);
+    phmrf_block* c = nullptr;
+    PHMRF_TRY(phmrf_block_create(nmax, 1, 2, &c));
+    int st = dev_alloc(&c->fwd_w, (size_t)nmax);
+    if (st == PHMRF_OK) st = dev_alloc(&c->uT, (size_t)2 * nmax);
+    if (st != PHMRF_OK) {
+      phmrf_block_destroy(c);
+      return st;
+    }
+    c->uT_valid = true;
+    c->has_grid = true;
+    c->has_graph = true;
+    c->has_logprob = true;
+    c->D = 0;
+    b->coarse[level] = c;
+  }
+  b->coarse[level]->stream = b->stream;
+  b->coarse[level]->num_neighbor = b->num_neighbor;
+  *out = b->coarse[level];
+  return PHMRF_OK;
+}
+
+// every label alpha of `labels_mask` once at one scale / offset: coarsen -> one strip pass per orientation on the
+// super-cell grid -> apply.  4 launches per label.
+static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off, int shift_r, int shift_c, int alpha_lo,
+                                int alpha_hi) {
+  phmrf_block* c = nullptr;
+  PHMRF_TRY(coarse_child(b, level, &c));
+  const int s = COARSE_SCALE[level];
+  if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
+  tic(b);
+  int n_launch = 0;
+  for (int a = alpha_lo; a < alpha_hi; ++a) {
+    PHMRF_TRY(launch_coarsen(b, c, s, off, a, beta));
+    PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, false, -1));
+    PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, false, -1));
+    if (b->tick) ++b->tick;
+    PHMRF_TRY(launch_coarse_apply(b, c, s, off, a));
+    n_launch += 4;
+  }
+  toc(b, KC_COARSE, n_launch);
+  return PHMRF_OK;
+}
+
+int phmrf_mrf_coarse_pass(phmrf_block_t b, double beta, int scale, int offset, int alpha, int shift_r, int shift_c,
+                          int64_t* changed) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "coarse moves need phmrf_block_set_grid");
+  PHMRF_CHECK(scale == 2 || scale == 4 || scale == 8, PHMRF_ERR_INVALID, "scale must be 2, 4 or 8");
+  PHMRF_CHECK(offset >= 0 && offset < scale, PHMRF_ERR_INVALID, "offset must be in [0, scale)");
+  PHMRF_CHECK(alpha >= 0 && alpha < b->K, PHMRF_ERR_INVALID, "alpha must be in [0, K)");
+  PHMRF_CHECK(shift_r >= 0 && shift_r <= 5 && shift_c >= 0 && shift_c <= 63, PHMRF_ERR_INVALID, "shift out of range");
+  PHMRF_TRY(zero_counter(b));
+  PHMRF_TRY(coarse_sweep_nocount(b, (float)beta, scale == 2 ? 0 : (scale == 4 ? 1 : 2), offset, shift_r, shift_c, alpha, alpha + 1));
   int64_t ch = 0;
   PHMRF_TRY(read_counter(b, &ch));
   if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
+int phmrf_block_coarse_problem(phmrf_block_t b, double beta, int scale, int offset, int alpha, int64_t* nc, float* D_out,
+                               float* lam_out) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(nc, PHMRF_ERR_INVALID, "nc is NULL");
+  PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "coarse moves need phmrf_block_set_grid");
+  PHMRF_CHECK(scale == 2 || scale == 4 || scale == 8, PHMRF_ERR_INVALID, "scale must be 2, 4 or 8");
+  PHMRF_CHECK(offset >= 0 && offset < scale, PHMRF_ERR_INVALID, "offset must be in [0, scale)");
+  PHMRF_CHECK(alpha >= 0 && alpha < b->K, PHMRF_ERR_INVALID, "alpha must be in [0, K)");
+  *nc = coarse_nodes(b, scale, offset);
+  if (!D_out && !lam_out) return PHMRF_OK;
+  phmrf_block* c = nullptr;
+  PHMRF_TRY(coarse_child(b, scale == 2 ? 0 : (scale == 4 ? 1 : 2), &c));
+  if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
+  PHMRF_TRY(launch_coarsen(b, c, scale, offset, alpha, (float)beta));
+  if (D_out) PHMRF_TRY(download(D_out, c->uT + *nc, (size_t)*nc * sizeof(float), b->stream));
+  if (lam_out) PHMRF_TRY(download(lam_out, c->fwd_w, (size_t)*nc * sizeof(float4), b->stream));
   return PHMRF_OK;
 }
 
@@ -855,6 +980,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   o.use_components = 1;
   o.use_strips = 1;
   o.use_expansion = 1;
+  o.use_coarse = 1;
   if (opts) {
     o = *opts;
     if (o.max_rounds <= 0) o.max_rounds = 64;
@@ -886,6 +1012,15 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   }
   if (expansions)
     for (int a = 0; a < K; ++a) slots.push_back(8 + a);
+  // coarse alpha-expansions: slots 80 (2 x 2 super-cells), 81 (4 x 4), 82 (8 x 8)
+  const bool coarse = strips && o.use_coarse && b->H >= 4 && b->W >= 4;
+  if (coarse)
+    for (int lv = 0; lv < N_COARSE; ++lv) slots.push_back(80 + lv);
+  int64_t last_changed = 0;            // labels changed by the previous round
+  int64_t coarse_changed[N_COARSE] = {0, 0, 0};  // ... by the coarse scales in their last run
+  bool coarse_ran[N_COARSE] = {false, false, false};
+  bool force_coarse = false;           // the tolerance wants to stop, but the coarse scales have not had their say
+  bool coarse_checked = false;
   std::vector<char> active(128, 0);
   for (int sl : slots) active[sl] = 1;
   bool all_active = true;
@@ -1013,7 +1148,26 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         }
       }
     }
+    // coarse alpha-expansions: in verification rounds, and while the labelling is still moving at large (the previous
+    // round changed at least 0.5 % of the labels) -- a warm start that is nearly converged never pays for them
+    // Coarse scales switch on while the labelling is still moving at large (the previous round changed >= 5 % of the
+    // labels: a cold or far-off start; the warm start of a later EM iteration, which moves 1-3 %, does not pay for them).
+    // A scale that changed labels in its last run stays on (like every move type), with the super-cell grid shifted by
+    // one node per round; a verification round tries every shift of both scales.
+    if (coarse) {
+      for (int lv = 0; lv < N_COARSE; ++lv) {
+        const int s = COARSE_SCALE[lv];
+        const bool on = verifying || force_coarse || (active[80 + lv] && (last_changed * COARSE_ON_DIV >= b->n || coarse_changed[lv] > 0));
+        coarse_ran[lv] = on;
+        if (!on) continue;
+        b->counter_slot = 80 + lv;
+        for (int off = 0; off < s; ++off)
+          if (verifying || off == r % s)
+            PHMRF_TRY(coarse_sweep_nocount(b, bf, lv, off, (2 * r + lv + off) % 6, (17 * r + 5 * lv + 13 * off) % 64, 0, K));
+      }
+    }
     b->counter_slot = 0;
+    if (b->timing) PHMRF_TRY(work_fetch_async(b));
     PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                              b->stream));
     double eu = 0, ep = 0;
@@ -1022,6 +1176,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     int64_t ch = 0;
     for (int sl : slots) ch += (int64_t)b->counters_host[sl];
     total += ch;
+    last_changed = ch;
+    for (int lv = 0; lv < N_COARSE; ++lv)
+      if (coarse_ran[lv]) coarse_changed[lv] = (int64_t)b->counters_host[80 + lv];
+    if (b->timing) work_fold(b);
     ++rounds;
     const bool improved = std::isinf(e_prev) ? ch > 0 : e_now < e_prev - 1e-11 * std::fabs(e_prev);
     static const bool trace = getenv("PHMRF_SOLVE_TRACE") != nullptr;   // development aid (one block at a time)
@@ -1034,7 +1192,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         static double seen[PHMRF_NUM_KERNEL_CLASSES] = {};
         resolve_timing(b);
         fprintf(stderr, "[phmrf solve]   ms:");
-        static const char* NM[PHMRF_NUM_KERNEL_CLASSES] = {"emis", "icm", "chain", "comp", "energy", "post", "strip", "prop"};
+        static const char* NM[PHMRF_NUM_KERNEL_CLASSES] = {"emis", "icm", "chain", "comp", "energy", "post", "strip", "prop", "coarse"};
         for (int kc = 0; kc < PHMRF_NUM_KERNEL_CLASSES; ++kc) {
           fprintf(stderr, " %s %.2f", NM[kc], b->ms[kc] - seen[kc]);
           seen[kc] = b->ms[kc];
@@ -1054,7 +1212,23 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     // accepted tolerance: the round (all active types; the rested ones were worth at most a quarter of the tolerance
     // together, see below) gained less than the tolerance.  A round that RAISED the energy (f32 move arithmetic against
     // the f64 energy) is not "converged": it is quiet, and the verification round decides.
+    bool coarse_moved = false, coarse_just_ran = coarse;
+    for (int lv = 0; lv < N_COARSE; ++lv) {
+      coarse_moved = coarse_moved || (coarse && coarse_ran[lv] && coarse_changed[lv] > 0);
+      coarse_just_ran = coarse_just_ran && coarse_ran[lv];
+    }
+    if (coarse_moved) coarse_checked = false;
+    force_coarse = false;
     if (o.energy_tol_ppb > 0 && gain >= 0.0 && gain < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
+      // A solve that has moved the labelling at large (>= 5 % of the labels so far: a cold or far-off start, not the
+      // warm start of a later EM iteration) does not stop before the coarse scales have run once more and gained less
+      // than the tolerance, too: their gains come in few large steps, not in the trickle the tolerance watches.
+      if (coarse && !coarse_checked && !coarse_just_ran && total * COARSE_ON_DIV >= b->n) {
+        coarse_checked = true;
+        force_coarse = true;
+        for (int sl : slots) active[sl] = 1;
+        continue;
+      }
       converged = 1;
       break;
     }
@@ -1199,6 +1373,43 @@ int phmrf_block_reset_timing(phmrf_block_t b) {
     b->ms[i] = 0;
     b->launches[i] = 0;
   }
+  for (int q = 0; q < 5; ++q) b->work[q] = 0;
+  PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * 4 * sizeof(unsigned long long), b->stream));
+  b->intervals.clear();
+  return PHMRF_OK;
+}
+
+int phmrf_time_base_reset(void) {
+  int dev = 0;
+  PHMRF_HIP(hipGetDevice(&dev));
+  PHMRF_CHECK(dev >= 0 && dev < 64, PHMRF_ERR_UNSUPPORTED, "device index >= 64");
+  if (!g_time_base[dev]) PHMRF_HIP(hipEventCreate(&g_time_base[dev]));
+  PHMRF_HIP(hipDeviceSynchronize());
+  PHMRF_HIP(hipEventRecord(g_time_base[dev], nullptr));
+  PHMRF_HIP(hipEventSynchronize(g_time_base[dev]));
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_work(phmrf_block_t b, int64_t* out) {
+  PHMRF_CHECK(b && out, PHMRF_ERR_INVALID, "NULL argument");
+  for (int q = 0; q < 5; ++q) out[q] = b->work[q];
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_intervals(phmrf_block_t b, int kclass, double* out, int64_t capacity, int64_t* count) {
+  PHMRF_CHECK(b && count, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(kclass >= 0 && kclass < PHMRF_NUM_KERNEL_CLASSES, PHMRF_ERR_INVALID, "no such kernel class");
+  resolve_timing(b);
+  int64_t c = 0;
+  for (const auto& iv : b->intervals)
+    if (iv.kclass == kclass) {
+      if (out && c < capacity) {
+        out[2 * c] = iv.t0;
+        out[2 * c + 1] = iv.t1;
+      }
+      ++c;
+    }
+  *count = c;
   return PHMRF_OK;
 }
 

@@ -1,0 +1,210 @@
+// gfx950 kernels of the COARSE alpha-expansion: the 2-D block move of strip.hip applied to super-cells.
+//
+// Why: a strip is 5 grid rows tall.  A region that should change label as a whole but is taller than that in both
+// directions (an entire 20 x 30 rectangle of one of two near-identical states that the current labelling has merged
+// into its surroundings) cannot be reached by strips: every 5-row slice of it pays two long new boundaries for a thin
+// gain, while a 10-row slab already wins.  gco's alpha-beta swap re-partitions such a region in one global cut
+// (GCoptimization.cpp:1372-1394); the fine moves alone leave it standing (measured on the 2,001,000-node block of
+// BASELINE configs[1]: +7e-4 of energy, all of it in ~100 such regions).
+//
+// What: tile the grid into s x s SUPER-CELLS (s = 2, 4, 8; shifted by an offset that changes from round to round).  For a
+// label alpha every super-cell either keeps its labels or switches ALL its nodes to alpha.  That is again a binary
+// pairwise problem on an 8-neighbour grid -- of the super-cells -- and because alpha-expansion tables are submodular
+// for a Potts model it can be written with one switch cost D_A per super-cell and one non-negative weight lambda_AB per
+// pair of adjacent super-cells:
+//     dE(x) = sum_A D_A x_A + beta * sum_AB lambda_AB [x_A != x_B],            x_A in {keep, switch}
+// Every fine edge (i, j) with table t00 = w[l_i != l_j], t01 = w[l_i != alpha] (j switches), t10 = w[alpha != l_j]
+// (i switches), t11 = 0 contributes: inside one super-cell -t00 to its D; across two super-cells
+// lambda = (t10 + t01 - t00) / 2 >= 0 to their pair, t10 - t00 - lambda to the D of i's super-cell and t01 - t00 - lambda
+// to the D of j's.  The coarse problem IS a two-label Potts block (unary 0 / D_A, weights lambda), so it is handed to
+// the SAME strip kernel (strip.hip, K = 2, alpha = 1, labels all 0) on a small child block: exact on 5 x 63 windows of
+// super-cells = 10..20 rows x 126..252 columns of nodes.  Its energy never goes above 0 = "nobody switches", so the
+// fine labelling's energy never goes up.  (Model: oracle/mrf_moves.coarse_problem / coarse_expansion.)
+
+#include "common.h"
+
+namespace phmrf {
+namespace {
+
+struct CoarseGeom {
+  int H, W, diagonal;    // fine grid
+  int s, off;            // super-cell side; super-cell index of fine (i, j) = ((i + off) / s, (j + off) / s)
+  int Hc, Wc;            // coarse grid
+};
+
+__device__ __forceinline__ int fine_node(const CoarseGeom& g, int i, int j) {
+  if (i < 0 || i >= g.H || j < 0 || j >= g.W) return -1;
+  if (g.diagonal) {
+    if (i > j) return -1;
+    return i * g.W - (i * (i - 1)) / 2 + (j - i);
+  }
+  return i * g.W + j;
+}
+
+__device__ __forceinline__ int coarse_node(const CoarseGeom& g, int I, int J) {
+  if (g.diagonal) return I * g.Wc - (I * (I - 1)) / 2 + (J - I);
+  return I * g.Wc + J;
+}
+
+__device__ __forceinline__ float comp4(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// D (switch cost, beta folded in) and the four forward coarse weights (E, SW, S, SE; without beta, like fwd_w) of every
+// super-cell.  A wavefront covers 64 consecutive grid columns of the s grid rows of one coarse row: lane <-> column, so
+// every load is a coalesced row segment (labels, forward weights and unary planes of the row itself and of the rows
+// above / below), and the s x s nodes of a super-cell are s adjacent lanes x s loop trips: their sums meet in an
+// s-lane butterfly.  A cross edge is seen from both of its super-cells: each adds its own unary share, the one the
+// pair's slot belongs to adds lambda.  No atomics.
+template <int SCALE>
+__global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, int64_t nc, const uint8_t* __restrict__ labels,
+                                                      const float* __restrict__ uT, const float4* __restrict__ fwd_w,
+                                                      int alpha, float beta, float* __restrict__ c_uT,
+                                                      float4* __restrict__ c_fwd, uint8_t* __restrict__ c_labels) {
+  const int I = blockIdx.y;
+  const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x) - g.off;      // (j + off) % SCALE == lane % SCALE
+  const int J = (int)(blockIdx.x * blockDim.x + threadIdx.x) / SCALE;
+  constexpr int FI[4] = {0, 1, 1, 1};
+  constexpr int FJ[4] = {1, -1, 0, 1};
+  float D = 0.f, lam[4] = {0.f, 0.f, 0.f, 0.f};
+  float wcross = 0.f;                       // total weight of the fine edges that leave the super-cell
+#pragma unroll
+  for (int di = 0; di < SCALE; ++di) {
+    const int i = I * SCALE - g.off + di;
+    const int node = fine_node(g, i, j);
+    if (node < 0) continue;
+    const int li = labels[node];
+    if (li != alpha) D += uT[(int64_t)alpha * n + node] - uT[(int64_t)li * n + node];
+    const float4 fw = fwd_w[node];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {           // edges this node holds
+      const float w = comp4(fw, e);
+      if (w == 0.f) continue;
+      const int ni = i + FI[e], nj = j + FJ[e];
+      const int nn = fine_node(g, ni, nj);
+      if (nn < 0) continue;
+      const int lj = labels[nn];
+      const float t00 = (li != lj) ? w : 0.f, t01 = (li != alpha) ? w : 0.f, t10 = (alpha != lj) ? w : 0.f;
+      const int dI = (ni + g.off) / SCALE - I, dJ = (nj + g.off) / SCALE - J;
+      if (dI == 0 && dJ == 0) {
+        D -= beta * t00;
+      } else {
+        const float lv = 0.5f * (t10 + t01 - t00);
+        D += beta * (t10 - t00 - lv);
+        wcross += w;
+        if (dI == 0 && dJ == 1) lam[0] += lv;
+        else if (dI == 1) lam[2 + dJ] += lv;           // SW (dJ -1) -> 1, S -> 2, SE -> 3
+        // (dI == 0, dJ == -1): the pair's slot is the E slot of the other super-cell, which adds it below
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {           // edges held by the four backward neighbours
+      const int ni = i - FI[e], nj = j - FJ[e];
+      if (ni < 0 || nj < 0) continue;
+      const int dI = (ni + g.off) / SCALE - I, dJ = (nj + g.off) / SCALE - J;
+      if (dI == 0 && dJ == 0) continue;               // inside this super-cell: counted from the holder
+      const int nn = fine_node(g, ni, nj);
+      if (nn < 0) continue;
+      const float w = comp4(fwd_w[nn], e);
+      if (w == 0.f) continue;
+      const int lj = labels[nn];                      // holder nn = "i" of the table, this node = "j"
+      const float t00 = (lj != li) ? w : 0.f, t01 = (lj != alpha) ? w : 0.f, t10 = (alpha != li) ? w : 0.f;
+      const float lv = 0.5f * (t10 + t01 - t00);
+      D += beta * (t01 - t00 - lv);
+      wcross += w;
+      if (dI == 0 && dJ == 1) lam[0] += lv;            // the holder sits in my E neighbour (a fine SW edge)
+    }
+  }
+  // the SCALE columns of a super-cell are SCALE adjacent lanes (fixed summation tree: deterministic)
+#pragma unroll
+  for (int m = 1; m < SCALE; m <<= 1) {
+    D += __shfl_xor(D, m, 64);
+    wcross += __shfl_xor(wcross, m, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lam[q] += __shfl_xor(lam[q], m, 64);
+  }
+  if ((threadIdx.x & (SCALE - 1)) != 0 || J >= g.Wc || (g.diagonal && J < I)) return;
+  const int c = coarse_node(g, I, J);
+  c_uT[c] = 0.f;
+  // A super-cell whose switch cost exceeds everything its pairs could give back (lambda <= w on every cross edge) is in
+  // no optimal switch set: taking it out of any set lowers the energy.  It is pinned (strip.hip: unary >= 1e29 = no
+  // proposal), and a strip of pinned super-cells costs the strip kernel its staging only.
+  c_uT[nc + c] = (D > beta * wcross * 1.0001f + 1e-6f) ? 1.0e30f : D;
+  c_fwd[c] = make_float4(lam[0], lam[1], lam[2], lam[3]);
+  c_labels[c] = 0;
+}
+
+// One thread per fine node: take alpha where the node's super-cell switched.
+__global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const uint8_t* __restrict__ c_labels, int alpha,
+                                                           uint8_t* __restrict__ labels, uint16_t* __restrict__ stamp, int tick,
+                                                           const int32_t* __restrict__ nbr, int D,
+                                                           unsigned long long* __restrict__ changed) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y * blockDim.y + threadIdx.y;
+  bool moved = false;
+  const int node = fine_node(g, i, j);
+  if (node >= 0) {
+    const int c = coarse_node(g, (i + g.off) / g.s, (j + g.off) / g.s);
+    if (c_labels[c] && labels[node] != alpha) {
+      labels[node] = (uint8_t)alpha;
+      if (stamp) {
+        stamp[node] = (uint16_t)tick;
+        const int32_t* nb = nbr + (int64_t)node * D;
+        for (int x = 0; x < D; ++x)
+          if (nb[x] >= 0) stamp[nb[x]] = (uint16_t)tick;
+      }
+      moved = true;
+    }
+  }
+  const unsigned long long m = __ballot(moved);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(changed, (unsigned long long)__popcll(m));
+}
+
+}  // namespace
+
+static CoarseGeom make_coarse_geom(const phmrf_block* b, int s, int off) {
+  CoarseGeom g;
+  g.H = b->H;
+  g.W = b->W;
+  g.diagonal = b->diagonal;
+  g.s = s;
+  g.off = off;
+  g.Hc = (b->H - 1 + off) / s + 1;
+  g.Wc = (b->W - 1 + off) / s + 1;
+  return g;
+}
+
+int64_t coarse_nodes(const phmrf_block* b, int s, int off) {
+  const CoarseGeom g = make_coarse_geom(b, s, off);
+  return g.diagonal ? (int64_t)g.Hc * (g.Hc + 1) / 2 : (int64_t)g.Hc * g.Wc;
+}
+
+// Point the child block at the coarse grid of (s, off) and fill its unary planes / forward weights / labels for alpha.
+int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta) {
+  const CoarseGeom g = make_coarse_geom(b, s, off);
+  child->H = g.Hc;
+  child->W = g.Wc;
+  child->diagonal = g.diagonal;
+  child->n = coarse_nodes(b, s, off);
+  const dim3 blk(256), grd((g.Wc * s + 255) / 256, g.Hc);
+  if (s == 2)
+    hipLaunchKernelGGL(coarsen_kernel<2>, grd, blk, 0, b->stream, g, b->n, child->n, b->labels, b->uT, b->fwd_w, alpha, beta,
+                       child->uT, child->fwd_w, child->labels);
+  else if (s == 4)
+    hipLaunchKernelGGL(coarsen_kernel<4>, grd, blk, 0, b->stream, g, b->n, child->n, b->labels, b->uT, b->fwd_w, alpha, beta,
+                       child->uT, child->fwd_w, child->labels);
+  else
+    hipLaunchKernelGGL(coarsen_kernel<8>, grd, blk, 0, b->stream, g, b->n, child->n, b->labels, b->uT, b->fwd_w, alpha, beta,
+                       child->uT, child->fwd_w, child->labels);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha) {
+  const CoarseGeom g = make_coarse_geom(b, s, off);
+  const dim3 blk(64, 4), grd((g.W + 63) / 64, (g.H + 3) / 4);
+  hipLaunchKernelGGL(coarse_apply_kernel, grd, blk, 0, b->stream, g, child->labels, alpha, b->labels,
+                     b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+}  // namespace phmrf

@@ -34,7 +34,7 @@ int fail(int status, const std::string& msg);
   } while (0)
 
 // ---- kernel classes for the built-in timers (phmrf.h) -------------------------------------------
-enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5, KC_STRIP = 6, KC_PROPOSE = 7 };
+enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5, KC_STRIP = 6, KC_PROPOSE = 7, KC_COARSE = 8 };
 
 // A chain family (grid rows / columns / diagonals / anti-diagonals): `nodes` lists node ids chain after
 // chain in chain order.  Chains of one colour share no edge.  Every chain is cut into SEGMENTS of at most
@@ -100,6 +100,8 @@ struct phmrf_block {
   float* uT = nullptr;                      // device [K][n]: unary planes, uT[k][i] = -logprob[i][k]
   bool uT_valid = false;                    //   ... current with logprob
   float* u_cur = nullptr;                   // device [n]: -logprob[i][l_i], kept current during the expansions of a round
+  // coarse alpha-expansions (coarse.hip): child blocks holding the two-label problem of the super-cells, side 2, 4, 8
+  phmrf_block* coarse[3] = {nullptr, nullptr, nullptr};
   unsigned long long* strip_mask = nullptr; // device [memo_strips]: OR of alpha_mask over a strip's cells (current cut)
   int32_t* work_list = nullptr;             // device [K][memo_strips]: strips queued for the expansion of each label
   int32_t* work_count = nullptr;            // device [64]: their number
@@ -122,8 +124,10 @@ struct phmrf_block {
   float* posteriors = nullptr;              // device [n, K], allocated on demand
   double* accum = nullptr;                  // device small f64 accumulator area
   double* accum_host = nullptr;             // pinned mirror
-  unsigned long long* counters = nullptr;   // device [8]
+  unsigned long long* counters = nullptr;   // device [128]
   unsigned long long* counters_host = nullptr;
+  unsigned long long* work_acc = nullptr;   // device [WORK_BANKS][4], zeroed and read back with the counters
+  unsigned long long* work_host = nullptr;  // pinned mirror
 
   // timing: event pairs recorded on the block's stream, resolved lazily (no host sync inside the measured loop)
   bool timing = false;
@@ -134,10 +138,15 @@ struct phmrf_block {
   hipEvent_t cur_start = nullptr;
   double ms[PHMRF_NUM_KERNEL_CLASSES] = {};
   int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {};
+  int64_t work[5] = {};                     // strips staged, their cells, staged cells, DP steps, strip launches (since reset_timing)
+  struct Interval { int kclass; float t0, t1; };
+  std::vector<Interval> intervals;          // resolved timed intervals on the library's common time base (ms)
 };
 
 namespace phmrf {
 
+constexpr int WORK_BANKS = 256;       // work_acc[WORK_BANKS][4]: strips staged, their cells, staged cells (with rim), DP
+                                      // steps of the strip kernels, one bank per workgroup id mod 256 (no hot address)
 constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every (K,S) the posterior / statistics kernel supports
                                      // (K <= 64, S <= 8: 4,688); phmrf_posterior_stats rejects anything larger
 
@@ -164,6 +173,9 @@ int launch_alpha_mask(phmrf_block* b, float beta);
 int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int geom);   // -> strip_newest, strip_mask
 int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev);
 int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
+int64_t coarse_nodes(const phmrf_block* b, int s, int off);                        // nodes of the coarse grid (s, off)
+int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta);
+int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
 
 }  // namespace phmrf

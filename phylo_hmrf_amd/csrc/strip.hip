@@ -268,13 +268,19 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
                                                     uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                     uint16_t* __restrict__ newest, int tick,
                                                     const int32_t* __restrict__ work_list,
-                                                    const int32_t* __restrict__ work_count) {
+                                                    const int32_t* __restrict__ work_count,
+                                                    unsigned long long* __restrict__ work) {
   __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];   // one 9.1 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
   float* tab = tabs + wave * SLAB;
   unsigned int my_changed = 0;
+  // work actually done by this wave (measurement: bench.py's roofline): strips staged, their cells, staged cells, DP
+  // steps walked.  Kept in LDS (lane 0 adds, fire and forget): no register may stay live across the strip loop for it.
+  __shared__ unsigned int wk[4];
+  if (threadIdx.x < 4) wk[threadIdx.x] = 0u;
+  __syncthreads();
 
   // waves are independent.  Expansions inside a solve walk the dense work list of their label (strip_scan_kernel),
   // everything else all strips of the cut.
@@ -311,6 +317,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
 
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
     if (debug == 16) continue;           // timing experiments: launch + memo + mask only
+    if (lane == 0) {
+      atomicAdd(&wk[0], 1u);
+      atomicAdd(&wk[1], (unsigned int)ncell);                  // nodes this unit re-decides
+      atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));     // the staged rectangle: strip + fixed rim (what is read)
+    }
     // ---- phase 1.  Step A: the strip's rectangle PLUS its fixed rim (7 x (ncols + 2) cells, lane <-> cell) is staged
     //      in LDS: per cell the four forward grid weights (times beta) and the packed labels -- 1 + 16 coalesced bytes
     //      per cell, each grid edge weight read once, by its upper/left end.  Step B: lane <-> strip cell
@@ -425,9 +436,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
               if (pl != lj) a1 += w;
             }
           }
+          // (a proposal whose unary cost is "infinite" is no proposal: coarse.hip pins super-cells that way)
+          const bool can2 = can && u1 < 1.0e29f;
           c0 = u0 + a0;
-          c1 = can ? u1 + a1 : BIG;
-          sw = can;
+          c1 = can2 ? u1 + a1 : BIG;
+          sw = can2;
         }
       }
       rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
@@ -458,6 +471,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
       t_lo = pl * 64 + (rl - rl % 6);
     }
 
+    if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
     if ((debug & 4) && lane == 0) {
       atomicAdd(changed - alpha - 8 + 102, 1ull);                                // strips reaching the DP
       atomicAdd(changed - alpha - 8 + 103, (unsigned long long)(t_end - t_lo + 1));   // DP steps
@@ -541,6 +555,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
+  __syncthreads();                       // every wave of the workgroup gets here (the strip loop only `continue`s)
+  if (work && threadIdx.x < 4) {         // one add per workgroup and counter, spread over WORK_BANKS addresses
+    const unsigned int v = wk[threadIdx.x];
+    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * 4 + threadIdx.x, (unsigned long long)v);
+  }
 }
 
 // One wave per strip of the current cut: newest[strip] = max dilated change stamp over the strip's cells (memo test),
@@ -873,7 +892,8 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
                      b->tick ? b->stamp : nullptr,                                                                     \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
                      use_memo ? b->strip_newest : nullptr, b->tick,                                                     \
-                     masks ? b->work_list + (int64_t)alpha * b->memo_strips : nullptr, masks ? b->work_count + alpha : nullptr)
+                     masks ? b->work_list + (int64_t)alpha * b->memo_strips : nullptr, masks ? b->work_count + alpha : nullptr, \
+                     b->work_acc)
   if (orient) PHMRF_LAUNCH_STRIP(1);
   else PHMRF_LAUNCH_STRIP(0);
 #undef PHMRF_LAUNCH_STRIP

@@ -316,13 +316,13 @@ def _pool(workers):
     if workers <= 1:
         return None
     if _POOL is None:
-        # Workers come from a FORK SERVER: a fresh interpreter (started by exec, with this module preloaded) forks them,
-        # so creating the pool is safe whenever it happens -- also after this process has initialised HIP / RCCL or
-        # started its block threads, where a plain fork() of the process itself is not.  Created once, reused for every
-        # later request (fewer tasks than workers leave some idle; more tasks queue); close_pool() ends it.
-        ctx = mp.get_context("forkserver")
-        ctx.set_forkserver_preload(["phylo_hmrf_amd.mstep"])
-        _POOL = ctx.Pool(workers)
+        # Forked ONCE.  The callers that own a GPU create the pool before anything initialises HIP (phyloHMRF.__init__
+        # before its first block, bench.py and the CLI before importing torch): a fork() of a process whose HIP / RCCL
+        # runtime and block threads are live is not safe.  (A fork server would lift that ordering, but it starts by
+        # exec-ing an interpreter, which rocprofv3 wraps and breaks, and which the GPU pool forbids once HIP is up.)
+        # An existing pool serves every later request, whatever its size (fewer tasks than workers leave some idle,
+        # more tasks queue): it is never re-forked; close_pool() ends it.
+        _POOL = mp.get_context("fork").Pool(workers)
         _POOL_SIZE = workers
     return _POOL
 

@@ -10,23 +10,51 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_prints_one_json_line_with_the_contract_keys():
+def _run(extra, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "2", "--warmup", "1",
-                          "--cpu-sample", "40"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          "--cpu-sample", "40"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900, env=e)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = out.stdout.strip().splitlines()[-1]
-    d = json.loads(line)
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    d = _run([])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
-    assert "workload" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["scaling"] in ("strong", "weak") and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["nodes_per_rank"] == [300 * 301 // 2 + 200 * 260] and d["config"]["blocks_per_rank"] == [2]
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # the dominant kernel's time per step is measured on one time line: it cannot exceed the step
+    assert 0 < r["busy_ms_per_step"] <= d["ms_per_step"]
+    for k in d["kernels"].values():
+        assert k["busy_ms"] <= k["ms"] + 1e-3 and k["busy_ms"] <= d["ms_per_step"] * d["steps"] + 1e-3
+    if r["kernel"] == "strip":
+        lim = d["roofline_limiter"]
+        assert lim["bound"] == "lds" and 0 < lim["frac"] < 1 and lim["units"] > 0 and lim["dp_steps"] > lim["units"]
+        assert lim["cells"] <= 315 * lim["units"]
     c = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "vectorised", "all_cores_upper_bound"):
         assert key in c, key
-    assert c["kind"] in ("reference", "port") and c["value"] > 0
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["vectorised"]["value"] >= c["value"] * 0.5
+
+
+def test_bench_rccl_path_single_rank():
+    """PHMRF_FORCE_DIST=1: the N > 1 code path (nccl process group = RCCL, all-reduce of the statistics, broadcast of the
+    M-step result, barrier, max-over-ranks timing) with one rank; the line must match the plain single-GPU run's shape."""
+    d = _run(["--no-cpu-baseline"], env={"PHMRF_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29519",
+                                         "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["blocks_per_rank"] == [2]
+    assert "cpu_baseline" not in d
+
+
+def test_bench_weak_scaling_mode_replicates_the_workload():
+    d = _run(["--no-cpu-baseline", "--scaling", "weak"])
+    assert d["scaling"] == "weak" and d["config"]["blocks_per_rank"] == [2]

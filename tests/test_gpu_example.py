@@ -116,23 +116,44 @@ def test_posterior_costs_and_statistics_of_the_reference_labels(ex, it):
     np.testing.assert_allclose(stats["obs*obs.T"], ex["it_stats_oo"][it], rtol=2e-4, atol=2e-2)
 
 
+FIT_SCRIPT = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["PHMRF_ROOT"])
+from phylo_hmrf_amd.hmrf import phyloHMRF
+g = np.load(os.path.join(os.environ["PHMRF_ROOT"], "tests", "golden", "example_chr22_em.npz"))
+X, K = g["X"], int(g["K"])
+tree = [[0, 1], [1, 2], [1, 3], [3, 4], [4, 5], [4, 6], [3, 7]]
+m = phyloHMRF(n_components=K, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree,
+              len_vec=g["len_vec"].tolist(), type_id=1, branch_list=[0, 32, 20, 6, 6, 6, 12], edge_list_1=[g["edges"]],
+              cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1,
+              initial_magnitude=1.0, learning_rate=0.001, estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7,
+              random_state=22, quiet=True)                      # mstep_workers=None: the default worker pool
+from phylo_hmrf_amd import mstep
+assert mstep._POOL is not None                                    # forked in __init__, before the first block
+res = m.fit_accumulate_test(X, g["len_vec"].tolist(), 0.001, "t", int(g["m_iter"]))
+out = dict(general=m.general_graph_regions, cost_vec=res[5].tolist(), tmax=int(res[6].max()), tn=int(res[6].shape[0]))
+m.close()
+assert mstep._POOL is None
+print("RESULT " + json.dumps(out))
+"""
+
+
 def test_fit_on_real_hic_reaches_the_reference_cost(ex):
-    """The whole drop-in: phyloHMRF.fit_accumulate_test on the same real block, same K and --miter.  EM trajectories are
-    not comparable step by step (other initial clustering, other labellings), the judged quantities are: it runs, costs
-    are finite, and the best cost1 is in the range of the reference's own run."""
-    from phylo_hmrf_amd.hmrf import phyloHMRF
-    X, K = ex["X"], int(ex["K"])
-    tree = [[0, 1], [1, 2], [1, 3], [3, 4], [4, 5], [4, 6], [3, 7]]
-    m = phyloHMRF(n_components=K, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree,
-                  len_vec=ex["len_vec"].tolist(), type_id=1, branch_list=[0, 32, 20, 6, 6, 6, 12],
-                  edge_list_1=[ex["edges"]], cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0, initial_weight=0.3,
-                  initial_weight1=0.1, initial_magnitude=1.0, learning_rate=0.001, estimate_type=3, max_iter=100,
-                  n_iter=5000, tol=1e-7, random_state=22, quiet=True)          # mstep_workers=None: the default pool
-    res = m.fit_accumulate_test(X, ex["len_vec"].tolist(), 0.001, "t", int(ex["m_iter"]))
-    assert m.general_graph_regions == []
-    m.close()
-    cost_vec, t_labels = res[5], res[6]
-    assert cost_vec.shape == (5, 4) and np.all(np.isfinite(cost_vec))
-    assert t_labels.shape == (X.shape[0],) and t_labels.max() < K
+    """The whole drop-in: phyloHMRF.fit_accumulate_test on the same real block, same K and --miter, with the DEFAULT
+    M-step worker pool (run in a fresh process: the pool is forked before that process touches the GPU).  EM
+    trajectories are not comparable step by step (other initial clustering, other labellings); judged: it runs, costs are
+    finite, and the best cost1 is in the range of the reference's own run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PHMRF_ROOT=root)
+    out = subprocess.run([sys.executable, "-c", FIT_SCRIPT], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    cost_vec = np.array(r["cost_vec"])
+    assert r["general"] == [] and cost_vec.shape == (5, 4) and np.all(np.isfinite(cost_vec))
+    assert r["tn"] == ex["X"].shape[0] and r["tmax"] < int(ex["K"])
     print("cost1 per iteration: GPU fit", np.round(cost_vec[:, 3], 4), " reference", np.round(ex["cost_vec"][:, 3], 4))
     assert cost_vec[:, 3].min() < ex["cost_vec"][:, 3].max()
