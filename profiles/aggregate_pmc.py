@@ -3,8 +3,8 @@
 
 usage: aggregate_pmc.py FETCH_DIR WRITE_DIR OUT_BY_KERNEL.json OUT_TRAFFIC.json
 FETCH_DIR / WRITE_DIR hold the outputs of
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE  --output-format csv -d FETCH_DIR -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d WRITE_DIR -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE  --output-format csv -d FETCH_DIR -- python3 bench.py --steps 2 --warmup 5 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d WRITE_DIR -- python3 bench.py --steps 2 --warmup 5 --no-cpu-baseline
 (separate passes: the TCC counters do not fit one pass, MI355X_MICROARCH.md).  Counter values are KiB.
 """
 import csv, glob, json, os, sys
@@ -51,8 +51,8 @@ def main():
             continue
         traffic[cls] = {"fetch_size_kb_per_launch": fs / n, "write_size_kb_per_launch": ws / n, "launches_profiled": n,
                         "hbm_bytes_per_launch": int(round((fs + ws) / n * 1024))}
-    note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 0 "
-            "--no-cpu-baseline` (whole-genome workload, averages over all launches of all blocks). Raw counter values x 1024; "
+    note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 --warmup 5 "
+            "--no-cpu-baseline` (whole-genome workload, 7 EM iterations of which 6 are steady-state warm starts; averages over all launches of all blocks). Raw counter values x 1024; "
             "on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x and is uncalibrated for narrower "
             "accesses (MI355X_MICROARCH.md, HBM), so the true read traffic lies between the raw value and twice it.")
     json.dump({"cfg3": traffic, "note": note}, open(out_t, "w"), indent=1)
