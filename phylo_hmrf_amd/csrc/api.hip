@@ -1089,6 +1089,17 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   // the energy before the first round (only needed when the caller asked for it: the first round of a solve that
   // changes labels always improves, and the tolerance refers to the energy after the round)
   double e_prev = res ? eu0 + ep0 : std::numeric_limits<double>::infinity();
+  // The strip alpha-expansions run on one of three fixed cuts (so that the per-strip memo of quiet runs applies).  The
+  // cut ADVANCES after a round that moved the labelling at large (>= 1/64 of the labels: the memo is worth little
+  // then), when a verification round begins, and from one solve to the next (b->geom_phase); it STAYS while the solve
+  // is mopping up, so those rounds only revisit the strips whose inputs changed -- a warm start pays for one full
+  // sweep per solve instead of one per round.
+  int geom = b->geom_phase % 3;
+  struct GeomScope {
+    phmrf_block* blk;
+    int* g;
+    ~GeomScope() { blk->geom_phase = (*g + 1) % 3; }
+  } geom_scope{b, &geom};
   while (rounds < o.max_rounds && b->tick < 60000) {      // (the change stamps are 16-bit launch ticks)
     const int r = rounds;
     PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
@@ -1127,7 +1138,6 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           PHMRF_TRY(strip_pass_nocount(b, bf, orient, (2 * r + 3 * orient) % 6, (17 * r + 31 * orient) % 64, -1));
         }
         if (expansions) {
-          const int geom = r % 3;                   // expansions cycle through three fixed cuts so the memo applies
           bool any = false;
           for (int a = 0; a < K; ++a) any = any || active[8 + a];
           if (any) {
@@ -1177,6 +1187,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     for (int sl : slots) ch += (int64_t)b->counters_host[sl];
     total += ch;
     last_changed = ch;
+    const bool moving = ch * 64 >= b->n;
+    if (moving) geom = (geom + 1) % 3;
     for (int lv = 0; lv < N_COARSE; ++lv)
       if (coarse_ran[lv]) coarse_changed[lv] = (int64_t)b->counters_host[80 + lv];
     if (b->timing) work_fold(b);
@@ -1238,9 +1250,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         converged = 1;
         break;
       }
-      for (int sl : slots) active[sl] = 1;           // verification round
+      for (int sl : slots) active[sl] = 1;           // verification round, on the next cut
       all_active = true;
       verifying = true;
+      if (!moving) geom = (geom + 1) % 3;
       continue;
     }
     verifying = false;

@@ -107,6 +107,7 @@ struct phmrf_block {
   int32_t* work_count = nullptr;            // device [64]: their number
   int mask_tick = -1, prop_tick = -1;       // tick of the last alpha-mask / proposal launch of this solve (-1: none)
   int scan_geom = 0;                        // which fixed cut launch_strip_scan is building the tables for
+  int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
   // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS
   // (0 = not since the solve began);
   // memo[orient][geom][strip][alpha] = tick of the last strip alpha-expansion of that strip that found nothing to do.
