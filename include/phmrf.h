@@ -162,6 +162,13 @@ PHMRF_API int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* ch
  * alpha (strip alpha-expansion); alpha < 0: every node may keep its label or take its best alternative label. */
 PHMRF_API int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, int alpha,
                                    int64_t* changed);
+/* Every strip alpha-expansion of the labels named by the bits of label_mask on one cut, in ascending label order, in ONE
+ * launch (strip_multi_kernel: a wave owns a strip, stages it once and runs the labels back to back; an exact filter
+ * settles most (strip, label) pairs without the DP).  Same result, label for label, as the phmrf_mrf_strip_pass calls
+ * of those labels in that order.  Replaces the K swap-cycle inner loops of gco's swap()
+ * (GCoptimization.cpp:1282-1394) inside phmrf_mrf_solve. */
+PHMRF_API int phmrf_mrf_strip_multi_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c,
+                                         uint64_t label_mask, int64_t* changed);
 /* One coarse alpha-expansion (coarse.hip): super-cells of scale x scale nodes (scale in {2, 4, 8}; super-cell of node
  * (i, j) = ((i + offset) / scale, (j + offset) / scale), 0 <= offset < scale) keep their labels or switch to alpha as a
  * whole; the two-label problem of the super-cells is solved by one strip pass per orientation (shift_r, shift_c as in

@@ -394,6 +394,46 @@ def strip_fusion(g, unary, labels, prop, beta, H, W, diagonal, orient, shift_r, 
     return ch
 
 
+def peel(g, unary, labels, beta, H, W, diagonal, orient, shift_r, shift_c, alpha, max_sweeps=None):
+    """The exact filter in front of the strip alpha-expansions (model of strip_multi_kernel's sweeps).
+
+    s_i = cost of switching node i alone to alpha;  disc_ij = beta w_ij (2 - [l_i != l_j]) = what an edge inside a
+    switching set saves against the single-site sums.  For an optimal switching set C* of a strip:
+      every member:   s_i <= sum_{j in C*, j ~ i} disc_ij          (else i would leave at a profit)
+      if it improves: s_i <  1/2 sum_{j in C*, j ~ i} disc_ij  for some member (a seed)
+    Deleting, sweep after sweep, the nodes of U (initially every strip node with l_i != alpha) that violate the first
+    line with U in place of C* never deletes a member of C*.  Returns (U[n] bool, seeded[NS] bool): the expansion of
+    alpha can only move nodes of U, and only in strips with a seed.  max_sweeps None: to the fixed point."""
+    nodes, _ = strip_node_table(H, W, diagonal, orient, shift_r, shift_c)
+    n = g.n
+    sid = -np.ones(n, dtype=np.int64)
+    ss, pp = np.nonzero(nodes >= 0)
+    sid[nodes[ss, pp]] = ss
+    NS = nodes.shape[0]
+    lab = np.asarray(labels, dtype=np.int64)
+    li, lj = lab[g.src], lab[g.col]
+    s = unary[:, alpha] - unary[np.arange(n), lab]
+    np.add.at(s, g.src, beta * g.wgt * ((lj != alpha).astype(np.float64) - (lj != li)))
+    disc = beta * g.wgt * (2.0 - (lj != li))
+    same = (sid[g.src] >= 0) & (sid[g.src] == sid[g.col])
+    U = (sid >= 0) & (lab != alpha) & (unary[:, alpha] < 1e29)
+    sweeps = 0
+    while True:
+        e = same & U[g.col]
+        cap = np.zeros(n)
+        np.add.at(cap, g.src[e], disc[e])
+        seeds = U & (s <= cap) & (s < 0.5 * cap)
+        U2 = U & (s <= cap)
+        sweeps += 1
+        done = bool((U2 == U).all()) or (max_sweeps is not None and sweeps >= max_sweeps)
+        U = U2
+        if done:
+            break
+    seeded = np.zeros(NS, dtype=bool)
+    np.logical_or.at(seeded, sid[seeds], True)
+    return U, seeded
+
+
 # ------------------------------------------------------------------------------------------------
 # coarse alpha-expansion (model of phylo_hmrf_amd/csrc/coarse.hip)
 # ------------------------------------------------------------------------------------------------

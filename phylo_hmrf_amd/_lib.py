@@ -75,6 +75,7 @@ SIGNATURES = {
     "phmrf_mrf_chain_sweep": [_vp, _d, _i, _lp],
     "phmrf_mrf_component_pass": [_vp, _d, _lp],
     "phmrf_mrf_strip_pass": [_vp, _d, _i, _i, _i, _i, _lp],
+    "phmrf_mrf_strip_multi_pass": [_vp, _d, _i, _i, _i, ctypes.c_uint64, _lp],
     "phmrf_mrf_energy": [_vp, _d, _dp, _dp, _dp],
     "phmrf_mrf_coarse_pass": [_vp, _d, _i, _i, _i, _i, _i, _lp],
     "phmrf_block_coarse_problem": [_vp, _d, _i, _i, _i, _lp, _fp, _fp],

@@ -144,6 +144,16 @@ class Block(object):
                                            ctypes.byref(c)))
         return c.value
 
+    def strip_multi_pass(self, beta, orient, shift_r, shift_c, labels=None):
+        """the strip alpha-expansions of `labels` (default: all K) on one cut, ascending, in one launch"""
+        mask = 0
+        for a in (range(self.K) if labels is None else labels):
+            mask |= 1 << int(a)
+        c = ctypes.c_int64(0)
+        check(self._L.phmrf_mrf_strip_multi_pass(self._h, float(beta), int(orient), int(shift_r), int(shift_c),
+                                                 ctypes.c_uint64(mask), ctypes.byref(c)))
+        return c.value
+
     def coarse_pass(self, beta, scale, offset, alpha, shift_r=0, shift_c=0):
         c = ctypes.c_int64(0)
         check(self._L.phmrf_mrf_coarse_pass(self._h, float(beta), int(scale), int(offset), int(alpha), int(shift_r),

@@ -884,6 +884,30 @@ int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, 
   return PHMRF_OK;
 }
 
+int phmrf_mrf_strip_multi_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, uint64_t label_mask,
+                               int64_t* changed) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "strip moves need phmrf_block_set_grid");
+  PHMRF_CHECK(b->num_neighbor == 8 || b->num_neighbor == 4, PHMRF_ERR_STATE, "bad grid");
+  PHMRF_CHECK(orient == 0 || orient == 1, PHMRF_ERR_INVALID, "orient must be 0 or 1");
+  PHMRF_CHECK(shift_r >= 0 && shift_r <= 5 && shift_c >= 0 && shift_c <= 63, PHMRF_ERR_INVALID, "shift out of range");
+  PHMRF_CHECK(b->K >= 64 || (label_mask >> b->K) == 0, PHMRF_ERR_INVALID, "label_mask names a label >= K");
+  PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
+  if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
+  tic(b);
+  PHMRF_TRY(launch_strip_multi(b, (float)beta, orient, shift_r, shift_c, label_mask, -1));
+  b->work[4] += 1;
+  toc(b, KC_STRIP, 1);
+  PHMRF_TRY(work_fetch_async(b));
+  PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  work_fold(b);
+  int64_t ch = 0;
+  for (int a = 0; a < b->K; ++a) ch += (int64_t)b->counters_host[8 + a];
+  if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
 // ---- coarse alpha-expansions (coarse.hip) ----------------------------------------------------------------------
 static const int N_COARSE = 3;
 static const int COARSE_SCALE[N_COARSE] = {2, 4, 8};
@@ -1138,23 +1162,24 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           PHMRF_TRY(strip_pass_nocount(b, bf, orient, (2 * r + 3 * orient) % 6, (17 * r + 31 * orient) % 64, -1));
         }
         if (expansions) {
-          bool any = false;
-          for (int a = 0; a < K; ++a) any = any || active[8 + a];
-          if (any) {
-            tic(b);
-            PHMRF_TRY(launch_alpha_mask(b, bf));    // which labels can still pay off where (fresh per orientation)
-            PHMRF_TRY(launch_strip_scan(b, orient, GEOM_R[geom], GEOM_C[geom], geom));
-            toc(b, KC_PROPOSE, 2);
-          }
-          int n_exp = 0;                            // one timed interval for the label loop (events cost, too)
-          if (any) tic(b);
+          // every active label's expansion of the cut in ONE launch: a wave owns a strip, stages it once and runs the
+          // labels back to back behind the exact filter (strip_multi_kernel)
+          unsigned long long lmask = 0ull;
           for (int a = 0; a < K; ++a)
-            if (active[8 + a]) {
-              b->counter_slot = 8 + a;
-              PHMRF_TRY(strip_pass_nocount(b, bf, orient, GEOM_R[geom], GEOM_C[geom], a, true, geom, false));
-              ++n_exp;
+            if (active[8 + a]) lmask |= 1ull << a;
+          if (lmask) {
+            if (!b->uT_valid) {
+              tic(b);
+              PHMRF_TRY(launch_unary_planes(b));
+              toc(b, KC_PROPOSE, 1);
             }
-          if (any) toc(b, KC_STRIP, n_exp);
+            tic(b);
+            ++b->tick;
+            PHMRF_TRY(launch_strip_multi(b, bf, orient, GEOM_R[geom], GEOM_C[geom], lmask, geom));
+            b->tick += K;                           // one tick per label inside the launch
+            b->work[4] += 1;
+            toc(b, KC_STRIP, 1);
+          }
         }
       }
     }

@@ -170,6 +170,8 @@ int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, 
 int launch_propose(phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
                       int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
+int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, unsigned long long label_mask,
+                       int geom = -1);   // all listed alpha-expansions of the cut, one wave per strip
 int launch_alpha_mask(phmrf_block* b, float beta);
 int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int geom);   // -> strip_newest, strip_mask
 int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev);

@@ -508,7 +508,9 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     dp_pass<2, true>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
     dp_pass<3, true>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
     dp_pass<4, true>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
-    const float cand = (m == mmin) ? (float)sidx : 127.f;
+    const float mmin2 = wave_min_f32(m);   // the recorded walk starts at the window's first group, the common walk at
+    //  the pass start: their values differ by the keep-costs of the cells in between -> the recorded walk's own minimum
+    const float cand = (m == mmin2) ? (float)sidx : 127.f;
     const float best = wave_min_f32(cand);
     int s = state_of_lane(__ffsll((long long)__ballot(cand == best)) - 1);
 
@@ -557,6 +559,404 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
   if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
   __syncthreads();                       // every wave of the workgroup gets here (the strip loop only `continue`s)
   if (work && threadIdx.x < 4) {         // one add per workgroup and counter, spread over WORK_BANKS addresses
+    const unsigned int v = wk[threadIdx.x];
+    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * 4 + threadIdx.x, (unsigned long long)v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// strip_multi_kernel: EVERY alpha-expansion of a strip in one wave, behind an exact filter.
+//
+// One wave owns one strip of the cut for the whole launch: it stages the strip's rectangle once, keeps what does not
+// depend on the label (weights, neighbour labels, running unaries) in registers, and then runs the expansions of all
+// listed labels back to back.  Most (strip, label) pairs never reach the DP:
+//
+//   s_i  = cost of switching cell i ALONE to alpha, everything else as it is
+//        = u_i(alpha) - u_i(l_i) + sum_j w_ij ([alpha != l_j] - [l_i != l_j])
+//   If a set C of strip cells switches, every edge inside C is cheaper than the single-site sums say by
+//   disc_ij = w_ij (2 - [l_i != l_j]).  Hence, for an OPTIMAL switching set C*:
+//     (a) no member can leave at a profit:  s_i <= sum_{j in C*, j ~ i} disc_ij      for every i in C*
+//     (b) if C* improves the energy at all: s_i <  1/2 sum_{j in C*, j ~ i} disc_ij  for some i in C*  (a "seed")
+//   Starting from U = all cells with l_i != alpha and deleting cells that violate (a) with C* replaced by U only ever
+//   removes cells outside C* (the right-hand side shrinks with U), so C* stays inside U through every sweep; when no
+//   cell of U passes (b) there is NO improving expansion of this label on this strip -- exactly, not heuristically.
+//   Otherwise the DP runs with the cells outside U pinned, on the window U spans.  (Model: oracle/mrf_moves.peel.)
+//
+// In the steady state of an EM fit ~5 sweeps settle 4 of 5 pairs without a DP, and U holds a few per cent of the cells
+// of the others.  Per label the wave reads 4 B per cell (the label's unary plane); labels and weights are read once
+// per strip instead of once per (strip, label).
+constexpr int PEEL_MAX = 8;       // sweeps before the DP takes over with whatever U is left (any U is sound)
+
+template <int ORIENT>
+__global__ __launch_bounds__(256, 3) void strip_multi_kernel(StripGeom g, int64_t n, int K, int D,
+                                                             const int32_t* __restrict__ nbr,
+                                                             const float4* __restrict__ fwd_w,
+                                                             const float* __restrict__ uT, uint8_t* __restrict__ labels,
+                                                             float beta, unsigned long long label_mask,
+                                                             unsigned long long* __restrict__ changed,
+                                                             uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
+                                                             int tick0, unsigned long long* __restrict__ work, int peel_max) {
+  __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];
+  __shared__ unsigned int wk[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int WPB = blockDim.x >> 6;
+  const int nstrips = g.nbands * g.nsegs;
+  float* tab = tabs + wave * SLAB;
+  int* tabi = reinterpret_cast<int*>(tab);
+  if (threadIdx.x < 4) wk[threadIdx.x] = 0u;
+  __syncthreads();
+  const int sh5 = lane & 31;
+  const bool hi_half = lane >= 32;
+
+  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
+    const int bnd = strip / g.nsegs;
+    const int seg = strip - bnd * g.nsegs;
+    const int rs0 = bnd * (SH + 1) - g.shift_r;
+    const int cs0 = seg * 64 - g.shift_c;
+    const int ca = cs0 > 0 ? cs0 : 0;
+    const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
+    const int ncols = cb > ca ? cb - ca : 0;
+    const int ncell = ncols * SH;
+    if (ncell <= 0) continue;
+
+    // ---- the strip's nodes (lane <-> cell t = 64 p + lane, column-major) and the labels that need a run: a label
+    //      is skipped while no (dilated) change stamp of the strip is newer than its last quiet run on this cut
+    int nodev[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      int t = p * 64 + lane;
+      asm volatile("" : "+v"(t));
+      nodev[p] = -1;
+      if (t < ncell) {
+        const int cc = t / SH, rr = t - cc * SH;
+        nodev[p] = strip_node(g, rs0 + rr, ca + cc);
+      }
+    }
+    unsigned long long todo = label_mask;
+    uint16_t* mrow = memo ? memo + (int64_t)strip * (K + 1) : nullptr;
+    if (mrow) {
+      int nw = 0;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p)
+        if (nodev[p] >= 0) {
+          const int st = stamp[nodev[p]];
+          nw = st > nw ? st : nw;
+        }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o2 = __shfl_xor(nw, off, 64);
+        nw = o2 > nw ? o2 : nw;
+      }
+      const int lq = lane < K ? (int)mrow[lane] : 0;
+      todo &= __ballot(lane < K && !(lq && nw < lq));
+    }
+    todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
+           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
+    if (!todo) continue;
+
+    // label-independent cell data, in registers for the whole label loop
+    float v8[NPASS][8];            // per neighbour d: inside the strip  w (2 - [l != l_d])  (= disc), outside  w
+    unsigned int laba[NPASS], labb[NPASS];   // the eight neighbour labels, one byte each
+    unsigned int meta[NPASS];      // own label | eq mask << 8 | inside mask << 16
+    unsigned int inm13[NPASS];     // the inside mask at the positions of the 13-bit neighbourhood window
+    float ucur[NPASS], hself[NPASS];
+    bool staged = false;
+
+    while (todo) {
+      if (!staged) {
+        // ---- staging (as strip_kernel, step A): labels and forward weights of the strip's rectangle and rim -> LDS
+        {
+          constexpr int NEP = (ECELLS + 63) / 64;
+          int enode[NEP], eidx[NEP];
+#pragma unroll
+          for (int q = 0; q < NEP; ++q) {
+            int er, ec;
+            if (ORIENT == 0) {
+              int l2 = lane;
+              asm volatile("" : "+v"(l2));
+              er = q < EH ? q : l2;
+              ec = q < EH ? l2 : 64;
+              if (q >= EH && l2 >= EH) ec = 1 << 20;
+            } else {
+              int e = q * 64 + lane;
+              asm volatile("" : "+v"(e));
+              ec = e / EH;
+              er = e - ec * EH;
+            }
+            const bool have = ec < ncols + 2;
+            eidx[q] = have ? ec * EH + er : -1;
+            enode[q] = have ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
+          }
+          int elab[NEP];
+          float4 ef[NEP];
+#pragma unroll
+          for (int q = 0; q < NEP; ++q) {
+            const int node = enode[q];
+            elab[q] = 0;
+            ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (node >= 0) {
+              elab[q] = labels[node];
+              ef[q] = fwd_w[node];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();        // (the slab may still hold the tables of the previous label's DP)
+#pragma unroll
+          for (int q = 0; q < NEP; ++q) {
+            const int e = eidx[q];
+            if (e >= 0) {
+              tab[e * REC + 0] = ef[q].x * beta;
+              tab[e * REC + 1] = ef[q].y * beta;
+              tab[e * REC + 2] = ef[q].z * beta;
+              tab[e * REC + 3] = ef[q].w * beta;
+              tabi[e * REC + 4] = enode[q] >= 0 ? elab[q] : 0;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
+        // ---- extraction: lane <-> strip cell
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          int t = p * 64 + lane;
+          asm volatile("" : "+v"(t));
+          unsigned int la = 0u, lb = 0u, mt = 0u, im = 0u;
+          float hs = 0.f, uc = 0.f;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) v8[p][d] = 0.f;
+          if (nodev[p] >= 0) {
+            const int cc = t / SH, rr = t - cc * SH;
+            const int e0 = (cc + 1) * EH + (rr + 1);
+            const int l = tabi[e0 * REC + 4] & 255;
+            mt = (unsigned int)l;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+              constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+              constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+              constexpr int WPOS[8] = {0, 5, 10, 1, 11, 2, 7, 12};      // dc * 5 + dr + 6
+              const int dr = DR[d], dc = DC[d];
+              const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;
+              const bool fwd = di > 0 || (di == 0 && dj > 0);
+              const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
+              const int en = e0 + dc * EH + dr;
+              const float w = fwd ? tab[e0 * REC + comp] : tab[en * REC + comp];
+              const int lj = tabi[en * REC + 4] & 255;
+              const int r2 = rr + dr, c2 = cc + dc;
+              const bool inside = r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols;
+              const bool eq = lj == l;
+              hs += eq ? w : 0.f;
+              v8[p][d] = (inside && eq) ? w + w : w;
+              mt |= (eq ? 1u : 0u) << (8 + d);
+              mt |= (inside ? 1u : 0u) << (16 + d);
+              im |= (inside ? 1u : 0u) << WPOS[d];
+              if (d < 4) la |= (unsigned int)lj << (8 * d);
+              else lb |= (unsigned int)lj << (8 * (d - 4));
+            }
+            uc = uT[(int64_t)l * n + nodev[p]];
+          }
+          laba[p] = la; labb[p] = lb; meta[p] = mt; inm13[p] = im; hself[p] = hs; ucur[p] = uc;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_wave_barrier();          // the slab is free for the cost tables from here on
+        staged = true;
+      }
+
+      const int alpha = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      if (lane == 0) {
+        atomicAdd(&wk[0], 1u);
+        atomicAdd(&wk[1], (unsigned int)ncell);
+      }
+
+      // ---- single-site costs and the starting set
+      float u1[NPASS], sc[NPASS];
+      unsigned long long U[NPASS];
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) u1[p] = nodev[p] >= 0 ? uT[(int64_t)alpha * n + nodev[p]] : BIG;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        float hist = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const int lj = (int)(((d < 4 ? laba[p] : labb[p]) >> (8 * (d & 3))) & 255u);
+          hist += lj == alpha ? v8[p][d] : 0.f;      // (a neighbour labelled alpha differs from l_i: v8 holds plain w)
+        }
+        const int l = (int)(meta[p] & 255u);
+        const bool ok = nodev[p] >= 0 && l != alpha && u1[p] < 1.0e29f;
+        sc[p] = u1[p] - ucur[p] + hself[p] - hist;
+        U[p] = __ballot(ok);
+      }
+
+      // ---- the filter: delete cells that could leave any switching set at a profit; stop when no seed is left
+      bool quiet = false;
+      for (int it = 0; it < peel_max; ++it) {
+        unsigned long long seeds = 0ull;
+        bool shrunk = false;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          if (U[p] == 0ull) continue;
+          const unsigned long long lo = p > 0 ? U[p > 0 ? p - 1 : 0] : 0ull;
+          const unsigned long long hi = p < NPASS - 1 ? U[p < NPASS - 1 ? p + 1 : 0] : 0ull;
+          const unsigned long long X = (U[p] << 6) | (lo >> 58);       // bit k: cell 64 p - 6 + k
+          const unsigned long long Y = (hi << 6) | (U[p] >> 58);       // bit k: cell 64 (p + 1) - 6 + k
+          const unsigned int x0 = (unsigned int)X, x1 = (unsigned int)(X >> 32), y0 = (unsigned int)Y;
+          const unsigned int wa = hi_half ? x1 : x0, wb = hi_half ? y0 : x1;
+          unsigned int W = __builtin_amdgcn_alignbit(wb, wa, sh5);      // bit k: cell t - 6 + k
+          W &= inm13[p];
+          float cap = 0.f;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            constexpr int WPOS[8] = {0, 5, 10, 1, 11, 2, 7, 12};
+            cap += ((W >> WPOS[d]) & 1u) ? v8[p][d] : 0.f;
+          }
+          const float capx = cap * 1.0001f + 1e-6f;                      // a hair of slack for the f32 sums
+          const unsigned long long keep = __ballot(sc[p] <= capx);
+          const unsigned long long sd = __ballot(sc[p] < 0.5f * capx);
+          const unsigned long long nu = U[p] & keep;
+          seeds |= nu & sd;
+          shrunk = shrunk || nu != U[p];
+          U[p] = nu;
+        }
+        if (!seeds) {
+          quiet = true;
+          break;
+        }
+        if (!shrunk) break;
+      }
+      const int tick_a = tick0 + alpha;
+#ifdef PHMRF_MULTI_DEBUG
+      if (strip == 6 && alpha == 3) {
+        if (lane == 58) printf("DBG strip %d alpha %d quiet %d U %llx %llx %llx %llx %llx sc4 %f u1 %f ucur %f hself %f node %d meta %x inm %x\n", strip, alpha, (int)quiet, U[0], U[1], U[2], U[3], U[4], sc[4], u1[4], ucur[4], hself[4], nodev[4], meta[4], inm13[4]);
+      }
+#endif
+      if (quiet) {
+        if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+        continue;
+      }
+
+      // ---- cell records of the DP (lane <-> cell), cells outside U pinned
+      float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
+      int rbits[NPASS];
+      int t_lo = NCELL_MAX, t_hi = -1;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
+        int bits = 0;
+        if (nodev[p] >= 0) {
+          const int l = (int)(meta[p] & 255u);
+          const bool in_u = (U[p] >> lane) & 1ull;
+          float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            constexpr int QOF[8] = {1, 0, -1, 2, -1, 3, -1, -1};
+            const int lj = (int)(((d < 4 ? laba[p] : labb[p]) >> (8 * (d & 3))) & 255u);
+            const bool eq = (meta[p] >> (8 + d)) & 1u;
+            const bool inside = (meta[p] >> (16 + d)) & 1u;
+            if (!inside) {
+              a0 += eq ? 0.f : v8[p][d];
+              a1 += lj != alpha ? v8[p][d] : 0.f;
+            } else if (QOF[d] >= 0) {
+              w4[QOF[d] >= 0 ? QOF[d] : 0] = eq ? 0.5f * v8[p][d] : v8[p][d];
+              const int nib = (eq ? 0 : 1) | (l != alpha ? 2 : 0) | (lj != alpha ? 4 : 0);
+              bits |= nib << (4 * (QOF[d] >= 0 ? QOF[d] : 0));
+            }
+          }
+          c0 = ucur[p] + a0;
+          c1 = in_u ? u1[p] + a1 : BIG;
+        }
+        rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
+        rbits[p] = bits;
+        if (U[p]) {
+          const int first = p * 64 + __ffsll((long long)U[p]) - 1;
+          const int last = p * 64 + 63 - __clzll((long long)U[p]);
+          t_lo = first < t_lo ? first : t_lo;
+          t_hi = last > t_hi ? last : t_hi;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (t_hi < 0) {
+        if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+        continue;
+      }
+      t_lo = __builtin_amdgcn_readfirstlane(t_lo);
+      int t_end = __builtin_amdgcn_readfirstlane(t_hi) + SH + 1;
+      {
+        const int pe = t_end >> 6, re = t_end & 63;
+        int r6 = re - re % 6 + 5;
+        if (r6 > 63) r6 = 63;
+        t_end = pe * 64 + r6;
+        if (t_end > NPASS * 64 - 1) t_end = NPASS * 64 - 1;
+        const int pl = t_lo >> 6, rl = t_lo & 63;
+        t_lo = pl * 64 + (rl - rl % 6);
+      }
+      if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
+
+      float m = lane == 0 ? 0.f : BIG;
+      unsigned long long took = 0ull;
+      unsigned int dlo[NPASS], dhi[NPASS];
+      dp_pass<0, false>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
+      dp_pass<1, false>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
+      dp_pass<2, false>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
+      dp_pass<3, false>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
+      dp_pass<4, false>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
+      const int q_end = t_end % 6;
+      int sidx = 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) sidx |= ((state_of_lane(lane) >> ((q_end - j + 6) % 6)) & 1) << j;
+      const float mmin = wave_min_f32(m);
+      if (!(took & 1ull) && PHMRF_RL(m, 0) == mmin) {
+        if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+        continue;
+      }
+      m = lane == 0 ? 0.f : BIG;
+      dp_pass<0, true>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
+      dp_pass<1, true>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
+      dp_pass<2, true>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
+      dp_pass<3, true>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
+      dp_pass<4, true>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
+      const float mmin2 = wave_min_f32(m);   // the recorded walk starts at the window's first group, the common walk at
+    //  the pass start: their values differ by the keep-costs of the cells in between -> the recorded walk's own minimum
+    const float cand = (m == mmin2) ? (float)sidx : 127.f;
+      const float best = wave_min_f32(cand);
+      int s = state_of_lane(__ffsll((long long)__ballot(cand == best)) - 1);
+      unsigned int xsel[NPASS];
+      s = __builtin_amdgcn_readfirstlane(s);
+      backtrack_pass<4>(s, t_lo, t_end, dlo[4], dhi[4], xsel[4]);
+      backtrack_pass<3>(s, t_lo, t_end, dlo[3], dhi[3], xsel[3]);
+      backtrack_pass<2>(s, t_lo, t_end, dlo[2], dhi[2], xsel[2]);
+      backtrack_pass<1>(s, t_lo, t_end, dlo[1], dhi[1], xsel[1]);
+      backtrack_pass<0>(s, t_lo, t_end, dlo[0], dhi[0], xsel[0]);
+
+      __builtin_amdgcn_wave_barrier();
+      unsigned int my_changed = 0;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int node = nodev[p];
+        if (xsel[p] && node >= 0) {
+          labels[node] = (uint8_t)alpha;
+          if (stamp) {
+            stamp[node] = (uint16_t)tick_a;
+            const int32_t* nb2 = nbr + (int64_t)node * D;
+            for (int j = 0; j < D; ++j)
+              if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick_a;
+          }
+          ++my_changed;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) my_changed += __shfl_xor(my_changed, off, 64);
+      if (lane == 0) {
+        if (my_changed) atomicAdd(changed + alpha, (unsigned long long)my_changed);
+        if (mrow) mrow[alpha] = my_changed ? (uint16_t)0 : (uint16_t)tick_a;
+      }
+      if (my_changed) {
+        __threadfence();          // the restaging below reads the labels this wave has just written
+        staged = false;
+      }
+    }
+  }
+  __syncthreads();
+  if (work && threadIdx.x < 4) {
     const unsigned int v = wk[threadIdx.x];
     if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * 4 + threadIdx.x, (unsigned long long)v);
   }
@@ -824,6 +1224,16 @@ static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: ph
   return v;
 }
 
+static int peel_sweeps() {   // PHMRF_PEEL_SWEEPS=0 switches the filter off (timing experiments: every pair goes to the DP)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PHMRF_PEEL_SWEEPS");
+    v = e ? atoi(e) : PEEL_MAX;
+    if (v < 0 || v > 64) v = PEEL_MAX;
+  }
+  return v;
+}
+
 static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int shift_c) {
   StripGeom g;
   g.H = b->H;
@@ -897,6 +1307,32 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   if (orient) PHMRF_LAUNCH_STRIP(1);
   else PHMRF_LAUNCH_STRIP(0);
 #undef PHMRF_LAUNCH_STRIP
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+// every alpha-expansion of the labels in `label_mask` on the cut (orient, shift_r, shift_c), one wave per strip
+// (strip_multi_kernel).  geom >= 0: the memo of quiet runs of that fixed cut applies (inside a solve).  The launch uses
+// the ticks b->tick .. b->tick + K - 1 (one per label, so that a label's quiet run after another label's move on the
+// same strip stays valid); the caller advances b->tick by K.
+int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, unsigned long long label_mask,
+                       int geom) {
+  const StripGeom g = make_geom(b, orient, shift_r, shift_c);
+  const int nstrips = g.nbands * g.nsegs;
+  if (nstrips <= 0 || !label_mask) return PHMRF_OK;
+  if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
+  const int TB = 256, WPB = 4;
+  int grid = (nstrips + WPB - 1) / WPB;
+  if (grid > 256 * 6) grid = 256 * 6;          // two resident sets of workgroups stride over the strips
+  const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
+#define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
+  hipLaunchKernelGGL((strip_multi_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
+                     b->uT, b->labels, beta, label_mask, b->counters + 8, b->tick ? b->stamp : nullptr,               \
+                     use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
+                     b->tick, b->work_acc, peel_sweeps())
+  if (orient) PHMRF_LAUNCH_MULTI(1);
+  else PHMRF_LAUNCH_MULTI(0);
+#undef PHMRF_LAUNCH_MULTI
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

@@ -109,6 +109,34 @@ def _integer_problem(seed, H, W, K, diagonal):
     return n, eid, w, -un, init
 
 
+@pytest.mark.parametrize("H,W,K,diagonal", [(23, 70, 4, False), (41, 41, 6, True), (6, 200, 3, False), (130, 7, 5, False),
+                                            (64, 129, 20, False), (3, 3, 2, True)])
+def test_strip_multi_pass_matches_the_single_label_passes(H, W, K, diagonal):
+    """strip_multi_kernel (every label of a cut in one launch, behind the exact filter) = the strip alpha-expansions of
+    the move model applied label after label, label for label -- the filter loses no move and breaks no tie differently."""
+    n, eid, w, lp, init = _integer_problem(6, H, W, K, diagonal)
+    g = M.Graph(n, eid, w)
+    b = _block(n, 2, K)
+    b.set_graph(eid, w)
+    b.set_grid(H, W, diagonal, 8)
+    b.set_logprob(lp)
+    b.set_labels(init)
+    lab = init.astype(np.int64).copy()
+    total = 0
+    for it, (orient, sr, sc, labels) in enumerate([(0, 0, 0, None), (1, 3, 17, None), (0, 2, 40, [K - 1, 0]), (1, 5, 63, None),
+                                                   (0, 4, 21, None), (1, 0, 42, None)]):
+        ch_ref = 0
+        for alpha in (range(K) if labels is None else sorted(labels)):
+            ch_ref += M.strip_fusion(g, -lp, lab, np.full(n, alpha), 1.0, H, W, diagonal, orient, sr, sc)
+        ch = b.strip_multi_pass(1.0, orient, sr, sc, labels)
+        got = b.get_labels().astype(np.int64)
+        assert np.array_equal(got, lab), (it, int((got != lab).sum()))
+        assert ch == ch_ref
+        total += ch
+    assert total > 0 or n < 20
+    b.close()
+
+
 @pytest.mark.parametrize("H,W,K,diagonal", [(37, 37, 5, True), (30, 45, 8, False), (70, 70, 20, True), (9, 200, 3, False)])
 def test_icm_sweep_matches_move_model(H, W, K, diagonal):
     n, eid, w, lp, init = _integer_problem(1, H, W, K, diagonal)
