@@ -1075,7 +1075,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         }
     PHMRF_HIP(hipMemsetAsync(b->chain_memo, 0, (total ? total : 1) * sizeof(uint16_t), b->stream));
   }
-  if (expansions) {
+  if (strips) {                         // (the fusion passes keep a memo, too: slot K)
     int64_t max_strips = 0;
     for (int orient = 0; orient < 2; ++orient) {
       const int Hs = orient ? b->W : b->H, Ws = orient ? b->H : b->W;
@@ -1159,7 +1159,9 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       for (int orient = 0; orient < 2; ++orient) {
         if (active[78 + orient]) {
           b->counter_slot = 78 + orient;
-          PHMRF_TRY(strip_pass_nocount(b, bf, orient, (2 * r + 3 * orient) % 6, (17 * r + 31 * orient) % 64, -1));
+          // the fusion pass runs on a cut of its own that moves with the expansions' (so that its memo of quiet strips
+          // applies while the cut stays): the expansion cut shifted by half a band / half a segment
+          PHMRF_TRY(strip_pass_nocount(b, bf, orient, (GEOM_R[geom] + 3) % 6, (GEOM_C[geom] + 31) % 64, -1, false, geom));
         }
         if (expansions) {
           // every active label's expansion of the cut in ONE launch: a wave owns a strip, stages it once and runs the
@@ -1192,12 +1194,16 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     if (coarse) {
       for (int lv = 0; lv < N_COARSE; ++lv) {
         const int s = COARSE_SCALE[lv];
-        const bool on = verifying || force_coarse || (active[80 + lv] && (last_changed * COARSE_ON_DIV >= b->n || coarse_changed[lv] > 0));
+        // (a verification round tries every shift of every scale -- as long as the solve has moved the labelling at
+        //  large or runs to the exact fixed point; the warm start of a later EM iteration under a stopping tolerance,
+        //  which moves 1-3 % of the labels, would pay several times its own cost for them)
+        const bool verify_coarse = verifying && (o.energy_tol_ppb == 0 || total * COARSE_ON_DIV >= b->n);
+        const bool on = verify_coarse || force_coarse || (active[80 + lv] && (last_changed * COARSE_ON_DIV >= b->n || coarse_changed[lv] > 0));
         coarse_ran[lv] = on;
         if (!on) continue;
         b->counter_slot = 80 + lv;
         for (int off = 0; off < s; ++off)
-          if (verifying || off == r % s)
+          if (verify_coarse || off == r % s)
             PHMRF_TRY(coarse_sweep_nocount(b, bf, lv, off, (2 * r + lv + off) % 6, (17 * r + 5 * lv + 13 * off) % 64, 0, K));
       }
     }
@@ -1247,8 +1253,9 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     const double gain = e_prev - e_now;
     if (e_now < e_prev) e_prev = e_now;
     // accepted tolerance: the round (all active types; the rested ones were worth at most a quarter of the tolerance
-    // together, see below) gained less than the tolerance.  A round that RAISED the energy (f32 move arithmetic against
-    // the f64 energy) is not "converged": it is quiet, and the verification round decides.
+    // together, see below) changed the energy by less than the tolerance.  A round that RAISED the energy by the
+    // tolerance or more (f32 move arithmetic against the f64 energy) is not "converged": it is quiet, and the
+    // verification round decides.
     bool coarse_moved = false, coarse_just_ran = coarse;
     for (int lv = 0; lv < N_COARSE; ++lv) {
       coarse_moved = coarse_moved || (coarse && coarse_ran[lv] && coarse_changed[lv] > 0);
@@ -1256,7 +1263,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     if (coarse_moved) coarse_checked = false;
     force_coarse = false;
-    if (o.energy_tol_ppb > 0 && gain >= 0.0 && gain < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
+    // (|gain| below the tolerance on either side: a round that moved three labels and changed the f64 energy sum by
+    //  2e-13 of itself, up or down, has converged; a rise of the tolerance's size or more has not -- the verification
+    //  round decides then)
+    if (o.energy_tol_ppb > 0 && std::fabs(gain) < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
       // A solve that has moved the labelling at large (>= 5 % of the labels so far: a cold or far-off start, not the
       // warm start of a later EM iteration) does not stop before the coarse scales have run once more and gained less
       // than the tolerance, too: their gains come in few large steps, not in the trickle the tolerance watches.

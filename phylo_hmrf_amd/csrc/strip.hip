@@ -305,8 +305,29 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     // (a listed strip has passed both tests in strip_scan_kernel already: no dependent loads in front of the work)
     if (my_memo && !work_list) {
       const int last_quiet = *my_memo;
-      if (last_quiet && (int)newest[strip] < last_quiet) continue;
+      if (last_quiet) {
+        int nw = 0;
+        if (newest) {
+          nw = newest[strip];
+        } else {                         // no per-strip table for this cut (the fusion passes): newest stamp of the cells
+          for (int e = lane; e < ncell; e += 64) {
+            const int cc = e / SH, rr = e - cc * SH;
+            const int node = strip_node(g, rs0 + rr, ca + cc);
+            if (node >= 0) {
+              const int st = stamp[node];
+              nw = st > nw ? st : nw;
+            }
+          }
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const int o2 = __shfl_xor(nw, off, 64);
+            nw = o2 > nw ? o2 : nw;
+          }
+        }
+        if (nw < last_quiet) continue;
+      }
     }
+
 
     // ---- phase 0 (expansions): strip_mask[strip] has bit a set when some cell of the strip could possibly profit from
     //      label a (alpha_mask_kernel, OR-ed per strip by strip_scan_kernel).  Otherwise: one 8-byte load and out.
@@ -549,7 +570,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
       const bool any_moved = __any(moved);
       if (my_memo && lane == 0) {
         *my_memo = any_moved ? (uint16_t)0 : (uint16_t)tick;
-        if (any_moved) newest[strip] = (uint16_t)tick;
+        if (any_moved && newest) newest[strip] = (uint16_t)tick;
       }
     }
   }
@@ -587,8 +608,11 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
 // per strip instead of once per (strip, label).
 constexpr int PEEL_MAX = 8;       // sweeps before the DP takes over with whatever U is left (any U is sound)
 
+#ifndef PHMRF_MULTI_WPE
+#define PHMRF_MULTI_WPE 3       // waves per SIMD the register allocation aims at (168 VGPRs at 3)
+#endif
 template <int ORIENT>
-__global__ __launch_bounds__(256, 3) void strip_multi_kernel(StripGeom g, int64_t n, int K, int D,
+__global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(StripGeom g, int64_t n, int K, int D,
                                                              const int32_t* __restrict__ nbr,
                                                              const float4* __restrict__ fwd_w,
                                                              const float* __restrict__ uT, uint8_t* __restrict__ labels,
@@ -807,7 +831,9 @@ __global__ __launch_bounds__(256, 3) void strip_multi_kernel(StripGeom g, int64_
 #pragma unroll
           for (int d = 0; d < 8; ++d) {
             constexpr int WPOS[8] = {0, 5, 10, 1, 11, 2, 7, 12};
-            cap += ((W >> WPOS[d]) & 1u) ? v8[p][d] : 0.f;
+            // bit -> all-ones mask (v_bfe_i32), mask the weight's bits, add: no compare / select chain
+            const int mk = __builtin_amdgcn_sbfe((int)W, WPOS[d], 1);
+            cap += __builtin_bit_cast(float, mk & __builtin_bit_cast(int, v8[p][d]));
           }
           const float capx = cap * 1.0001f + 1e-6f;                      // a hair of slack for the f32 sums
           const unsigned long long keep = __ballot(sc[p] <= capx);
@@ -1301,7 +1327,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
                      (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3),               \
                      b->tick ? b->stamp : nullptr,                                                                     \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
-                     use_memo ? b->strip_newest : nullptr, b->tick,                                                     \
+                     (use_memo && alpha >= 0) ? b->strip_newest : nullptr, b->tick,                                                   \
                      masks ? b->work_list + (int64_t)alpha * b->memo_strips : nullptr, masks ? b->work_count + alpha : nullptr, \
                      b->work_acc)
   if (orient) PHMRF_LAUNCH_STRIP(1);

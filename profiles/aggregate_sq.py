@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
             e = out.setdefault(k, {})
             e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
 keep = {k: v for k, v in out.items() if any(s in k for s in ("strip_kernel", "chain_kernel", "comp_table", "cc_union", "propose",
-                                                             "alpha_mask", "energy_kernel", "posterior", "emission", "strip_scan"))}
+                                                             "alpha_mask", "energy_kernel", "posterior", "emission", "strip_scan", "strip_multi", "cc_", "comp_"))}
 for k, v in keep.items():
     wc = v.get("SQ_WAVE_CYCLES", 0.0)
     if wc > 0:
