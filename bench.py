@@ -23,8 +23,9 @@ Extra objects on the JSON line:
                       units the launches actually processed, COUNTED ON THE DEVICE) / the time during which at least one
                       kernel of the class was running (HIP events on the blocks' streams, merged on one time line, so the
                       class's time per step can never exceed ms_per_step), against the 8 TB/s HBM peak.
-  "roofline_limiter"  the same kernel against what actually bounds it (the LDS pipe: bytes its DP steps, cost tables and
-                      staging move through LDS, from the same device counters, against 256 B/clk/CU).
+  "roofline_limiter"  what actually bounds that kernel: it is neither HBM nor the LDS pipe but instruction issue and the
+                      latency of dependent loads at 3 waves per SIMD -- the SQ counters of the committed rocprofv3 --pmc
+                      pass (profiles/r2_sq_issue_by_kernel.json) next to the LDS bytes counted live on the device.
   "cpu_baseline"      (rank 0, N=1) the reference's CPU path on a bounded sample -- see cpu_baseline().
 """
 import argparse
@@ -258,7 +259,7 @@ def main():
                 ce = e0
         return float(tot + ce - cs)
 
-    agg, work = {}, dict(units=0, cells=0, staged_cells=0, dp_steps=0, launches=0)
+    agg, work = {}, dict(units=0, cells=0, staged_cells=0, dp_steps=0, launches=0, swept_cells=0, label_cells=0)
     for b in blocks:
         for name, (ms, ln) in b.timing().items():
             d = agg.setdefault(name, [0.0, 0, 0.0])
@@ -270,7 +271,12 @@ def main():
         for k, v in b.work().items():
             work[k] += v
     if "strip" in agg:
-        agg["strip"][2] = kernel_bytes("strip", 0, K, S) * work["cells"]        # 83 B x the cells the units re-decided
+        # SURVEY.md 8d, counted on the device: a fusion / single-proposal unit re-decides its cells between two labels
+        # (83 B per cell: two unary entries, label, proposal, explicit adjacency); strip_multi_kernel sweeps a strip's
+        # cells ONCE for all listed labels: explicit adjacency + label + write (73 B per cell swept) and one unary entry
+        # per cell and listed label (4 B) -- "one MRF sweep = 4K + 9 deg + 1 bytes per node" with the K it actually ran
+        agg["strip"][2] = (kernel_bytes("strip", 0, K, S) * work["cells"] + (9 * 8 + 1) * work["swept_cells"]
+                           + 4.0 * work["label_cells"])
     busy = {name: union_ms(np.concatenate([b.intervals(name) for b in blocks] or [np.zeros((0, 2))]))
             for name in agg} if not a.no_kernel_timing and blocks else {}
     roofline = roofline_limiter = None
@@ -283,21 +289,29 @@ def main():
                     "launches": int(dom_launches), "algorithmic_bytes_per_launch": int(dom_bytes / max(dom_launches, 1)),
                     "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2),
                     "busy_ms_per_step": round(busy[dom_name] / a.steps, 3),
-                    "note": "achieved = algorithmic bytes of all launches / time during which >= 1 launch of the class "
-                            "was running (blocks run concurrently on their own streams); avg_launch_us = mean launch "
-                            "duration incl. the share of the GPU other streams took"}
+                    "note": "achieved = algorithmic bytes (SURVEY.md 8d accounting x the cells the launches processed, "
+                            "counted on the device) / time during which >= 1 launch of the class was running (blocks "
+                            "run concurrently on their own streams); avg_launch_us = mean launch duration incl. the "
+                            "share of the GPU other streams took; traffic = PMC FETCH_SIZE + WRITE_SIZE per launch"}
         if dom_name == "strip":
-            # what one unit moves through LDS: DP steps x 64 lanes x 8 B; per 64-cell pass 64 x 128 B of cost tables
-            # written; staging 5 words per staged cell written and (1 + 2 x 8) words per strip cell read back
-            lds_bytes = work["dp_steps"] * 512.0 + work["cells"] * (128.0 + 68.0) + work["staged_cells"] * 20.0
+            # what the strip kernels move through LDS (device counters): a DP step reads 64 lanes x 8 B and its cell's
+            # table (128 B) was written once; staging writes 5 words per staged cell and reads 17 back per strip cell
+            lds_bytes = (work["dp_steps"] * (512.0 + 128.0) + work["staged_cells"] * 20.0
+                         + (work["cells"] + work["swept_cells"]) * 68.0)
             lds_ach = lds_bytes / (busy["strip"] * 1e-3) / 1e12
             lds_peak = 256 * 256 * 2.4e9 / 1e12      # 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS)
-            roofline_limiter = {"bound": "lds", "kernel": "strip", "achieved": round(lds_ach, 2), "peak": round(lds_peak, 1),
-                                "unit": "TB/s", "frac": round(lds_ach / lds_peak, 4),
-                                "units": int(work["units"]), "cells": int(work["cells"]), "dp_steps": int(work["dp_steps"]),
-                                "designed_hbm_bytes_per_launch": int(25.0 * work["staged_cells"] / max(work["launches"], 1)),
-                                "note": "LDS bytes from the device counters; the DP walk also needs ~6 VALU "
-                                        "instructions per step (profiles/: SQ issue counters)"}
+            roofline_limiter = {"bound": "issue+latency", "kernel": "strip",
+                                "sq": sq_profile("strip_multi_kernel"),
+                                "lds": {"achieved": round(lds_ach, 2), "peak": round(lds_peak, 1), "unit": "TB/s",
+                                        "frac": round(lds_ach / lds_peak, 4)},
+                                "units": int(work["units"]), "single_proposal_cells": int(work["cells"]),
+                                "swept_cells": int(work["swept_cells"]), "label_cells": int(work["label_cells"]),
+                                "dp_steps": int(work["dp_steps"]),
+                                "note": "since the exact filter (DESIGN.md 3.1) few (strip, label) pairs reach the DP: the "
+                                        "kernel is bound neither by HBM nor by the LDS pipe but by VALU/SALU issue at 3 "
+                                        "waves per SIMD and the latency of its dependent loads; `sq` = the SQ counters of "
+                                        "profiles/ (rocprofv3 --pmc, one block at a time): VALU issue share of a wave's "
+                                        "cycles x waves per SIMD = share of the SIMD's issue capacity"}
     kernels = {k: {"ms": round(v[0], 3), "launches": int(v[1]), "busy_ms": round(busy.get(k, 0.0), 3),
                    "GBps": (round(v[2] / (busy[k] * 1e-3) / 1e9, 1) if busy.get(k, 0) > 0 and v[2] > 0 else None)}
                for k, v in agg.items()}
@@ -338,6 +352,19 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def sq_profile(kernel):
+    """SQ counters of one kernel from the rocprofv3 --pmc pass committed under profiles/ (r2_sq_issue_by_kernel.json),
+    as ratios of the wave's cycles; None when not on file."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_sq_issue_by_kernel.json")))[kernel]
+        out = {k.replace("SQ_", "").replace("/WAVE_CYCLES", "_per_wave_cycle").lower(): v for k, v in d.items() if "/" in k}
+        if "SQ_INSTS_VALU" in d and "SQ_WAVE_CYCLES" in d:
+            out["valu_issue_share_of_simd_at_3_waves"] = round(3.0 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 3)
+        return out
+    except Exception:
+        return None
 
 
 def pmc_traffic(workload, kernel_class):

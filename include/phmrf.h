@@ -218,8 +218,11 @@ PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
  *   out[0] strips staged (one unit = one strip under one move: alpha-expansion or fusion)
  *   out[1] their strip cells (the nodes a unit re-decides: 5 x columns)
  *   out[2] grid cells staged (strip + fixed rim, 7 x (columns + 2): what a unit reads from HBM)
- *   out[3] DP steps walked (one 64-state step = one cell of one unit)   out[4] strip launches                      */
-PHMRF_API int phmrf_block_get_work(phmrf_block_t b, int64_t* out /*[5]*/);
+ *   out[3] DP steps walked (one 64-state step = one cell of one unit)   out[4] strip launches
+ *   strip_multi_kernel (all labels of a strip in one wave) counts a (strip, label) pair in out[0] and, instead of
+ *   out[1]:  out[5] the strip cells it swept (once per strip visit, whatever the number of labels),
+ *            out[6] cells x labels examined (one label's unary term per cell)                                        */
+PHMRF_API int phmrf_block_get_work(phmrf_block_t b, int64_t* out /*[7]*/);
 /* The timed intervals of one kernel class on a time base common to all blocks of the calling thread's device
  * (phmrf_time_base_reset marks t = 0; call it before the timed region): out = [start_ms, end_ms] pairs, at most
  * `capacity` of them; *count = how many there are.  Blocks run on their own streams, so their intervals overlap:

@@ -336,10 +336,10 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
   if (st == PHMRF_OK) guard(dev_alloc(&b->labels_tmp, (size_t)n));
   if (st == PHMRF_OK) guard(dev_alloc(&b->accum, (size_t)ACCUM_DOUBLES));
   if (st == PHMRF_OK) guard(dev_alloc(&b->counters, (size_t)128));
-  if (st == PHMRF_OK) guard(dev_alloc(&b->work_acc, (size_t)WORK_BANKS * 4));
-  if (st == PHMRF_OK && hipMemsetAsync(b->work_acc, 0, WORK_BANKS * 4 * sizeof(unsigned long long), b->own_stream) != hipSuccess)
+  if (st == PHMRF_OK) guard(dev_alloc(&b->work_acc, (size_t)WORK_BANKS * WORK_SLOTS));
+  if (st == PHMRF_OK && hipMemsetAsync(b->work_acc, 0, WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long), b->own_stream) != hipSuccess)
     guard(fail(PHMRF_ERR_HIP, "hipMemset failed"));
-  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->work_host), WORK_BANKS * 4 * sizeof(unsigned long long)) != hipSuccess)
+  if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->work_host), WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long)) != hipSuccess)
     guard(fail(PHMRF_ERR_HIP, "hipHostMalloc failed"));
   if (st == PHMRF_OK) guard(dev_alloc(&b->emis_params, (size_t)K * (S + S * (S + 1) / 2 + 1)));
   if (st == PHMRF_OK && hipHostMalloc(reinterpret_cast<void**>(&b->accum_host), ACCUM_DOUBLES * sizeof(double)) != hipSuccess)
@@ -757,13 +757,14 @@ static int zero_counter(phmrf_block_t b) {
 
 // strip-kernel work counters: device banks -> host totals (the stream must be synchronised by the caller afterwards)
 static int work_fetch_async(phmrf_block_t b) {
-  PHMRF_HIP(hipMemcpyAsync(b->work_host, b->work_acc, WORK_BANKS * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
-  PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * 4 * sizeof(unsigned long long), b->stream));
+  PHMRF_HIP(hipMemcpyAsync(b->work_host, b->work_acc, WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long), b->stream));
   return PHMRF_OK;
 }
 static void work_fold(phmrf_block_t b) {
+  static const int SLOT_OF[WORK_SLOTS] = {0, 1, 2, 3, 5, 6};      // work[4] = launches (host-counted)
   for (int k = 0; k < WORK_BANKS; ++k)
-    for (int q = 0; q < 4; ++q) b->work[q] += (int64_t)b->work_host[k * 4 + q];
+    for (int q = 0; q < WORK_SLOTS; ++q) b->work[SLOT_OF[q]] += (int64_t)b->work_host[k * WORK_SLOTS + q];
 }
 
 static int check_solvable(phmrf_block_t b) {
@@ -1421,8 +1422,8 @@ int phmrf_block_reset_timing(phmrf_block_t b) {
     b->ms[i] = 0;
     b->launches[i] = 0;
   }
-  for (int q = 0; q < 5; ++q) b->work[q] = 0;
-  PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * 4 * sizeof(unsigned long long), b->stream));
+  for (int q = 0; q < 8; ++q) b->work[q] = 0;
+  PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long), b->stream));
   b->intervals.clear();
   return PHMRF_OK;
 }
@@ -1440,7 +1441,7 @@ int phmrf_time_base_reset(void) {
 
 int phmrf_block_get_work(phmrf_block_t b, int64_t* out) {
   PHMRF_CHECK(b && out, PHMRF_ERR_INVALID, "NULL argument");
-  for (int q = 0; q < 5; ++q) out[q] = b->work[q];
+  for (int q = 0; q < 7; ++q) out[q] = b->work[q];
   return PHMRF_OK;
 }
 

@@ -127,7 +127,7 @@ struct phmrf_block {
   double* accum_host = nullptr;             // pinned mirror
   unsigned long long* counters = nullptr;   // device [128]
   unsigned long long* counters_host = nullptr;
-  unsigned long long* work_acc = nullptr;   // device [WORK_BANKS][4], zeroed and read back with the counters
+  unsigned long long* work_acc = nullptr;   // device [WORK_BANKS][WORK_SLOTS], zeroed and read back with the counters
   unsigned long long* work_host = nullptr;  // pinned mirror
 
   // timing: event pairs recorded on the block's stream, resolved lazily (no host sync inside the measured loop)
@@ -139,14 +139,15 @@ struct phmrf_block {
   hipEvent_t cur_start = nullptr;
   double ms[PHMRF_NUM_KERNEL_CLASSES] = {};
   int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {};
-  int64_t work[5] = {};                     // strips staged, their cells, staged cells, DP steps, strip launches (since reset_timing)
+  int64_t work[8] = {};                     // strips staged, their cells, staged cells, DP steps, strip launches (since reset_timing)
   struct Interval { int kclass; float t0, t1; };
   std::vector<Interval> intervals;          // resolved timed intervals on the library's common time base (ms)
 };
 
 namespace phmrf {
 
-constexpr int WORK_BANKS = 256;       // work_acc[WORK_BANKS][4]: strips staged, their cells, staged cells (with rim), DP
+constexpr int WORK_SLOTS = 6;         // see phmrf_block_get_work
+constexpr int WORK_BANKS = 256;       // work_acc[WORK_BANKS][WORK_SLOTS]: strips staged, their cells, staged cells (with rim), DP
                                       // steps of the strip kernels, one bank per workgroup id mod 256 (no hot address)
 constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every (K,S) the posterior / statistics kernel supports
                                      // (K <= 64, S <= 8: 4,688); phmrf_posterior_stats rejects anything larger

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
   __syncthreads();                       // every wave of the workgroup gets here (the strip loop only `continue`s)
   if (work && threadIdx.x < 4) {         // one add per workgroup and counter, spread over WORK_BANKS addresses
     const unsigned int v = wk[threadIdx.x];
-    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * 4 + threadIdx.x, (unsigned long long)v);
+    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + threadIdx.x, (unsigned long long)v);
   }
 }
 
@@ -621,13 +621,13 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
                                                              uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                              int tick0, unsigned long long* __restrict__ work, int peel_max) {
   __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];
-  __shared__ unsigned int wk[4];
+  __shared__ unsigned int wk[WORK_SLOTS];   // units, -, staged cells, DP steps, cells swept (once per strip visit), label-cells
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
   float* tab = tabs + wave * SLAB;
   int* tabi = reinterpret_cast<int*>(tab);
-  if (threadIdx.x < 4) wk[threadIdx.x] = 0u;
+  if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
   __syncthreads();
   const int sh5 = lane & 31;
   const bool hi_half = lane >= 32;
@@ -738,7 +738,10 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
+        if (lane == 0) {
+          atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
+          atomicAdd(&wk[4], (unsigned int)ncell);               // the strip's cells, swept for every listed label
+        }
         // ---- extraction: lane <-> strip cell
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
       todo &= todo - 1ull;
       if (lane == 0) {
         atomicAdd(&wk[0], 1u);
-        atomicAdd(&wk[1], (unsigned int)ncell);
+        atomicAdd(&wk[5], (unsigned int)ncell);                 // one label's unary terms for the strip's cells
       }
 
       // ---- single-site costs and the starting set
@@ -982,9 +985,9 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
     }
   }
   __syncthreads();
-  if (work && threadIdx.x < 4) {
+  if (work && threadIdx.x < WORK_SLOTS) {
     const unsigned int v = wk[threadIdx.x];
-    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * 4 + threadIdx.x, (unsigned long long)v);
+    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + threadIdx.x, (unsigned long long)v);
   }
 }
 

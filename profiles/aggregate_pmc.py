@@ -9,8 +9,9 @@ FETCH_DIR / WRITE_DIR hold the outputs of
 """
 import csv, glob, json, os, sys
 
-CLASSES = {"strip": ["strip_kernel"], "chain": ["chain_kernel"], "icm": ["icm_kernel"], "posterior_stats": ["posterior_kernel"],
+CLASSES = {"strip": ["strip_multi_kernel", "strip_kernel"], "chain": ["chain_kernel"], "icm": ["icm_kernel"], "posterior_stats": ["posterior_kernel"],
            "energy": ["energy_kernel"], "propose": ["propose_kernel", "alpha_mask_kernel", "strip_scan_kernel", "unary_planes_kernel"],
+           "coarse": ["coarsen_kernel", "coarse_apply_kernel"],
            "emission": ["emission_kernel"],
            "component": ["cc_init_kernel", "cc_union_kernel", "cc_flatten_kernel", "comp_table_kernel", "comp_decide_kernel",
                          "comp_block_kernel", "comp_apply_kernel"]}
@@ -45,8 +46,9 @@ def main():
     for cls, kernels in CLASSES.items():
         fs = sum(fetch.get(k, {}).get("sum", 0.0) for k in kernels)
         ws = sum(write.get(k, {}).get("sum", 0.0) for k in kernels)
-        # a class "launch" is one launch of its first (main) kernel
-        n = fetch.get(kernels[0], {}).get("launches", 0)
+        # a class "launch" is one launch of its main kernel(s): both strip kernels for the strip class
+        n = (sum(fetch.get(k, {}).get("launches", 0) for k in kernels) if cls == "strip"
+             else fetch.get(kernels[0], {}).get("launches", 0))
         if not n:
             continue
         traffic[cls] = {"fetch_size_kb_per_launch": fs / n, "write_size_kb_per_launch": ws / n, "launches_profiled": n,
