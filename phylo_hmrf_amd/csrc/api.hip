@@ -912,7 +912,8 @@ int phmrf_mrf_strip_multi_pass(phmrf_block_t b, double beta, int orient, int shi
 // ---- coarse alpha-expansions (coarse.hip) ----------------------------------------------------------------------
 static const int N_COARSE = 3;
 static const int COARSE_SCALE[N_COARSE] = {2, 4, 8};
-static const int64_t COARSE_ON_DIV = 20;      // "moving at large": a round / a solve changed >= 1/20 of the labels
+static const int64_t COARSE_ON_DIV = 20;      // "moved at large": a solve changed >= 1/20 of the labels so far
+static const int64_t COARSE_ROUND_DIV = 4;    // "moving at large": a round changed >= 1/4 of the labels (a cold start)
 
 static int coarse_child(phmrf_block_t b, int level, phmrf_block** out) {
   if (!b->coarse[level]) {
@@ -951,6 +952,7 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   int n_launch = 0;
   for (int a = alpha_lo; a < alpha_hi; ++a) {
     PHMRF_TRY(launch_coarsen(b, c, s, off, a, beta));
+    // (measured: the filtered multi-label kernel is 15-20 % slower than the plain one on these one-label problems)
     PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, false, -1));
     PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, false, -1));
     if (b->tick) ++b->tick;
@@ -1188,8 +1190,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     // coarse alpha-expansions: in verification rounds, and while the labelling is still moving at large (the previous
     // round changed at least 0.5 % of the labels) -- a warm start that is nearly converged never pays for them
-    // Coarse scales switch on while the labelling is still moving at large (the previous round changed >= 5 % of the
-    // labels: a cold or far-off start; the warm start of a later EM iteration, which moves 1-3 %, does not pay for them).
+    // Coarse scales switch on while the labelling is still moving at large (the previous round changed >= 25 % of the
+    // labels: a cold start).  A solve that has moved >= 5 % of the labels in all (the far-off warm start of an early EM
+    // iteration) gets them once at the end, before the tolerance may stop it (force_coarse below); the warm start of a
+    // later EM iteration, which moves 1-3 %, does not pay for them at all.
     // A scale that changed labels in its last run stays on (like every move type), with the super-cell grid shifted by
     // one node per round; a verification round tries every shift of both scales.
     if (coarse) {
@@ -1199,7 +1203,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         //  large or runs to the exact fixed point; the warm start of a later EM iteration under a stopping tolerance,
         //  which moves 1-3 % of the labels, would pay several times its own cost for them)
         const bool verify_coarse = verifying && (o.energy_tol_ppb == 0 || total * COARSE_ON_DIV >= b->n);
-        const bool on = verify_coarse || force_coarse || (active[80 + lv] && (last_changed * COARSE_ON_DIV >= b->n || coarse_changed[lv] > 0));
+        const bool on = verify_coarse || force_coarse || (active[80 + lv] && (last_changed * COARSE_ROUND_DIV >= b->n || coarse_changed[lv] > 0));
         coarse_ran[lv] = on;
         if (!on) continue;
         b->counter_slot = 80 + lv;

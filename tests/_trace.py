@@ -20,7 +20,7 @@ b.emission(mu2, cv2)
 res = b.solve(1.0, energy_tol_ppb=tol, init_mode=1, use_expansion=expn)
 print("cold solve:", res)
 # warm start as in EM iteration >= 1: perturb the parameters slightly, keep labels
-P3 = np.clip(P2 * (1 + 0.02 * rng.standard_normal(P.shape)), 1e-3, 50); mu3, cv3 = tree.mean_cov(P3); cv3 = cv3 + 1e-3 * np.eye(S)
+P3 = np.clip(P2 * (1 + float(os.environ.get("PHMRF_TRACE_PERT", "0.02")) * rng.standard_normal(P.shape)), 1e-3, 50); mu3, cv3 = tree.mean_cov(P3); cv3 = cv3 + 1e-3 * np.eye(S)
 b.emission(mu3, cv3)
 sys.stderr.write("---- warm\n")
 res = b.solve(1.0, energy_tol_ppb=tol, init_mode=0, use_expansion=expn)
