@@ -1122,6 +1122,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   // is mopping up, so those rounds only revisit the strips whose inputs changed -- a warm start pays for one full
   // sweep per solve instead of one per round.
   int geom = b->geom_phase % 3;
+  bool prev_moving = false;            // the previous round moved >= 1/64 of the labels
   struct GeomScope {
     phmrf_block* blk;
     int* g;
@@ -1151,7 +1152,12 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       b->counter_slot = 76;
       PHMRF_TRY(icm_sweep_nocount(b, bf));
     }
-    if (o.use_components && active[77]) {
+    // component moves: a full pass over the block (seven kernels) whatever the number of labels that changed.  On grid
+    // blocks they run in a solve's first round, after a round that moved the labelling at large, and in verification
+    // rounds; the mop-up rounds in between (a few hundred changed labels, of which the pass would take a dozen) skip
+    // them.  On general graphs, where they are one of two move types, they run in every round.
+    const bool comp_round = rounds == 0 || verifying || prev_moving || !(chains || strips);
+    if (o.use_components && active[77] && comp_round) {
       b->counter_slot = 77;
       if (b->tick) ++b->tick;
       tic(b);
@@ -1224,6 +1230,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     total += ch;
     last_changed = ch;
     const bool moving = ch * 64 >= b->n;
+    prev_moving = moving;
     if (moving) geom = (geom + 1) % 3;
     for (int lv = 0; lv < N_COARSE; ++lv)
       if (coarse_ran[lv]) coarse_changed[lv] = (int64_t)b->counters_host[80 + lv];

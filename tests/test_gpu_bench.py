@@ -38,8 +38,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k["busy_ms"] <= k["ms"] + 1e-3 and k["busy_ms"] <= d["ms_per_step"] * d["steps"] + 1e-3
     if r["kernel"] == "strip":
         lim = d["roofline_limiter"]
-        assert lim["bound"] == "lds" and 0 < lim["frac"] < 1 and lim["units"] > 0 and lim["dp_steps"] > lim["units"]
-        assert lim["cells"] <= 315 * lim["units"]
+        # device-counted work: (strip, label) pairs, cells swept once per strip visit, one unary entry per cell and label
+        assert lim["bound"] == "issue+latency" and 0 < lim["lds"]["frac"] < 1 and lim["units"] > 0 and lim["dp_steps"] > 0
+        assert 0 < lim["swept_cells"] <= lim["label_cells"] <= 315 * lim["units"]
+        assert lim["single_proposal_cells"] > 0
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "vectorised", "all_cores_upper_bound"):
         assert key in c, key
