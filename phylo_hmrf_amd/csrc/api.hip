@@ -383,17 +383,11 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->comp_best);
   dev_free(b->comp_gain);
   dev_free(b->comp_move);
-  dev_free(b->alpha_mask);
   dev_free(b->stamp);
   dev_free(b->memo);
   dev_free(b->chain_memo);
-  dev_free(b->strip_newest);
-  dev_free(b->strip_mask);
-  dev_free(b->work_list);
-  dev_free(b->work_count);
   dev_free(b->fwd_w);
   dev_free(b->uT);
-  dev_free(b->u_cur);
   dev_free(b->emis_params);
   dev_free(b->posteriors);
   dev_free(b->accum);
@@ -848,8 +842,8 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   return PHMRF_OK;
 }
 
-static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask = false,
-                              int geom = -1, bool timed = true) {
+static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, int geom = -1,
+                              bool timed = true) {
   if (alpha < 0) {
     tic(b);
     PHMRF_TRY(launch_propose(b, beta));
@@ -862,7 +856,7 @@ static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift
   }
   if (timed) tic(b);
   if (b->tick) ++b->tick;
-  PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, use_mask, geom));
+  PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, geom));
   b->work[4] += 1;
   if (timed) toc(b, KC_STRIP, 1);
   return PHMRF_OK;
@@ -953,8 +947,8 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   for (int a = alpha_lo; a < alpha_hi; ++a) {
     PHMRF_TRY(launch_coarsen(b, c, s, off, a, beta));
     // (measured: the filtered multi-label kernel is 15-20 % slower than the plain one on these one-label problems)
-    PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, false, -1));
-    PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, false, -1));
+    PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, -1));
+    PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, -1));
     if (b->tick) ++b->tick;
     PHMRF_TRY(launch_coarse_apply(b, c, s, off, a));
     n_launch += 4;
@@ -1057,7 +1051,6 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
   PHMRF_HIP(hipMemsetAsync(b->stamp, 0, (size_t)b->n * sizeof(uint16_t), b->stream));
   b->tick = 1;
-  b->mask_tick = -1;
   b->prop_tick = -1;
   if (chains) {                       // segment memos of all families: one buffer, one memset
     size_t total = 0;
@@ -1087,14 +1080,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     if (!b->memo || b->memo_strips < max_strips) {
       dev_free(b->memo);
-      dev_free(b->strip_newest);
-      dev_free(b->strip_mask);
-      dev_free(b->work_list);
-      if (!b->work_count) PHMRF_TRY(dev_alloc(&b->work_count, (size_t)64));
-      PHMRF_TRY(dev_alloc(&b->work_list, (size_t)max_strips * K));
       PHMRF_TRY(dev_alloc(&b->memo, (size_t)6 * max_strips * (K + 1)));
-      PHMRF_TRY(dev_alloc(&b->strip_newest, (size_t)max_strips));
-      PHMRF_TRY(dev_alloc(&b->strip_mask, (size_t)max_strips));
       b->memo_strips = max_strips;
     }
     PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * (K + 1) * sizeof(uint16_t), b->stream));
@@ -1104,7 +1090,6 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     ~SolveScope() {
       blk->tick = 0;
       blk->counter_slot = 0;
-      blk->mask_tick = -1;
       blk->prop_tick = -1;
     }
   } scope{b};
@@ -1170,7 +1155,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           b->counter_slot = 78 + orient;
           // the fusion pass runs on a cut of its own that moves with the expansions' (so that its memo of quiet strips
           // applies while the cut stays): the expansion cut shifted by half a band / half a segment
-          PHMRF_TRY(strip_pass_nocount(b, bf, orient, (GEOM_R[geom] + 3) % 6, (GEOM_C[geom] + 31) % 64, -1, false, geom));
+          PHMRF_TRY(strip_pass_nocount(b, bf, orient, (GEOM_R[geom] + 3) % 6, (GEOM_C[geom] + 31) % 64, -1, geom));
         }
         if (expansions) {
           // every active label's expansion of the cut in ONE launch: a wave owns a strip, stages it once and runs the

@@ -94,19 +94,13 @@ struct phmrf_block {
   int32_t* comp_best = nullptr;             // device [n]
   float* comp_gain = nullptr;               // device [n]
   uint8_t* comp_move = nullptr;             // device [n]
-  unsigned long long* alpha_mask = nullptr; // device [n]: labels a node could profit from (strip expansions)
   // grid-native inputs of the strip kernels
   float4* fwd_w = nullptr;                  // device [n]: weights of the four forward grid edges (E, SW, S, SE)
   float* uT = nullptr;                      // device [K][n]: unary planes, uT[k][i] = -logprob[i][k]
   bool uT_valid = false;                    //   ... current with logprob
-  float* u_cur = nullptr;                   // device [n]: -logprob[i][l_i], kept current during the expansions of a round
   // coarse alpha-expansions (coarse.hip): child blocks holding the two-label problem of the super-cells, side 2, 4, 8
   phmrf_block* coarse[3] = {nullptr, nullptr, nullptr};
-  unsigned long long* strip_mask = nullptr; // device [memo_strips]: OR of alpha_mask over a strip's cells (current cut)
-  int32_t* work_list = nullptr;             // device [K][memo_strips]: strips queued for the expansion of each label
-  int32_t* work_count = nullptr;            // device [64]: their number
-  int mask_tick = -1, prop_tick = -1;       // tick of the last alpha-mask / proposal launch of this solve (-1: none)
-  int scan_geom = 0;                        // which fixed cut launch_strip_scan is building the tables for
+  int prop_tick = -1;                       // tick of the last proposal launch of this solve (-1: none)
   int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
   // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS
   // (0 = not since the solve began);
@@ -116,7 +110,6 @@ struct phmrf_block {
   uint16_t* memo = nullptr;                 // device [2][3][memo_strips][K+1]  (slot K: the fusion pass)
   uint16_t* chain_memo = nullptr;           // device: the chain families' segment memos (ChainFamily::memo slices)
   size_t chain_memo_count = 0;
-  uint16_t* strip_newest = nullptr;         // device [memo_strips]: newest stamp among a strip's cells (current cut)
   int64_t memo_strips = 0;
   int tick = 0;                             // host launch counter inside one solve (0 = stamping off)
   int counter_slot = 0;                     // which of counters[128] the next move launches add their changes to
@@ -169,17 +162,15 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
 int launch_component_pass(phmrf_block* b, float beta);
 int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, double beta1);
 int launch_propose(phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
-int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
-                      int geom = -1);   // geom 0..2: one of the three fixed expansion geometries (enables the memo)
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha,
+                      int geom = -1);   // geom 0..2: one of the three fixed cuts (enables the memo of quiet strips)
 int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, unsigned long long label_mask,
                        int geom = -1);   // all listed alpha-expansions of the cut, one wave per strip
-int launch_alpha_mask(phmrf_block* b, float beta);
-int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int geom);   // -> strip_newest, strip_mask
 int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev);
 int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
 int64_t coarse_nodes(const phmrf_block* b, int s, int off);                        // nodes of the coarse grid (s, off)
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta);
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha);
-int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT   // node -> set of labels worth an expansion (alpha_mask)  // adds relabelled nodes to counters[0]
+int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
 
 }  // namespace phmrf

@@ -261,14 +261,10 @@ constexpr int NPASS = 5;   // ceil(315 / 64)
 template <int ORIENT>
 __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g, int64_t n, int K, int D,
                                                     const int32_t* __restrict__ nbr, const float4* __restrict__ fwd_w,
-                                                    const float* __restrict__ uT, float* __restrict__ u_cur,
-                                                    uint8_t* __restrict__ labels, const uint8_t* __restrict__ prop,
-                                                    int alpha, float beta, unsigned long long* __restrict__ changed,
-                                                    const unsigned long long* __restrict__ strip_mask, int debug,
-                                                    uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
-                                                    uint16_t* __restrict__ newest, int tick,
-                                                    const int32_t* __restrict__ work_list,
-                                                    const int32_t* __restrict__ work_count,
+                                                    const float* __restrict__ uT, uint8_t* __restrict__ labels,
+                                                    const uint8_t* __restrict__ prop, int alpha, float beta,
+                                                    unsigned long long* __restrict__ changed, int debug,
+                                                    uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo, int tick,
                                                     unsigned long long* __restrict__ work) {
   __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];   // one 9.1 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -282,11 +278,8 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
   if (threadIdx.x < 4) wk[threadIdx.x] = 0u;
   __syncthreads();
 
-  // waves are independent.  Expansions inside a solve walk the dense work list of their label (strip_scan_kernel),
-  // everything else all strips of the cut.
-  const int n_work = work_list ? *work_count : nstrips;
-  for (int wi = blockIdx.x * WPB + wave; wi < n_work; wi += gridDim.x * WPB) {
-    const int strip = work_list ? work_list[wi] : wi;
+  // waves are independent: every wave walks strips of the cut
+  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
     const int rs0 = bnd * (SH + 1) - g.shift_r;
@@ -296,44 +289,30 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
     const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
 
-    // ---- memo test (inside a solve): `newest[strip]` is the newest DILATED change stamp among the strip's cells
-    //      (strip_newest_kernel, kept current by this kernel); a stamp is renewed whenever the node or one of its
-    //      neighbours changes label, so it covers the fixed border too.  If nothing changed since this very strip was
-    //      last found quiet for this move, its inputs are identical -> nothing to do.
+    // ---- memo test (inside a solve, fixed cuts): a (dilated) change stamp is renewed whenever the node or one of its
+    //      neighbours changes label, so the newest stamp among the strip's cells covers the fixed border too.  If nothing
+    //      changed since this very strip was last found quiet for this move, its inputs are identical -> nothing to do.
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 100, 1ull);   // strips seen (expansion slots only)
     uint16_t* my_memo = memo ? memo + (int64_t)strip * (K + 1) + (alpha >= 0 ? alpha : K) : nullptr;
-    // (a listed strip has passed both tests in strip_scan_kernel already: no dependent loads in front of the work)
-    if (my_memo && !work_list) {
+    if (my_memo) {
       const int last_quiet = *my_memo;
       if (last_quiet) {
         int nw = 0;
-        if (newest) {
-          nw = newest[strip];
-        } else {                         // no per-strip table for this cut (the fusion passes): newest stamp of the cells
-          for (int e = lane; e < ncell; e += 64) {
-            const int cc = e / SH, rr = e - cc * SH;
-            const int node = strip_node(g, rs0 + rr, ca + cc);
-            if (node >= 0) {
-              const int st = stamp[node];
-              nw = st > nw ? st : nw;
-            }
+        for (int e = lane; e < ncell; e += 64) {
+          const int cc = e / SH, rr = e - cc * SH;
+          const int node = strip_node(g, rs0 + rr, ca + cc);
+          if (node >= 0) {
+            const int st = stamp[node];
+            nw = st > nw ? st : nw;
           }
+        }
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) {
-            const int o2 = __shfl_xor(nw, off, 64);
-            nw = o2 > nw ? o2 : nw;
-          }
+        for (int off = 32; off > 0; off >>= 1) {
+          const int o2 = __shfl_xor(nw, off, 64);
+          nw = o2 > nw ? o2 : nw;
         }
         if (nw < last_quiet) continue;
       }
-    }
-
-
-    // ---- phase 0 (expansions): strip_mask[strip] has bit a set when some cell of the strip could possibly profit from
-    //      label a (alpha_mask_kernel, OR-ed per strip by strip_scan_kernel).  Otherwise: one 8-byte load and out.
-    if (strip_mask && !work_list && alpha >= 0 && !((strip_mask[strip] >> alpha) & 1ull)) {
-      if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
-      continue;
     }
 
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
@@ -424,7 +403,7 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
           const int lw = tabi[e0 * REC + 4];
           const int l = lw & 255, pl = (lw >> 8) & 255;
           const bool can = pl != l;
-          const float u0 = u_cur ? u_cur[node] : uT[(int64_t)l * n + node];
+          const float u0 = uT[(int64_t)l * n + node];
           const float u1 = can ? uT[(int64_t)pl * n + node] : BIG;
           float a0 = 0.f, a1 = 0.f;            // rim sums
 #pragma unroll
@@ -555,7 +534,6 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
         const int node = strip_node(g, rs0 + rr, ca + cc);
         if (node < 0) continue;
         labels[node] = prop ? prop[node] : (uint8_t)alpha;
-        if (u_cur) u_cur[node] = uT[(int64_t)alpha * n + node];
         if (stamp) {
           stamp[node] = (uint16_t)tick;
           const int32_t* nb2 = nbr + (int64_t)node * D;
@@ -570,7 +548,6 @@ __global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g
       const bool any_moved = __any(moved);
       if (my_memo && lane == 0) {
         *my_memo = any_moved ? (uint16_t)0 : (uint16_t)tick;
-        if (any_moved && newest) newest[strip] = (uint16_t)tick;
       }
     }
   }
@@ -621,6 +598,9 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
                                                              uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                              int tick0, unsigned long long* __restrict__ work, int peel_max) {
   __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];
+  // the strip's node ids, cell order (lane <-> cell t = 64 p + lane): read back from LDS wherever the label loop needs
+  // them, so that they do not sit in (spilled) registers across it
+  __shared__ int node_tab[4][NPASS * 64];
   __shared__ unsigned int wk[WORK_SLOTS];   // units, -, staged cells, DP steps, cells swept (once per strip visit), label-cells
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -655,6 +635,7 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
         const int cc = t / SH, rr = t - cc * SH;
         nodev[p] = strip_node(g, rs0 + rr, ca + cc);
       }
+      node_tab[wave][p * 64 + lane] = nodev[p];
     }
     unsigned long long todo = label_mask;
     uint16_t* mrow = memo ? memo + (int64_t)strip * (K + 1) : nullptr;
@@ -685,6 +666,28 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
     unsigned int inm13[NPASS];     // the inside mask at the positions of the 13-bit neighbourhood window
     float ucur[NPASS], hself[NPASS];
     bool staged = false;
+    // the label's unary terms: loaded one label AHEAD into the same registers (they are free once the single-site
+    // costs are formed; the rare DP reads its label's terms again), so that the load's latency hides behind the sweeps
+    float u1[NPASS];
+    int alpha_cur = __ffsll((long long)todo) - 1;
+    {
+      // (node ids from LDS through an opaque index: kept in registers across the label loop -- as ids or as hoisted
+      //  64-bit addresses -- they get spilled, and every load then waits for a scratch reload and for the load before.
+      //  Absent cells load node 0 and discard it: no divergent branch between the five loads.)
+      int nd[NPASS];
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        int ix = p * 64 + lane;
+        asm volatile("" : "+v"(ix));
+        nd[p] = node_tab[wave][ix];
+      }
+      const float* plane = uT + (int64_t)alpha_cur * n;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const float v = plane[nd[p] < 0 ? 0 : nd[p]];
+        u1[p] = nd[p] >= 0 ? v : BIG;
+      }
+    }
 
     while (todo) {
       if (!staged) {
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
             const int cc = t / SH, rr = t - cc * SH;
             const int e0 = (cc + 1) * EH + (rr + 1);
             const int l = tabi[e0 * REC + 4] & 255;
-            mt = (unsigned int)l;
+            mt = (unsigned int)l | (1u << 24);            // bit 24: the cell is a node
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
               constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
@@ -788,7 +791,7 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
         staged = true;
       }
 
-      const int alpha = __ffsll((long long)todo) - 1;
+      const int alpha = alpha_cur;
       todo &= todo - 1ull;
       if (lane == 0) {
         atomicAdd(&wk[0], 1u);
@@ -796,10 +799,8 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
       }
 
       // ---- single-site costs and the starting set
-      float u1[NPASS], sc[NPASS];
+      float sc[NPASS];
       unsigned long long U[NPASS];
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) u1[p] = nodev[p] >= 0 ? uT[(int64_t)alpha * n + nodev[p]] : BIG;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         float hist = 0.f;
@@ -809,9 +810,30 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
           hist += lj == alpha ? v8[p][d] : 0.f;      // (a neighbour labelled alpha differs from l_i: v8 holds plain w)
         }
         const int l = (int)(meta[p] & 255u);
-        const bool ok = nodev[p] >= 0 && l != alpha && u1[p] < 1.0e29f;
+        const bool ok = ((meta[p] >> 24) & 1u) && l != alpha && u1[p] < 1.0e29f;
         sc[p] = u1[p] - ucur[p] + hself[p] - hist;
         U[p] = __ballot(ok);
+      }
+      if (todo) {                                   // the next label's terms, in flight during the sweeps
+        alpha_cur = __ffsll((long long)todo) - 1;
+    {
+      // (node ids from LDS through an opaque index: kept in registers across the label loop -- as ids or as hoisted
+      //  64-bit addresses -- they get spilled, and every load then waits for a scratch reload and for the load before.
+      //  Absent cells load node 0 and discard it: no divergent branch between the five loads.)
+      int nd[NPASS];
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        int ix = p * 64 + lane;
+        asm volatile("" : "+v"(ix));
+        nd[p] = node_tab[wave][ix];
+      }
+      const float* plane = uT + (int64_t)alpha_cur * n;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const float v = plane[nd[p] < 0 ? 0 : nd[p]];
+        u1[p] = nd[p] >= 0 ? v : BIG;
+      }
+    }
       }
 
       // ---- the filter: delete cells that could leave any switching set at a profit; stop when no seed is left
@@ -853,11 +875,6 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
         if (!shrunk) break;
       }
       const int tick_a = tick0 + alpha;
-#ifdef PHMRF_MULTI_DEBUG
-      if (strip == 6 && alpha == 3) {
-        if (lane == 58) printf("DBG strip %d alpha %d quiet %d U %llx %llx %llx %llx %llx sc4 %f u1 %f ucur %f hself %f node %d meta %x inm %x\n", strip, alpha, (int)quiet, U[0], U[1], U[2], U[3], U[4], sc[4], u1[4], ucur[4], hself[4], nodev[4], meta[4], inm13[4]);
-      }
-#endif
       if (quiet) {
         if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
         continue;
@@ -871,7 +888,7 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
       for (int p = 0; p < NPASS; ++p) {
         float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
         int bits = 0;
-        if (nodev[p] >= 0) {
+        if ((meta[p] >> 24) & 1u) {
           const int l = (int)(meta[p] & 255u);
           const bool in_u = (U[p] >> lane) & 1ull;
           float a0 = 0.f, a1 = 0.f;
@@ -891,7 +908,7 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
             }
           }
           c0 = ucur[p] + a0;
-          c1 = in_u ? u1[p] + a1 : BIG;
+          c1 = in_u ? (uT + (int64_t)alpha * n)[node_tab[wave][p * 64 + lane]] + a1 : BIG;
         }
         rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
         rbits[p] = bits;
@@ -960,7 +977,7 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
       unsigned int my_changed = 0;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
-        const int node = nodev[p];
+        const int node = node_tab[wave][p * 64 + lane];
         if (xsel[p] && node >= 0) {
           labels[node] = (uint8_t)alpha;
           if (stamp) {
@@ -988,79 +1005,6 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
   if (work && threadIdx.x < WORK_SLOTS) {
     const unsigned int v = wk[threadIdx.x];
     if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + threadIdx.x, (unsigned long long)v);
-  }
-}
-
-// One wave per strip of the current cut: newest[strip] = max dilated change stamp over the strip's cells (memo test),
-// smask[strip] = OR of the cells' alpha masks (phase 0 of the expansions).
-constexpr int SCAN_BATCH = 8;   // strips per wave between two rounds of work-list atomics
-
-__global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, const uint16_t* __restrict__ stamp,
-                                                         const unsigned long long* __restrict__ node_mask,
-                                                         uint16_t* __restrict__ newest,
-                                                         unsigned long long* __restrict__ smask,
-                                                         const uint16_t* __restrict__ memo, int K,
-                                                         int32_t* __restrict__ work_list, int32_t* __restrict__ work_count,
-                                                         int64_t list_stride) {
-  __shared__ int32_t pend[4][SCAN_BATCH][64];   // per wave: the strips each lane (= label) is about to queue
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int WPB = blockDim.x >> 6;
-  const int nstrips = g.nbands * g.nsegs;
-  for (int s0 = (blockIdx.x * WPB + wave) * SCAN_BATCH; s0 < nstrips; s0 += gridDim.x * WPB * SCAN_BATCH) {
-    int npend = 0;
-    for (int k = 0; k < SCAN_BATCH && s0 + k < nstrips; ++k) {
-      const int strip = s0 + k;
-      const int bnd = strip / g.nsegs;
-      const int seg = strip - bnd * g.nsegs;
-      const int rs0 = bnd * (SH + 1) - g.shift_r;
-      const int cs0 = seg * 64 - g.shift_c;
-      const int ca = cs0 > 0 ? cs0 : 0;
-      const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
-      const int ncols = cb > ca ? cb - ca : 0;
-      int nw = 0;
-      unsigned int mlo = 0u, mhi = 0u;
-      for (int e = lane; e < SH * ncols; e += 64) {
-        // consecutive lanes along the memory-contiguous axis: strip columns for orient 0, strip rows for orient 1
-        int rr, cc;
-        if (g.orient) { cc = e / SH; rr = e - cc * SH; }
-        else { rr = e / ncols; cc = e - rr * ncols; }
-        const int node = strip_node(g, rs0 + rr, ca + cc);
-        if (node >= 0) {
-          if (stamp) {
-            const int st = stamp[node];
-            nw = st > nw ? st : nw;
-          }
-          if (node_mask) {
-            const unsigned long long m = node_mask[node];
-            mlo |= (unsigned int)m;
-            mhi |= (unsigned int)(m >> 32);
-          }
-        }
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const int o2 = __shfl_xor(nw, off, 64);
-        nw = o2 > nw ? o2 : nw;
-        mlo |= (unsigned int)__shfl_xor((int)mlo, off, 64);
-        mhi |= (unsigned int)__shfl_xor((int)mhi, off, 64);
-      }
-      const unsigned long long sm = ((unsigned long long)mhi << 32) | mlo;
-      if (lane == 0) {
-        newest[strip] = (uint16_t)nw;
-        smask[strip] = sm;
-      }
-      // work lists of the expansions (lane <-> label): the strip is queued for label a when some cell could profit from
-      // a and something changed since the strip was last found quiet for a.  The expansion launches then walk dense
-      // lists instead of testing (and mostly skipping) every strip.
-      if (work_list && lane < K && ((sm >> lane) & 1ull)) {
-        const int last_quiet = memo[(int64_t)strip * (K + 1) + lane];
-        if (!(last_quiet && nw < last_quiet)) pend[wave][npend++][lane] = strip;
-      }
-    }
-    if (npend > 0) {       // one atomic per (wave, label) for the whole batch; list order does not matter
-      const int base = atomicAdd(work_count + lane, npend);
-      for (int q = 0; q < npend; ++q) work_list[(int64_t)lane * list_stride + base + q] = pend[wave][q][lane];
-    }
   }
 }
 
@@ -1137,92 +1081,9 @@ __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ 
   }
 }
 
-// node_mask[i] bit a  <=>  u_i(a) - u_i(l_i) <= beta * sum_{j in N(i)} w_ij   (a != l_i):
-// label a costs node i no more in unary terms than ALL its edges could ever give back.  Every node an
-// alpha-expansion can move satisfies this (it is the strip kernel's own test with every neighbour counted), so a strip
-// without such a node for alpha needs no work.
-template <int VEC>
-__global__ __launch_bounds__(256) void alpha_mask_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp, int D,
-                                                         const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
-                                                         const uint8_t* __restrict__ labels, float beta,
-                                                         unsigned long long* __restrict__ mask, float* __restrict__ u_cur,
-                                                         const uint16_t* __restrict__ stamp, int since) {
-  extern __shared__ float tile[];
-  const int TB = blockDim.x;
-  const int KV = K / VEC;
-  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
-    const int64_t rem = n - base;
-    const int rows = rem < TB ? (int)rem : TB;
-    // since >= 0: masks and running unaries of the previous launch are still valid wherever no (dilated) stamp is newer
-    if (since >= 0 && !__syncthreads_or((int)threadIdx.x < rows && (int)stamp[base + threadIdx.x] > since)) continue;
-    for (int q = threadIdx.x; q < rows * KV; q += TB) {
-      const int r = q / KV;
-      const int c = (q - r * KV) * VEC;
-      const float* src = logprob + (base + r) * K + c;
-      float* dst = tile + r * Kp + c;
-      if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(src);
-        dst[0] = -t.x; dst[1] = -t.y; dst[2] = -t.z; dst[3] = -t.w;
-      } else if (VEC == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(src);
-        dst[0] = -t.x; dst[1] = -t.y;
-      } else {
-        dst[0] = -src[0];
-      }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < rows) {
-      const int64_t i = base + threadIdx.x;
-      const float* row = tile + threadIdx.x * Kp;
-      const int cur = labels[i];
-      const int32_t* nb = nbr + i * D;
-      const float* wg = wgt + i * D;
-      float wdiff = 0.f;
-      for (int j0 = 0; j0 < D; j0 += 4) {
-        const int4 cv = *reinterpret_cast<const int4*>(nb + j0);
-        const float4 wv = *reinterpret_cast<const float4*>(wg + j0);
-        if (cv.x >= 0) wdiff += beta * wv.x;
-        if (cv.y >= 0) wdiff += beta * wv.y;
-        if (cv.z >= 0) wdiff += beta * wv.z;
-        if (cv.w >= 0) wdiff += beta * wv.w;
-      }
-      const float thr = row[cur] + wdiff * 1.0001f + 1e-6f;     // a hair of slack: the strip kernel sums in another order
-      unsigned long long m = 0ull;
-      for (int k = 0; k < K; ++k)
-        if (k != cur && !(row[k] > thr)) m |= 1ull << k;
-      mask[i] = m;
-      u_cur[i] = row[cur];
-    }
-    __syncthreads();
-  }
-}
-
 inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 }  // namespace
-
-int launch_alpha_mask(phmrf_block* b, float beta) {
-  // inside a solve the previous masks stay valid where nothing changed (b->mask_tick: tick of the previous launch)
-  const int since = (b->tick && b->alpha_mask && b->u_cur) ? b->mask_tick : -1;
-  if (!b->alpha_mask) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->alpha_mask), (size_t)b->n * sizeof(unsigned long long)));
-  if (!b->u_cur) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->u_cur), (size_t)b->n * sizeof(float)));
-  const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
-  const size_t lds = (size_t)TB * Kp * sizeof(float);
-  int64_t g64 = (b->n + TB - 1) / TB;
-  const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
-#define PHMRF_LAUNCH_AM(VEC_)                                                                                          \
-  hipLaunchKernelGGL((alpha_mask_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
-                     b->wgt, b->labels, beta, b->alpha_mask, b->u_cur, b->stamp, since)
-  switch (vec_of(K)) {
-    case 4: PHMRF_LAUNCH_AM(4); break;
-    case 2: PHMRF_LAUNCH_AM(2); break;
-    default: PHMRF_LAUNCH_AM(1); break;
-  }
-#undef PHMRF_LAUNCH_AM
-  PHMRF_HIP(hipGetLastError());
-  b->mask_tick = b->tick ? b->tick : -1;
-  return PHMRF_OK;
-}
 
 int launch_propose(phmrf_block* b, float beta) {
   const int since = b->tick ? b->prop_tick : -1;
@@ -1291,28 +1152,9 @@ int launch_unary_planes(phmrf_block* b) {
   return PHMRF_OK;
 }
 
-// per-strip tables of the cut (orient, shift_r, shift_c): newest stamp and OR of the alpha masks (inside a solve)
-int launch_strip_scan(phmrf_block* b, int orient, int shift_r, int shift_c, int geom) {
-  b->scan_geom = geom;
-  const StripGeom g = make_geom(b, orient, shift_r, shift_c);
-  const int nstrips = g.nbands * g.nsegs;
-  if (nstrips <= 0 || !b->tick || (int64_t)nstrips > b->memo_strips) return PHMRF_OK;
-  int grid = (nstrips + 4 * SCAN_BATCH - 1) / (4 * SCAN_BATCH);
-  if (grid > 256 * 32) grid = 256 * 32;
-  PHMRF_HIP(hipMemsetAsync(b->work_count, 0, 64 * sizeof(int32_t), b->stream));
-  const int geom_id = b->scan_geom;
-  hipLaunchKernelGGL(strip_scan_kernel, dim3(grid), dim3(256), 0, b->stream, g, b->stamp, b->alpha_mask, b->strip_newest,
-                     b->strip_mask, b->memo + ((int64_t)(orient * 3 + geom_id) * b->memo_strips) * (b->K + 1), b->K,
-                     b->work_list, b->work_count, b->memo_strips);
-  PHMRF_HIP(hipGetLastError());
-  return PHMRF_OK;
-}
-
-// alpha < 0: fusion with the proposals in b->labels_tmp (launch_propose); alpha >= 0: strip alpha-expansion.
-// geom >= 0 names one of the fixed cuts whose memo and per-strip tables (launch_strip_scan) apply; use_mask additionally
-// says that b->alpha_mask / b->u_cur / b->strip_mask are current (launch_alpha_mask + launch_strip_scan ran for this cut).
-int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, bool use_mask,
-                      int geom) {
+// alpha < 0: fusion with the proposals in b->labels_tmp (launch_propose); alpha >= 0: strip alpha-expansion of one
+// label.  geom >= 0 names one of the fixed cuts whose memo of quiet runs applies (inside a solve).
+int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha, int geom) {
   const StripGeom g = make_geom(b, orient, shift_r, shift_c);
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0) return PHMRF_OK;
@@ -1320,19 +1162,14 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   const int TB = 256, WPB = 4;
   int grid = (nstrips + WPB - 1) / WPB;
   if (grid > 256 * 32) grid = 256 * 32;
-  const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
-  const bool masks = use_mask && use_memo && alpha >= 0;
-  if (masks && grid > 1024) grid = 1024;     // list-driven: one resident set of waves strides over the work list
+  const bool use_memo = b->tick && geom >= 0 && b->memo && (int64_t)nstrips <= b->memo_strips;
 #define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
   hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
-                     masks ? b->u_cur : nullptr, b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta,          \
-                     b->counters + b->counter_slot, masks ? b->strip_mask : nullptr,                                   \
+                     b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters + b->counter_slot,       \
                      (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3),               \
                      b->tick ? b->stamp : nullptr,                                                                     \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
-                     (use_memo && alpha >= 0) ? b->strip_newest : nullptr, b->tick,                                                   \
-                     masks ? b->work_list + (int64_t)alpha * b->memo_strips : nullptr, masks ? b->work_count + alpha : nullptr, \
-                     b->work_acc)
+                     b->tick, b->work_acc)
   if (orient) PHMRF_LAUNCH_STRIP(1);
   else PHMRF_LAUNCH_STRIP(0);
 #undef PHMRF_LAUNCH_STRIP
