@@ -258,15 +258,18 @@ constexpr int NPASS = 5;   // ceil(315 / 64)
 #ifndef PHMRF_STRIP_WPE
 #define PHMRF_STRIP_WPE 4
 #endif
+#ifndef PHMRF_STRIP_WPB
+#define PHMRF_STRIP_WPB 1       // waves per workgroup (the waves are independent: one-wave workgroups, finest dispatch grain)
+#endif
 template <int ORIENT>
-__global__ __launch_bounds__(256, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g, int64_t n, int K, int D,
+__global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_kernel(StripGeom g, int64_t n, int K, int D,
                                                     const int32_t* __restrict__ nbr, const float4* __restrict__ fwd_w,
                                                     const float* __restrict__ uT, uint8_t* __restrict__ labels,
                                                     const uint8_t* __restrict__ prop, int alpha, float beta,
                                                     unsigned long long* __restrict__ changed, int debug,
                                                     uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo, int tick,
                                                     unsigned long long* __restrict__ work) {
-  __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];   // one 9.1 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
+  __shared__ __attribute__((aligned(16))) float tabs[PHMRF_STRIP_WPB * SLAB];   // one 9.1 KB slab per wave: phase-1 staging, then the cost tables of the pass walked
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
@@ -588,8 +591,11 @@ constexpr int PEEL_MAX = 8;       // sweeps before the DP takes over with whatev
 #ifndef PHMRF_MULTI_WPE
 #define PHMRF_MULTI_WPE 3       // waves per SIMD the register allocation aims at (168 VGPRs at 3)
 #endif
+#ifndef PHMRF_MULTI_WPB
+#define PHMRF_MULTI_WPB 1       // waves per workgroup: the waves are independent (a wave owns a strip), so one-wave
+#endif                          // workgroups give the dispatcher the finest grain and leave no slot waiting for a sibling
 template <int ORIENT>
-__global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(StripGeom g, int64_t n, int K, int D,
+__global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_multi_kernel(StripGeom g, int64_t n, int K, int D,
                                                              const int32_t* __restrict__ nbr,
                                                              const float4* __restrict__ fwd_w,
                                                              const float* __restrict__ uT, uint8_t* __restrict__ labels,
@@ -597,10 +603,10 @@ __global__ __launch_bounds__(256, PHMRF_MULTI_WPE) void strip_multi_kernel(Strip
                                                              unsigned long long* __restrict__ changed,
                                                              uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                              int tick0, unsigned long long* __restrict__ work, int peel_max) {
-  __shared__ __attribute__((aligned(16))) float tabs[4 * SLAB];
+  __shared__ __attribute__((aligned(16))) float tabs[PHMRF_MULTI_WPB * SLAB];
   // the strip's node ids, cell order (lane <-> cell t = 64 p + lane): read back from LDS wherever the label loop needs
   // them, so that they do not sit in (spilled) registers across it
-  __shared__ int node_tab[4][NPASS * 64];
+  __shared__ int node_tab[PHMRF_MULTI_WPB][NPASS * 64];
   __shared__ unsigned int wk[WORK_SLOTS];   // units, -, staged cells, DP steps, cells swept (once per strip visit), label-cells
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -1159,9 +1165,9 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0) return PHMRF_OK;
   if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
-  const int TB = 256, WPB = 4;
+  const int WPB = PHMRF_STRIP_WPB, TB = 64 * WPB;
   int grid = (nstrips + WPB - 1) / WPB;
-  if (grid > 256 * 32) grid = 256 * 32;
+  if (grid > 256 * 128 / WPB) grid = 256 * 128 / WPB;
   const bool use_memo = b->tick && geom >= 0 && b->memo && (int64_t)nstrips <= b->memo_strips;
 #define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
   hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
@@ -1187,9 +1193,9 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0 || !label_mask) return PHMRF_OK;
   if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
-  const int TB = 256, WPB = 4;
+  const int WPB = PHMRF_MULTI_WPB, TB = 64 * WPB;
   int grid = (nstrips + WPB - 1) / WPB;
-  if (grid > 256 * 6) grid = 256 * 6;          // two resident sets of workgroups stride over the strips
+  if (grid > 256 * 96 / WPB) grid = 256 * 96 / WPB;   // (beyond 8 resident sets of waves they stride over the strips)
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
 #define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
   hipLaunchKernelGGL((strip_multi_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
