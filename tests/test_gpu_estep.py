@@ -666,15 +666,17 @@ def test_degenerate_sizes(H, W, diagonal, K, nn):
     b.close()
 
 
-def test_full_size_largest_block_of_the_metric_config():
+@pytest.mark.parametrize("N", [4980, 24896])
+def test_full_size_largest_block_of_the_metric_config(N):
     """The largest block of the metric configuration (hg38 chr1 at 50 kb: 4980 x 4980 diagonal block, 12,402,690
-    nodes, S=4, K=20) through properties that need no host copy of the big arrays: the solver lowers the energy and
+    nodes, S=4, K=20) and of BASELINE's config 5 (chr1 at 10 kb: 24896 x 24896, 309,917,856 nodes: the biggest single
+    MRF the path holds on one GPU, 64-bit offsets everywhere) through properties that need no host copy of the big arrays: the solver lowers the energy and
     converges; the energy kernel, the solver's own report and the posterior kernel's cost numerators agree (three
     different kernels); statistics identities against torch reductions of X; a second solve changes (almost) nothing."""
     import torch
     from phylo_hmrf_amd import Block, synthetic
     from phylo_hmrf_amd.tree import PhyloTree
-    N, S, K = 4980, 4, 20
+    S, K = 4, 20
     n = N * (N + 1) // 2
     tree = PhyloTree(synthetic.tree_for(S))
     rng = np.random.default_rng(1)
