@@ -213,8 +213,8 @@ PHMRF_API int phmrf_kmeans_step(phmrf_block_t b, const double* centers /* [K,S] 
 PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
 PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[9]*/, int64_t* launches /*[9]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
-/* Work the strip kernels (class 6) actually did since the last reset, counted ON THE DEVICE (a launch inside a solve
- * walks a work list of the strips whose inputs changed; the rest of the block costs it nothing):
+/* Work the strip kernels (class 6) actually did since the last reset, counted ON THE DEVICE (inside a solve a strip
+ * whose inputs did not change since its last quiet run is skipped after a look at its stamps and counts nothing):
  *   out[0] strips staged (one unit = one strip under one move: alpha-expansion or fusion)
  *   out[1] their strip cells (the nodes a unit re-decides: 5 x columns)
  *   out[2] grid cells staged (strip + fixed rim, 7 x (columns + 2): what a unit reads from HBM)
