@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-chr1", "small"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-chr1", "cfg4", "cfg5", "cfg5-chr1", "small"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the workload's blocks dealt to the ranks (total work fixed); weak = N copies of "
                          "the workload dealt to the ranks (work per GPU fixed)")

@@ -41,6 +41,8 @@ WORKLOADS = {
     # the biggest single MRF the path has to hold on one GPU.
     "cfg5": ("10kb", 4, 20, 8, "synthetic whole-genome hg38 10 kb, 4 species, K=20, syntenic blocks sharded over the GPUs"),
     "cfg5-chr1": ([(24896, 24896, True)], 4, 20, 8, "the chr1 block of the 10 kb workload alone (309,917,856 nodes), 4 species, K=20"),
+    # what the fullest rank of an 8-GPU strong-scaling run of cfg3 holds: the chr1 block alone
+    "cfg3-chr1": ([(4980, 4980, True)], 4, 20, 8, "the chr1 block of the 50 kb workload alone (12,402,690 nodes), 4 species, K=20"),
     "small": ([(300, 300, True), (200, 260, False)], 4, 20, 8, "small smoke workload"),
 }
 
