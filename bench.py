@@ -86,6 +86,8 @@ def kernel_bytes(cls, n, K, S, D=8):
         return n * (4 * S + 4 * K + nbr + 1)
     if cls == "energy":
         return n * (4 + nbr + 1)
+    if cls == "component":                    # one pass over the unary rows and the adjacency (move table), four over
+        return n * (4 * K + nbr + 4 * (4 * D + 1) + 12)   # neighbour ids + labels (union-find, block test), roots / flags
     return None
 
 
@@ -280,7 +282,9 @@ def main():
     busy = {name: union_ms(np.concatenate([b.intervals(name) for b in blocks] or [np.zeros((0, 2))]))
             for name in agg} if not a.no_kernel_timing and blocks else {}
     roofline = roofline_limiter = None
-    dom_name = max(agg.items(), key=lambda kv: kv[1][0])[0] if agg else None
+    # the dominant class among those with a byte model (the coarse expansions' gathers have none)
+    with_model = {k: v for k, v in agg.items() if v[2] > 0}
+    dom_name = max(with_model.items(), key=lambda kv: kv[1][0])[0] if with_model else None
     if dom_name and busy.get(dom_name, 0) > 0 and agg[dom_name][2] > 0:
         dom_ms, dom_launches, dom_bytes = agg[dom_name]
         ach = dom_bytes / (busy[dom_name] * 1e-3) / 1e9

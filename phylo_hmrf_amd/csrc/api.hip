@@ -1117,19 +1117,27 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     const int r = rounds;
     PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
     {
+      // Chain moves (exact 1-D Viterbi over all K labels): with the strip expansions in place they run in verification
+      // rounds only.  Measured (round 2, live-gco parity cases and the whole-genome bench): in ordinary rounds they make
+      // 60 % of a warm start's label changes but the strips find the same energy without them -- the 2,001,000-node
+      // K=10 cold start even ends 2e-4 LOWER and in 12 rounds instead of 32 (1-D moves leave row / column streaks that
+      // the 2-D moves then have to undo) -- and they were 14 % of the device time.  Without strip expansions (general
+      // graphs have no chains at all; `use_expansion = 0`) rows and columns run in every round as before.
+      const int n_ord_fams = expansions ? 0 : 2;
       int n_chain = 0;
-      tic(b);
-      // rows and columns in every round; the two diagonal families only in verification rounds (measured: with the
-      // strip moves in place they add nothing in ordinary rounds, and they are 6 of the 10 chain launches)
       for (int f = 0; f < n_fam; ++f)
-        if (active[72 + f] && (f < 2 || verifying)) {
-          b->counter_slot = 72 + f;
-          // cut phase 0 in ordinary rounds (so the segment memo applies from the second round on); the other set of
-          // separators is used by the verification rounds
-          PHMRF_TRY(chain_sweep_nocount(b, bf, f, verifying ? 1 : 0, false));
-          n_chain += b->families[f].n_colours;
-        }
-      toc(b, KC_CHAIN, n_chain);
+        if (active[72 + f] && (f < n_ord_fams || verifying)) n_chain += b->families[f].n_colours;
+      if (n_chain > 0) {
+        tic(b);
+        for (int f = 0; f < n_fam; ++f)
+          if (active[72 + f] && (f < n_ord_fams || verifying)) {
+            b->counter_slot = 72 + f;
+            // cut phase 0 in ordinary rounds (so the segment memo applies from the second round on); the other set of
+            // separators is used by the verification rounds
+            PHMRF_TRY(chain_sweep_nocount(b, bf, f, verifying ? 1 : 0, false));
+          }
+        toc(b, KC_CHAIN, n_chain);
+      }
     }
     // single-site ICM: every strip cell and every chain node is already optimal given the rest, so ICM only earns its
     // launches on the fixed separator cells; it runs in verification rounds and on graphs without grid moves

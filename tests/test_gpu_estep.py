@@ -353,10 +353,11 @@ def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, p
 
     The reference's result is gco's swap THROUGH PYGCO'S QUANTISATION (phylo_hmrf.py:496-498): the GPU labelling must
     be at or below it STRICTLY -- both labellings are scored by the same float64 function, no slack.  gco at its finest
-    safe quantisation is not what the reference computes; the gap to it is printed and bounded by 3e-4 (neither local
+    safe quantisation is not what the reference computes; the gap to it is printed and bounded by 5e-5 (neither local
     optimum dominates the other in theory: global swap moves vs window-restricted expansion / fusion / chain moves at
-    four scales).  Measured (round 2): below fine-quantised swap on every K >= 20 case (-1e-4 .. -2.5e-3); on the K = 10
-    cases -4e-5 (22,500 nodes) and +1.7e-4 (2,001,000 nodes, from uniformly random initial labels)."""
+    four scales).  Measured (end of round 2, profiles/r2_y_live_gco_energy_gaps.txt): BELOW fine-quantised swap in every
+    case, -1.0e-5 ... -3.5e-3, the 2,001,000-node K = 10 block from uniformly random labels included (-1.5e-5 at the
+    stopping tolerance, -1.9e-5 at the exact fixed point)."""
     from oracle import gco_ref
     if not gco_ref.available():
         pytest.skip("oracle/_ref/libgco_ref.so not present")
@@ -385,7 +386,7 @@ def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, p
                  (e_mine - e_ref["fine"]) / abs(e_ref["fine"]), res["rounds"]))
         assert res["converged"]
         assert e_mine <= e_ref["pygco"], (tol_ppb, e_mine, e_ref)
-        assert e_mine <= e_ref["fine"] + 3e-4 * abs(e_ref["fine"]), (tol_ppb, e_mine, e_ref)
+        assert e_mine <= e_ref["fine"] + 5e-5 * abs(e_ref["fine"]), (tol_ppb, e_mine, e_ref)
     b.close()
 
 
