@@ -336,14 +336,18 @@ __global__ __launch_bounds__(256) void comp_table_kernel(const float* __restrict
     __syncthreads();
     if ((int)threadIdx.x < rows) {
       const int64_t i = base + threadIdx.x;
-      const int ci = comp[i];
-      roots[threadIdx.x] = ci;
+      roots[threadIdx.x] = comp[i];
       float* row = tile + threadIdx.x * Kp;
       const int32_t* nb = nbr + i * D;
       const float* wg = wgt + i * D;
+      const int li = labels[i];
       for (int j = 0; j < D; ++j) {
         const int c = nb[j];
-        if (c >= 0 && comp[c] != ci) row[labels[c]] -= beta * wg[j];
+        if (c < 0) continue;
+        // a neighbour belongs to another component exactly when it carries another label (components are the connected
+        // sets of equal label): one byte from a cache line the wave shares instead of a 4-byte root id per neighbour
+        const int lc = labels[c];
+        if (lc != li) row[lc] -= beta * wg[j];
       }
     }
     __syncthreads();
