@@ -906,7 +906,7 @@ int phmrf_mrf_strip_multi_pass(phmrf_block_t b, double beta, int orient, int shi
 // ---- coarse alpha-expansions (coarse.hip) ----------------------------------------------------------------------
 static const int N_COARSE = 3;
 static const int COARSE_SCALE[N_COARSE] = {2, 4, 8};
-static const int64_t COARSE_ON_DIV = 20;      // "moved at large": a solve changed >= 1/20 of the labels so far
+static const int64_t COARSE_ON_DIV = 8;       // "moved at large": a solve changed >= 1/8 of the labels so far
 static const int64_t COARSE_ROUND_DIV = 4;    // "moving at large": a round changed >= 1/4 of the labels (a cold start)
 
 static int coarse_child(phmrf_block_t b, int level, phmrf_block** out) {
@@ -1190,7 +1190,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     // coarse alpha-expansions: in verification rounds, and while the labelling is still moving at large (the previous
     // round changed at least 0.5 % of the labels) -- a warm start that is nearly converged never pays for them
     // Coarse scales switch on while the labelling is still moving at large (the previous round changed >= 25 % of the
-    // labels: a cold start).  A solve that has moved >= 5 % of the labels in all (the far-off warm start of an early EM
+    // labels: a cold start).  A solve that has moved >= 12.5 % of the labels in all (a far-off warm start of an EM
     // iteration) gets them once at the end, before the tolerance may stop it (force_coarse below); the warm start of a
     // later EM iteration, which moves 1-3 %, does not pay for them at all.
     // A scale that changed labels in its last run stays on (like every move type), with the super-cell grid shifted by
@@ -1272,7 +1272,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     //  2e-13 of itself, up or down, has converged; a rise of the tolerance's size or more has not -- the verification
     //  round decides then)
     if (o.energy_tol_ppb > 0 && std::fabs(gain) < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
-      // A solve that has moved the labelling at large (>= 5 % of the labels so far: a cold or far-off start, not the
+      // A solve that has moved the labelling at large (>= 12.5 % of the labels so far: a cold or far-off start, not the
       // warm start of a later EM iteration) does not stop before the coarse scales have run once more and gained less
       // than the tolerance, too: their gains come in few large steps, not in the trickle the tolerance watches.
       if (coarse && !coarse_checked && !coarse_just_ran && total * COARSE_ON_DIV >= b->n) {
