@@ -281,6 +281,42 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ l
   }
 }
 
+// The same energy on a grid block, from the forward-edge records the strip kernels use (fwd_w: E, SW, S, SE -- every
+// undirected edge once, held by its upper / left end) and four neighbour labels found by geometry: 21 B per node where
+// the adjacency form reads 64 B of ids and weights and gathers eight labels.  One thread per cell of the H x W square
+// (upper-triangular blocks: the cells below the diagonal idle).
+__global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restrict__ logprob, int64_t n, int K, int H, int W,
+                                                          int diagonal, const float4* __restrict__ fwd_w,
+                                                          const uint8_t* __restrict__ labels, double* __restrict__ accum) {
+  __shared__ double red[8];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  double eu = 0.0, ep = 0.0;
+  for (int i = blockIdx.y * 4 + (threadIdx.x >> 6); i < H; i += gridDim.y * 4) {
+    if (j >= W || (diagonal && j < i)) continue;
+    const int64_t row = diagonal ? (int64_t)i * W - ((int64_t)i * (i - 1)) / 2 - i : (int64_t)i * W;      // node = row + j
+    const int64_t node = row + j;
+    const int l = labels[node];
+    eu -= (double)logprob[node * K + l];
+    const float4 w = fwd_w[node];
+    float s = 0.f;
+    if (j + 1 < W && labels[node + 1] != l) s += w.x;                                   // E
+    if (i + 1 < H) {
+      const int64_t row2 = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
+      const int jlo = diagonal ? i + 1 : 0;
+      if (j - 1 >= jlo && labels[row2 + j - 1] != l) s += w.y;                        // SW
+      if (j >= jlo && labels[row2 + j] != l) s += w.z;                                // S
+      if (j + 1 < W && labels[row2 + j + 1] != l) s += w.w;                            // SE
+    }
+    ep += (double)s;
+  }
+  const double tu = block_sum(eu, red);
+  const double tp = block_sum(ep, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(accum + ACC_ENERGY, tu);
+    atomicAdd(accum + ACC_ENERGY + 1, tp);
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // b3 posteriors + costs + sufficient statistics, fused (phylo_hmrf.py:334-355, :374-396, :311-314).
 //   pp[i,k]   = beta * sum_{e in inc(i)} w'_e [l_other != k]          (w' = w if estimate_type==3 else 1)
@@ -512,6 +548,16 @@ int launch_icm_colour(const phmrf_block* b, float beta, int colour) {
 
 int launch_energy(const phmrf_block* b, float beta) {
   (void)beta;
+  if (b->has_grid && b->fwd_w && b->H > 0 && b->W > 0) {
+    const int gx = (b->W + 63) / 64;
+    int gy = (b->H + 3) / 4;
+    const int cap = 2048 / gx + 1;          // ~2048 workgroups: each sums many rows before its two f64 atomics
+    if (gy > cap) gy = cap;
+    hipLaunchKernelGGL(energy_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->logprob, b->n, b->K, b->H,
+                       b->W, b->diagonal, b->fwd_w, b->labels, b->accum);
+    PHMRF_HIP(hipGetLastError());
+    return PHMRF_OK;
+  }
   const int grid = grid_for(b->n, 256, 256 * 8);
   hipLaunchKernelGGL(energy_kernel, dim3(grid), dim3(256), 0, b->stream, b->logprob, b->n, b->K, b->D, b->nbr, b->wgt,
                      b->labels, b->accum);
