@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restric
 //   stats     : post | obs | obs*obs.T = Gamma^T [1 | x | x (x) x], accumulated in f64 across tiles,
 //               one atomic flush per workgroup at the end (grid is capped, blocks stride over tiles)
 // -------------------------------------------------------------------------------------------------
-constexpr int MAXO = 18;  // outputs per thread; needs K*(1+S+S*S) <= MAXO*TB
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int S, int VEC, bool WRITE_POST>
 __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ X, const float* __restrict__ logprob,
@@ -344,16 +344,12 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
   __shared__ double red[8];
 
   const int KM = K * M;
-  int ok[MAXO], om[MAXO];
-  double acc[MAXO];
-#pragma unroll
-  for (int p = 0; p < MAXO; ++p) {
-    const int o = threadIdx.x + p * TB;
-    ok[p] = o < KM ? o / M : -1;
-    om[p] = o < KM ? o - (o / M) * M : 0;
-    acc[p] = 0.0;
-  }
+  // statistics of this workgroup, f64, in LDS behind the two tiles (8-byte aligned: TB * (Kp + Mp) is even)
+  double* sacc = reinterpret_cast<double*>(lds + TB * (Kp + Mp));
+  for (int o = threadIdx.x; o < KM; o += TB) sacc[o] = 0.0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double c_pair = 0.0, c_pcn = 0.0, c_un = 0.0;
+  __syncthreads();
 
   for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
     const int64_t rem = n - base;
@@ -440,30 +436,43 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     }
     __syncthreads();
     if (WRITE_POST) tile_to_rows<VEC>(post_out + base * K, rows, K, Kp, tile);
-    // phase 4: stats[k][m] += sum_r gamma[r][k] * feat[r][m]; thread owns outputs o = tid + p*TB
+    // phase 4: stats[k][m] += sum_r gamma[r][k] * feat[r][m] -- a (K x rows) x (rows x M) product per tile, on the matrix
+    // cores in exact f32 (v_mfma_f32_32x32x2_f32: A lane l = gamma^T[k = l & 31][r = l >> 5], B lane l = feat[r = l >> 5]
+    // [m = l & 31], 16 results per lane at column l & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).  Each wave sums
+    // its own 64 rows of the tile in f32 and adds the 32 x 32 block to the workgroup's f64 accumulators in LDS.
+    {
+      const int r0 = wave * 64 + (lane >> 5), c = lane & 31;
+      for (int kb = 0; kb < K; kb += 32)
+        for (int mb = 0; mb < M; mb += 32) {
+          f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          const bool ka = kb + c < K, ma = mb + c < M;
+#pragma unroll 8
+          for (int st = 0; st < 32; ++st) {
+            const int r = r0 + 2 * st;
+            const float a = (ka && r < rows) ? tile[r * Kp + kb + c] : 0.f;
+            const float bq = (ma && r < rows) ? feat[r * Mp + mb + c] : 0.f;
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, d, 0, 0, 0);
+          }
+          if (ma && wave * 64 < rows) {
 #pragma unroll
-    for (int p = 0; p < MAXO; ++p) {
-      if (ok[p] >= 0) {
-        const float* g = tile + ok[p];
-        const float* f = feat + om[p];
-        float a = 0.f;
-        for (int r = 0; r < rows; ++r) a = fmaf(g[r * Kp], f[r * Mp], a);
-        acc[p] += (double)a;
-      }
+            for (int q = 0; q < 16; ++q) {
+              const int k = kb + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+              if (k < K) atomicAdd(sacc + k * M + mb + c, (double)d[q]);
+            }
+          }
+        }
     }
     __syncthreads();
   }
   // flush: statistics (layout post[K] | obs[K,S] | obsobsT[K,S,S]) and the three cost numerators
-#pragma unroll
-  for (int p = 0; p < MAXO; ++p) {
-    if (ok[p] >= 0) {
-      const int k = ok[p], m = om[p];
-      int dst;
-      if (m == 0) dst = k;
-      else if (m <= S) dst = K + k * S + (m - 1);
-      else dst = K + K * S + k * S * S + (m - 1 - S);
-      atomicAdd(accum + ACC_STATS + dst, acc[p]);
-    }
+  __syncthreads();
+  for (int o = threadIdx.x; o < KM; o += TB) {
+    const int k = o / M, m = o - k * M;
+    int dst;
+    if (m == 0) dst = k;
+    else if (m <= S) dst = K + k * S + (m - 1);
+    else dst = K + K * S + k * S * S + (m - 1 - S);
+    atomicAdd(accum + ACC_STATS + dst, sacc[o]);
   }
   const double t0 = block_sum(c_pair, red);
   const double t1 = block_sum(c_pcn, red);
@@ -482,11 +491,11 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
   const int K = b->K, Kp = padded_k(K);
   int TB = 256;
-  while (TB > 64 && (size_t)TB * (Kp + Mp) * sizeof(float) > 64 * 1024 - 256) TB >>= 1;
-  PHMRF_CHECK((size_t)TB * (Kp + Mp) * sizeof(float) <= 64 * 1024 - 256, PHMRF_ERR_UNSUPPORTED,
+  const size_t acc_bytes = (size_t)K * M * sizeof(double);            // the workgroup's f64 statistics
+  while (TB > 64 && (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes > 64 * 1024 - 256) TB >>= 1;
+  PHMRF_CHECK((size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes <= 64 * 1024 - 256, PHMRF_ERR_UNSUPPORTED,
               "posterior_stats: K and S too large for the LDS tile");
-  PHMRF_CHECK(K * M <= MAXO * TB, PHMRF_ERR_UNSUPPORTED, "posterior_stats: K*(1+S+S*S) exceeds the per-workgroup output capacity");
-  const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float);
+  const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes;
   const int grid = grid_for(b->n, TB, 256 * 8);
   const int use_w = estimate_type == 3 ? 1 : 0;
 #define PHMRF_LAUNCH_POST(VEC_, WP_)                                                                                \
