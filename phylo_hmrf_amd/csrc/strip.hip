@@ -94,6 +94,8 @@ __device__ __forceinline__ float xor_exchange(float v) {
 constexpr int TAB = 36;
 // phase-1 staging record per cell (same LDS slab, before the tables are built): the four forward grid weights of the
 // cell (times beta) and its packed labels (l | p << 8 | present << 16); stride 5 words: conflict-free.
+// (the packed labels travel as float bit patterns: every access of the slab is a float access, so that the type-based
+// alias rules cannot order a label read after the table stores that reuse the slab)
 constexpr int REC = 5;
 constexpr int EH = 7;                   // rows of the staged rectangle: the strip's 5 plus the fixed row above and below
 constexpr int ECELLS = EH * (63 + 2);   // ... times its columns plus the fixed column left and right
@@ -334,7 +336,6 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
     float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
     int rbits[NPASS];
     int t_lo = NCELL_MAX, t_hi = -1;
-    int* tabi = reinterpret_cast<int*>(tab);
     {
       constexpr int NEP = (ECELLS + 63) / 64;       // 8 lane-passes over the staged rectangle
       int enode[NEP], eidx[NEP];
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
           tab[e * REC + 1] = ef[q].y * beta;
           tab[e * REC + 2] = ef[q].z * beta;
           tab[e * REC + 3] = ef[q].w * beta;
-          tabi[e * REC + 4] = present ? (elab[q] | (epl[q] << 8)) : 0;
+          tab[e * REC + 4] = __builtin_bit_cast(float, (int)(present ? (elab[q] | (epl[q] << 8)) : 0));
         }
       }
     }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
         node = strip_node(g, rs0 + rr, ca + cc);
         if (node >= 0) {
           const int e0 = (cc + 1) * EH + (rr + 1);
-          const int lw = tabi[e0 * REC + 4];
+          const int lw = __builtin_bit_cast(int, tab[e0 * REC + 4]);
           const int l = lw & 255, pl = (lw >> 8) & 255;
           const bool can = pl != l;
           const float u0 = uT[(int64_t)l * n + node];
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
             const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
             const int en = e0 + dc * EH + dr;
             const float w = fwd ? tab[e0 * REC + comp] : tab[en * REC + comp];
-            const int nl = tabi[en * REC + 4];
+            const int nl = __builtin_bit_cast(int, tab[en * REC + 4]);
             const int lj = nl & 255, pj = (nl >> 8) & 255;
             const int r2 = rr + dr, c2 = cc + dc;
             const bool inside = r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols;
@@ -586,6 +587,15 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
 // In the steady state of an EM fit ~5 sweeps settle 4 of 5 pairs without a DP, and U holds a few per cent of the cells
 // of the others.  Per label the wave reads 4 B per cell (the label's unary plane); labels and weights are read once
 // per strip instead of once per (strip, label).
+// lanes of pass p (cell t = 64 p + lane, row t mod 5) whose row has a neighbour dr rows away
+constexpr unsigned long long row_mask(int p, int dr) {
+  unsigned long long m = 0ull;
+  for (int l = 0; l < 64; ++l) {
+    const int r = (64 * p + l) % SH + dr;
+    if (r >= 0 && r < SH) m |= 1ull << l;
+  }
+  return m;
+}
 constexpr int PEEL_MAX = 16;      // sweeps before the DP takes over with whatever U is left (any U is sound; measured: 8 -> 16 sweeps = -30 % DP steps, -1.5 % E-step)
 
 #ifndef PHMRF_MULTI_WPE
@@ -612,11 +622,8 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
   const int WPB = blockDim.x >> 6;
   const int nstrips = g.nbands * g.nsegs;
   float* tab = tabs + wave * SLAB;
-  int* tabi = reinterpret_cast<int*>(tab);
   if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
   __syncthreads();
-  const int sh5 = lane & 31;
-  const bool hi_half = lane >= 32;
 
   for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
     const int bnd = strip / g.nsegs;
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
     float v8[NPASS][8];            // per neighbour d: inside the strip  w (2 - [l != l_d])  (= disc), outside  w
     unsigned int laba[NPASS], labb[NPASS];   // the eight neighbour labels, one byte each
     unsigned int meta[NPASS];      // own label | eq mask << 8 | inside mask << 16
-    unsigned int inm13[NPASS];     // the inside mask at the positions of the 13-bit neighbourhood window
+    unsigned long long pres[NPASS]; // (scalar) labels present among the neighbours of the pass's cells
     float ucur[NPASS], hself[NPASS];
     bool staged = false;
     // the label's unary terms: loaded one label AHEAD into the same registers (they are free once the single-site
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
               tab[e * REC + 1] = ef[q].y * beta;
               tab[e * REC + 2] = ef[q].z * beta;
               tab[e * REC + 3] = ef[q].w * beta;
-              tabi[e * REC + 4] = enode[q] >= 0 ? elab[q] : 0;
+              tab[e * REC + 4] = __builtin_bit_cast(float, (int)(enode[q] >= 0 ? elab[q] : 0));
             }
           }
         }
@@ -756,27 +763,27 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
         for (int p = 0; p < NPASS; ++p) {
           int t = p * 64 + lane;
           asm volatile("" : "+v"(t));
-          unsigned int la = 0u, lb = 0u, mt = 0u, im = 0u;
+          unsigned int la = 0u, lb = 0u, mt = 0u;
+          unsigned long long pm = 0ull;
           float hs = 0.f, uc = 0.f;
 #pragma unroll
           for (int d = 0; d < 8; ++d) v8[p][d] = 0.f;
           if (nodev[p] >= 0) {
             const int cc = t / SH, rr = t - cc * SH;
             const int e0 = (cc + 1) * EH + (rr + 1);
-            const int l = tabi[e0 * REC + 4] & 255;
+            const int l = __builtin_bit_cast(int, tab[e0 * REC + 4]) & 255;
             mt = (unsigned int)l | (1u << 24);            // bit 24: the cell is a node
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
               constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
               constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-              constexpr int WPOS[8] = {0, 5, 10, 1, 11, 2, 7, 12};      // dc * 5 + dr + 6
               const int dr = DR[d], dc = DC[d];
               const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;
               const bool fwd = di > 0 || (di == 0 && dj > 0);
               const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
               const int en = e0 + dc * EH + dr;
               const float w = fwd ? tab[e0 * REC + comp] : tab[en * REC + comp];
-              const int lj = tabi[en * REC + 4] & 255;
+              const int lj = __builtin_bit_cast(int, tab[en * REC + 4]) & 255;
               const int r2 = rr + dr, c2 = cc + dc;
               const bool inside = r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols;
               const bool eq = lj == l;
@@ -784,13 +791,23 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
               v8[p][d] = (inside && eq) ? w + w : w;
               mt |= (eq ? 1u : 0u) << (8 + d);
               mt |= (inside ? 1u : 0u) << (16 + d);
-              im |= (inside ? 1u : 0u) << WPOS[d];
+              pm |= 1ull << (lj & 63);
               if (d < 4) la |= (unsigned int)lj << (8 * d);
               else lb |= (unsigned int)lj << (8 * (d - 4));
             }
             uc = uT[(int64_t)l * n + nodev[p]];
           }
-          laba[p] = la; labb[p] = lb; meta[p] = mt; inm13[p] = im; hself[p] = hs; ucur[p] = uc;
+          laba[p] = la; labb[p] = lb; meta[p] = mt; hself[p] = hs; ucur[p] = uc;
+          {
+            unsigned int p0 = (unsigned int)pm, p1 = (unsigned int)(pm >> 32);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+              p0 |= (unsigned int)__shfl_xor((int)p0, off, 64);
+              p1 |= (unsigned int)__shfl_xor((int)p1, off, 64);
+            }
+            pres[p] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)p1) << 32) |
+                      (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)p0);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_wave_barrier();          // the slab is free for the cost tables from here on
@@ -810,10 +827,12 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         float hist = 0.f;
+        if ((pres[p] >> alpha) & 1ull) {             // (wave-uniform: many labels are absent from a pass's neighbourhoods)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          const int lj = (int)(((d < 4 ? laba[p] : labb[p]) >> (8 * (d & 3))) & 255u);
-          hist += lj == alpha ? v8[p][d] : 0.f;      // (a neighbour labelled alpha differs from l_i: v8 holds plain w)
+          for (int d = 0; d < 8; ++d) {
+            const int lj = (int)(((d < 4 ? laba[p] : labb[p]) >> (8 * (d & 3))) & 255u);
+            hist += lj == alpha ? v8[p][d] : 0.f;    // (a neighbour labelled alpha differs from l_i: v8 holds plain w)
+          }
         }
         const int l = (int)(meta[p] & 255u);
         const bool ok = ((meta[p] >> 24) & 1u) && l != alpha && u1[p] < 1.0e29f;
@@ -850,21 +869,23 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
           if (U[p] == 0ull) continue;
+          // bit `lane` of M_d: is neighbour d of cell 64 p + lane in U?  Column-major cells: the neighbour sits dc * 5 + dr
+          // cells away, so M_d is a funnel shift of the (scalar) U words, cut to the lanes whose row has that neighbour
+          // (a compile-time pattern: the row of cell t is t mod 5).  All of it is SALU work; the VALU only adds the
+          // weight under the mask.
+          const unsigned long long up = U[p];
           const unsigned long long lo = p > 0 ? U[p > 0 ? p - 1 : 0] : 0ull;
           const unsigned long long hi = p < NPASS - 1 ? U[p < NPASS - 1 ? p + 1 : 0] : 0ull;
-          const unsigned long long X = (U[p] << 6) | (lo >> 58);       // bit k: cell 64 p - 6 + k
-          const unsigned long long Y = (hi << 6) | (U[p] >> 58);       // bit k: cell 64 (p + 1) - 6 + k
-          const unsigned int x0 = (unsigned int)X, x1 = (unsigned int)(X >> 32), y0 = (unsigned int)Y;
-          const unsigned int wa = hi_half ? x1 : x0, wb = hi_half ? y0 : x1;
-          unsigned int W = __builtin_amdgcn_alignbit(wb, wa, sh5);      // bit k: cell t - 6 + k
-          W &= inm13[p];
           float cap = 0.f;
 #pragma unroll
           for (int d = 0; d < 8; ++d) {
-            constexpr int WPOS[8] = {0, 5, 10, 1, 11, 2, 7, 12};
-            // bit -> all-ones mask (v_bfe_i32), mask the weight's bits, add: no compare / select chain
-            const int mk = __builtin_amdgcn_sbfe((int)W, WPOS[d], 1);
-            cap += __builtin_bit_cast(float, mk & __builtin_bit_cast(int, v8[p][d]));
+            constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+            constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+            const int off = DC[d] * SH + DR[d];
+            unsigned long long M = off > 0 ? (up >> (off > 0 ? off : 1)) | (hi << (off > 0 ? 64 - off : 1))
+                                           : (up << (off < 0 ? -off : 1)) | (lo >> (off < 0 ? 64 + off : 1));
+            M &= row_mask(p, DR[d]);
+            cap += __builtin_amdgcn_inverse_ballot_w64(M) ? v8[p][d] : 0.f;
           }
           const float capx = cap * 1.0001f + 1e-6f;                      // a hair of slack for the f32 sums
           const unsigned long long keep = __ballot(sc[p] <= capx);

@@ -23,5 +23,7 @@ print("cold solve:", res)
 P3 = np.clip(P2 * (1 + float(os.environ.get("PHMRF_TRACE_PERT", "0.02")) * rng.standard_normal(P.shape)), 1e-3, 50); mu3, cv3 = tree.mean_cov(P3); cv3 = cv3 + 1e-3 * np.eye(S)
 b.emission(mu3, cv3)
 sys.stderr.write("---- warm\n")
+b.reset_timing()
 res = b.solve(1.0, energy_tol_ppb=tol, init_mode=0, use_expansion=expn)
 print("warm solve:", res)
+print("work:", b.work())
