@@ -617,6 +617,10 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
   // the strip's node ids, cell order (lane <-> cell t = 64 p + lane): read back from LDS wherever the label loop needs
   // them, so that they do not sit in (spilled) registers across it
   __shared__ int node_tab[PHMRF_MULTI_WPB][NPASS * 64];
+  // per cell { unary term of its own label, weight sum of the neighbours that share it }: read once per label.  In LDS
+  // rather than in registers: the ten registers went to scratch, and a scratch reload waits for every older load --
+  // also for the next label's unary terms, which are meant to stay in flight behind the sweeps
+  __shared__ float2 cell_tab[PHMRF_MULTI_WPB][NPASS * 64];
   __shared__ unsigned int wk[WORK_SLOTS];   // units, -, staged cells, DP steps, cells swept (once per strip visit), label-cells
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int WPB = blockDim.x >> 6;
@@ -624,6 +628,20 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
   float* tab = tabs + wave * SLAB;
   if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
   __syncthreads();
+#ifdef PHMRF_PHASE_CLOCK
+  // development build: shader-clock cycles per phase into the work counters (1 memo/ids, 2 staging, 3 single-site costs
+  // incl. the wait for the label's unary terms, 4 sweeps, 5 DP and apply; slot 0 still counts the pairs)
+  unsigned int phc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned long long pht = __builtin_amdgcn_s_memtime();
+#define PH(K_)                                                            \
+  {                                                                       \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();          \
+    phc[K_] += (unsigned int)(tn_ - pht);                                 \
+    pht = tn_;                                                            \
+  }
+#else
+#define PH(K_)
+#endif
 
   for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
     const int bnd = strip / g.nsegs;
@@ -635,6 +653,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
     const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
     if (ncell <= 0) continue;
+    PH(1)
 
     // ---- the strip's nodes (lane <-> cell t = 64 p + lane, column-major) and the labels that need a run: a label
     //      is skipped while no (dilated) change stamp of the strip is newer than its last quiet run on this cut
@@ -677,7 +696,6 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
     unsigned int laba[NPASS], labb[NPASS];   // the eight neighbour labels, one byte each
     unsigned int meta[NPASS];      // own label | eq mask << 8 | inside mask << 16
     unsigned long long pres[NPASS]; // (scalar) labels present among the neighbours of the pass's cells
-    float ucur[NPASS], hself[NPASS];
     bool staged = false;
     // the label's unary terms: loaded one label AHEAD into the same registers (they are free once the single-site
     // costs are formed; the rare DP reads its label's terms again), so that the load's latency hides behind the sweeps
@@ -686,7 +704,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
     {
       // (node ids from LDS through an opaque index: kept in registers across the label loop -- as ids or as hoisted
       //  64-bit addresses -- they get spilled, and every load then waits for a scratch reload and for the load before.
-      //  Absent cells load node 0 and discard it: no divergent branch between the five loads.)
+      //  Absent cells load node 0; their value is never used: `ok` below tests the node bit.)
       int nd[NPASS];
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
@@ -697,11 +715,11 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
       const float* plane = uT + (int64_t)alpha_cur * n;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
-        const float v = plane[nd[p] < 0 ? 0 : nd[p]];
-        u1[p] = nd[p] >= 0 ? v : BIG;
+        u1[p] = plane[nd[p] < 0 ? 0 : nd[p]];     // (no select on the loaded value: it would wait for the load right here)
       }
     }
 
+    PH(1)
     while (todo) {
       if (!staged) {
         // ---- staging (as strip_kernel, step A): labels and forward weights of the strip's rectangle and rim -> LDS
@@ -755,10 +773,24 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
+#ifndef PHMRF_PHASE_CLOCK
           atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
           atomicAdd(&wk[4], (unsigned int)ncell);               // the strip's cells, swept for every listed label
+#endif
         }
-        // ---- extraction: lane <-> strip cell
+        // ---- extraction: lane <-> strip cell.  The unary terms of the cells' own labels first, all five loads in flight
+        //      while the neighbourhoods are put together (absent cells read node 0 of label 0 and drop it)
+        float ucl[NPASS];
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          int t = p * 64 + lane;
+          asm volatile("" : "+v"(t));
+          const int cc = t / SH, rr = t - cc * SH;
+          const int e0 = (cc + 1) * EH + (rr + 1);
+          const bool have = nodev[p] >= 0;
+          const int l = have ? __builtin_bit_cast(int, tab[have ? e0 * REC + 4 : 4]) & 255 : 0;
+          ucl[p] = uT[(int64_t)l * n + (have ? nodev[p] : 0)];
+        }
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
           int t = p * 64 + lane;
@@ -795,9 +827,10 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
               if (d < 4) la |= (unsigned int)lj << (8 * d);
               else lb |= (unsigned int)lj << (8 * (d - 4));
             }
-            uc = uT[(int64_t)l * n + nodev[p]];
+            uc = ucl[p];
           }
-          laba[p] = la; labb[p] = lb; meta[p] = mt; hself[p] = hs; ucur[p] = uc;
+          laba[p] = la; labb[p] = lb; meta[p] = mt;
+          cell_tab[wave][t] = make_float2(uc, hs);
           {
             unsigned int p0 = (unsigned int)pm, p1 = (unsigned int)(pm >> 32);
 #pragma unroll
@@ -812,13 +845,16 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
         }
         __builtin_amdgcn_wave_barrier();          // the slab is free for the cost tables from here on
         staged = true;
+        PH(2)
       }
 
       const int alpha = alpha_cur;
       todo &= todo - 1ull;
       if (lane == 0) {
         atomicAdd(&wk[0], 1u);
+#ifndef PHMRF_PHASE_CLOCK
         atomicAdd(&wk[5], (unsigned int)ncell);                 // one label's unary terms for the strip's cells
+#endif
       }
 
       // ---- single-site costs and the starting set
@@ -836,15 +872,19 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
         }
         const int l = (int)(meta[p] & 255u);
         const bool ok = ((meta[p] >> 24) & 1u) && l != alpha && u1[p] < 1.0e29f;
-        sc[p] = u1[p] - ucur[p] + hself[p] - hist;
+        int ix = p * 64 + lane;
+        asm volatile("" : "+v"(ix));
+        const float2 uh = cell_tab[wave][ix];
+        sc[p] = u1[p] - uh.x + uh.y - hist;
         U[p] = __ballot(ok);
       }
+      PH(3)
       if (todo) {                                   // the next label's terms, in flight during the sweeps
         alpha_cur = __ffsll((long long)todo) - 1;
     {
       // (node ids from LDS through an opaque index: kept in registers across the label loop -- as ids or as hoisted
       //  64-bit addresses -- they get spilled, and every load then waits for a scratch reload and for the load before.
-      //  Absent cells load node 0 and discard it: no divergent branch between the five loads.)
+      //  Absent cells load node 0; their value is never used: `ok` below tests the node bit.)
       int nd[NPASS];
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
@@ -855,12 +895,12 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
       const float* plane = uT + (int64_t)alpha_cur * n;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
-        const float v = plane[nd[p] < 0 ? 0 : nd[p]];
-        u1[p] = nd[p] >= 0 ? v : BIG;
+        u1[p] = plane[nd[p] < 0 ? 0 : nd[p]];     // (no select on the loaded value: it would wait for the load right here)
       }
     }
       }
 
+      PH(1)
       // ---- the filter: delete cells that could leave any switching set at a profit; stop when no seed is left
       bool quiet = false;
       for (int it = 0; it < peel_max; ++it) {
@@ -901,6 +941,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
         }
         if (!shrunk) break;
       }
+      PH(4)
       const int tick_a = tick0 + alpha;
       if (quiet) {
         if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
@@ -911,6 +952,14 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
       float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
       int rbits[NPASS];
       int t_lo = NCELL_MAX, t_hi = -1;
+      // (the label's unary terms again -- u1 already holds the NEXT label's: five loads in flight together)
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        int ix = p * 64 + lane;
+        asm volatile("" : "+v"(ix));
+        const int nd = node_tab[wave][ix];
+        rc1[p] = (uT + (int64_t)alpha * n)[nd < 0 ? 0 : nd];
+      }
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -934,8 +983,8 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
               bits |= nib << (4 * (QOF[d] >= 0 ? QOF[d] : 0));
             }
           }
-          c0 = ucur[p] + a0;
-          c1 = in_u ? (uT + (int64_t)alpha * n)[node_tab[wave][p * 64 + lane]] + a1 : BIG;
+          c0 = cell_tab[wave][p * 64 + lane].x + a0;
+          c1 = in_u ? rc1[p] + a1 : BIG;
         }
         rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
         rbits[p] = bits;
@@ -949,6 +998,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
       }
       if (t_hi < 0) {
         if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+        PH(5)
         continue;
       }
       t_lo = __builtin_amdgcn_readfirstlane(t_lo);
@@ -962,7 +1012,9 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
         const int pl = t_lo >> 6, rl = t_lo & 63;
         t_lo = pl * 64 + (rl - rl % 6);
       }
+#ifndef PHMRF_PHASE_CLOCK
       if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
+#endif
 
       float m = lane == 0 ? 0.f : BIG;
       unsigned long long took = 0ull;
@@ -979,6 +1031,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
       const float mmin = wave_min_f32(m);
       if (!(took & 1ull) && PHMRF_RL(m, 0) == mmin) {
         if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+        PH(5)
         continue;
       }
       m = lane == 0 ? 0.f : BIG;
@@ -1026,8 +1079,14 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
         __threadfence();          // the restaging below reads the labels this wave has just written
         staged = false;
       }
+      PH(5)
     }
   }
+#ifdef PHMRF_PHASE_CLOCK
+  if (lane == 0)
+    for (int k = 1; k < 6; ++k) wk[k] = phc[k] >> 4;
+#endif
+#undef PH
   __syncthreads();
   if (work && threadIdx.x < WORK_SLOTS) {
     const unsigned int v = wk[threadIdx.x];
