@@ -696,7 +696,7 @@ int phmrf_emission_dev(const float* X_dev, int64_t n, int S, int K, const float*
                        void* hip_stream) {
   PHMRF_CHECK(X_dev && packed_dev && logprob_dev, PHMRF_ERR_INVALID, "NULL argument");
   PHMRF_CHECK(n > 0 && K >= 1 && K <= 64, PHMRF_ERR_INVALID, "bad n/K");
-  return launch_emission(X_dev, n, S, K, packed_dev, logprob_dev, reinterpret_cast<hipStream_t>(hip_stream));
+  return launch_emission(X_dev, n, S, K, packed_dev, logprob_dev, nullptr, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 int phmrf_emission(phmrf_block_t b, const double* means, const double* covars) {
@@ -707,10 +707,11 @@ int phmrf_emission(phmrf_block_t b, const double* means, const double* covars) {
   PHMRF_TRY(phmrf_emission_pack(b->S, b->K, means, covars, packed.data()));
   PHMRF_TRY(upload(b->emis_params, packed.data(), packed.size() * sizeof(float), b->stream));
   tic(b);
-  PHMRF_TRY(launch_emission(b->X, b->n, b->S, b->K, b->emis_params, b->logprob, b->stream));
+  // (a block that has run strip moves before owns its unary planes: the kernel writes them along with logprob)
+  PHMRF_TRY(launch_emission(b->X, b->n, b->S, b->K, b->emis_params, b->logprob, b->uT, b->stream));
   toc(b, KC_EMISSION, 1);
   b->has_logprob = true;
-  b->uT_valid = false;
+  b->uT_valid = b->uT != nullptr;
   return PHMRF_OK;
 }
 

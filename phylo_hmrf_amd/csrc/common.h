@@ -153,7 +153,7 @@ inline int tile_threads(int K) { return K <= 40 ? 256 : 128; }
 inline int padded_k(int K) { return (K % 2 == 0) ? K + 1 : K; }  // odd LDS row stride: conflict-free row-per-lane access
 
 // kernels (defined in the .hip files) -------------------------------------------------------------
-int launch_emission(const float* X, int64_t n, int S, int K, const float* packed, float* logprob, hipStream_t st);
+int launch_emission(const float* X, int64_t n, int S, int K, const float* packed, float* logprob, float* uT, hipStream_t st);
 int launch_argmax_labels(const phmrf_block* b);
 int launch_icm_colour(const phmrf_block* b, float beta, int colour);
 int launch_energy(const phmrf_block* b, float beta);  // -> accum[0]=unary, accum[1]=pair (caller zeroes)

@@ -103,7 +103,8 @@ inline int grid_for(int64_t work_items, int tb, int max_blocks = 256 * 16) {
 // -------------------------------------------------------------------------------------------------
 template <int S, int VEC>
 __global__ __launch_bounds__(256) void emission_kernel(const float* __restrict__ X, int64_t n, int K, int Kp,
-                                                       const float* __restrict__ P, float* __restrict__ out) {
+                                                       const float* __restrict__ P, float* __restrict__ out,
+                                                       float* __restrict__ uT) {
   extern __shared__ float tile[];
   constexpr int PS = S + S * (S + 1) / 2 + 1;
   const int TB = blockDim.x;
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(256) void emission_kernel(const float* __restrict__
           for (int c = 0; c <= r; ++c) y = fmaf(p[idx++], d[c], y);
           q = fmaf(y, y, q);
         }
-        row[k] = fmaf(-0.5f, q, p[idx]);
+        const float lp = fmaf(-0.5f, q, p[idx]);
+        row[k] = lp;
+        if (uT) uT[(int64_t)k * n + i] = -lp;        // the label-major unary planes of the strip moves, while the value is at hand
       }
     }
     __syncthreads();
@@ -148,14 +151,14 @@ __global__ __launch_bounds__(256) void emission_kernel(const float* __restrict__
 }
 
 template <int S>
-int launch_emission_s(const float* X, int64_t n, int K, const float* packed, float* logprob, hipStream_t st) {
+int launch_emission_s(const float* X, int64_t n, int K, const float* packed, float* logprob, float* uT, hipStream_t st) {
   const int TB = tile_threads(K), Kp = padded_k(K);
   const size_t lds = (size_t)TB * Kp * sizeof(float);
   const int grid = grid_for(n, TB);
   switch (vec_of(K)) {
-    case 4: hipLaunchKernelGGL((emission_kernel<S, 4>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob); break;
-    case 2: hipLaunchKernelGGL((emission_kernel<S, 2>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob); break;
-    default: hipLaunchKernelGGL((emission_kernel<S, 1>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob); break;
+    case 4: hipLaunchKernelGGL((emission_kernel<S, 4>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob, uT); break;
+    case 2: hipLaunchKernelGGL((emission_kernel<S, 2>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob, uT); break;
+    default: hipLaunchKernelGGL((emission_kernel<S, 1>), dim3(grid), dim3(TB), lds, st, X, n, K, Kp, packed, logprob, uT); break;
   }
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
@@ -285,29 +288,55 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ l
 // undirected edge once, held by its upper / left end) and four neighbour labels found by geometry: 21 B per node where
 // the adjacency form reads 64 B of ids and weights and gathers eight labels.  One thread per cell of the H x W square
 // (upper-triangular blocks: the cells below the diagonal idle).
-__global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restrict__ logprob, int64_t n, int K, int H, int W,
+__global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restrict__ logprob, const float* __restrict__ uT,
+                                                          int64_t n, int K, int H, int W,
                                                           int diagonal, const float4* __restrict__ fwd_w,
                                                           const uint8_t* __restrict__ labels, double* __restrict__ accum) {
   __shared__ double red[8];
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   double eu = 0.0, ep = 0.0;
-  for (int i = blockIdx.y * 4 + (threadIdx.x >> 6); i < H; i += gridDim.y * 4) {
-    if (j >= W || (diagonal && j < i)) continue;
-    const int64_t row = diagonal ? (int64_t)i * W - ((int64_t)i * (i - 1)) / 2 - i : (int64_t)i * W;      // node = row + j
-    const int64_t node = row + j;
-    const int l = labels[node];
-    eu -= (double)logprob[node * K + l];
-    const float4 w = fwd_w[node];
-    float s = 0.f;
-    if (j + 1 < W && labels[node + 1] != l) s += w.x;                                   // E
-    if (i + 1 < H) {
-      const int64_t row2 = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
-      const int jlo = diagonal ? i + 1 : 0;
-      if (j - 1 >= jlo && labels[row2 + j - 1] != l) s += w.y;                        // SW
-      if (j >= jlo && labels[row2 + j] != l) s += w.z;                                // S
-      if (j + 1 < W && labels[row2 + j + 1] != l) s += w.w;                            // SE
+  // four rows of the thread's column per trip, their loads issued side by side: the chain label -> unary term -> neighbour
+  // labels is latency, not bandwidth, and one row per trip left the memory system idle most of the time.  The unary term
+  // comes from the label-major planes when they are current (neighbouring nodes mostly share a label, so the reads
+  // coalesce, where the node-major rows cost a 64-byte sector per node).
+  constexpr int UR = 4;
+  const int stride = gridDim.y * 4;
+  for (int i0 = blockIdx.y * 4 + (threadIdx.x >> 6); i0 < H; i0 += stride * UR) {
+    int64_t node[UR];
+    int lab[UR];
+    bool on[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int i = i0 + u * stride;
+      on[u] = i < H && j < W && !(diagonal && j < i);
+      const int64_t row = diagonal ? (int64_t)i * W - ((int64_t)i * (i - 1)) / 2 - i : (int64_t)i * W;      // node = row + j
+      node[u] = on[u] ? row + j : 0;
+      lab[u] = labels[node[u]];
     }
-    ep += (double)s;
+    float un[UR];
+    float4 w[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      un[u] = uT ? uT[(int64_t)lab[u] * n + node[u]] : -logprob[node[u] * K + lab[u]];
+      w[u] = fwd_w[node[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      if (!on[u]) continue;
+      const int i = i0 + u * stride;
+      const int l = lab[u];
+      eu += (double)un[u];
+      float s = 0.f;
+      if (j + 1 < W && labels[node[u] + 1] != l) s += w[u].x;                                   // E
+      if (i + 1 < H) {
+        const int64_t row2 = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
+        const int jlo = diagonal ? i + 1 : 0;
+        if (j - 1 >= jlo && labels[row2 + j - 1] != l) s += w[u].y;                        // SW
+        if (j >= jlo && labels[row2 + j] != l) s += w[u].z;                                // S
+        if (j + 1 < W && labels[row2 + j + 1] != l) s += w[u].w;                            // SE
+      }
+      ep += (double)s;
+    }
   }
   const double tu = block_sum(eu, red);
   const double tp = block_sum(ep, red);
@@ -515,9 +544,9 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
 }  // namespace
 
 // ---- launchers --------------------------------------------------------------------------------------
-int launch_emission(const float* X, int64_t n, int S, int K, const float* packed, float* logprob, hipStream_t st) {
+int launch_emission(const float* X, int64_t n, int S, int K, const float* packed, float* logprob, float* uT, hipStream_t st) {
   switch (S) {
-#define PHMRF_CASE(S_) case S_: return launch_emission_s<S_>(X, n, K, packed, logprob, st);
+#define PHMRF_CASE(S_) case S_: return launch_emission_s<S_>(X, n, K, packed, logprob, uT, st);
     PHMRF_CASE(1) PHMRF_CASE(2) PHMRF_CASE(3) PHMRF_CASE(4) PHMRF_CASE(5) PHMRF_CASE(6) PHMRF_CASE(7) PHMRF_CASE(8)
     PHMRF_CASE(9) PHMRF_CASE(10) PHMRF_CASE(11) PHMRF_CASE(12) PHMRF_CASE(13) PHMRF_CASE(14) PHMRF_CASE(15) PHMRF_CASE(16)
 #undef PHMRF_CASE
@@ -562,8 +591,8 @@ int launch_energy(const phmrf_block* b, float beta) {
     int gy = (b->H + 3) / 4;
     const int cap = 2048 / gx + 1;          // ~2048 workgroups: each sums many rows before its two f64 atomics
     if (gy > cap) gy = cap;
-    hipLaunchKernelGGL(energy_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->logprob, b->n, b->K, b->H,
-                       b->W, b->diagonal, b->fwd_w, b->labels, b->accum);
+    hipLaunchKernelGGL(energy_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->logprob,
+                       (b->uT && b->uT_valid) ? b->uT : nullptr, b->n, b->K, b->H, b->W, b->diagonal, b->fwd_w, b->labels, b->accum);
     PHMRF_HIP(hipGetLastError());
     return PHMRF_OK;
   }
