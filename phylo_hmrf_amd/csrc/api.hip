@@ -845,14 +845,14 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
 
 static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, int geom = -1,
                               bool timed = true) {
+  if (!b->uT_valid) {                       // (before the proposals: on a grid they are formed from the planes)
+    tic(b);
+    PHMRF_TRY(launch_unary_planes(b));
+    toc(b, KC_PROPOSE, 1);
+  }
   if (alpha < 0) {
     tic(b);
     PHMRF_TRY(launch_propose(b, beta));
-    toc(b, KC_PROPOSE, 1);
-  }
-  if (!b->uT_valid) {
-    tic(b);
-    PHMRF_TRY(launch_unary_planes(b));
     toc(b, KC_PROPOSE, 1);
   }
   if (timed) tic(b);

@@ -1167,6 +1167,67 @@ __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ 
   }
 }
 
+// The same proposals on a grid block, from the tables the strip moves use: the unary terms from the label-major planes
+// (coalesced as they are, no transposition through LDS), the eight edge weights from the forward-edge table of the node
+// and of its four backward neighbours (found by geometry) -- 98 B per node where the adjacency form reads 145 B.  The
+// neighbours are visited in the order of the adjacency rows (NW N NE W E SW S SE), so the two kernels agree bit for bit.
+__global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restrict__ uT, int64_t n, int K, int Kp, int H, int W,
+                                                           int diagonal, const float4* __restrict__ fwd_w,
+                                                           const uint8_t* __restrict__ labels, float beta,
+                                                           uint8_t* __restrict__ prop, const uint16_t* __restrict__ stamp,
+                                                           int since) {
+  extern __shared__ float tile[];
+  const int TB = blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    if (since >= 0 && !__syncthreads_or((int)threadIdx.x < rows && (int)stamp[base + threadIdx.x] > since)) continue;
+    if ((int)threadIdx.x < rows) {
+      const int64_t v = base + threadIdx.x;
+      float* row = tile + threadIdx.x * Kp;
+      for (int k = 0; k < K; ++k) row[k] = uT[(int64_t)k * n + v];
+      int i, j;
+      if (!diagonal) {
+        i = (int)(v / W);
+        j = (int)(v - (int64_t)i * W);
+      } else {                      // start(i) = i W - i (i - 1) / 2: the largest i with start(i) <= v
+        const double bq = 2.0 * W + 1.0;
+        int r = (int)((bq - sqrt(bq * bq - 8.0 * (double)v)) * 0.5);
+        r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
+        while (r > 0 && (int64_t)r * W - ((int64_t)r * (r - 1)) / 2 > v) --r;
+        while (r + 1 < W && (int64_t)(r + 1) * W - ((int64_t)(r + 1) * r) / 2 <= v) ++r;
+        i = r;
+        j = r + (int)(v - ((int64_t)r * W - ((int64_t)r * (r - 1)) / 2));
+      }
+      // rows above / below: node of (i2, j2) = start(i2) + j2 - (diagonal ? i2 : 0)
+      const int64_t up = diagonal ? (int64_t)(i - 1) * W - ((int64_t)(i - 1) * (i - 2)) / 2 - (i - 1) : (int64_t)(i - 1) * W;
+      const int64_t dn = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
+      const int jlo_dn = diagonal ? i + 1 : 0;          // first column of the row below (the row above starts further left)
+      const float4 own = fwd_w[v];
+      if (i > 0) {
+        if (j - 1 >= 0) { const int64_t c = up + j - 1; row[labels[c]] -= beta * fwd_w[c].w; }     // NW holds me as its SE
+        { const int64_t c = up + j; row[labels[c]] -= beta * fwd_w[c].z; }                            // N: its S
+        if (j + 1 < W) { const int64_t c = up + j + 1; row[labels[c]] -= beta * fwd_w[c].y; }      // NE: its SW
+      }
+      if (j - 1 >= (diagonal ? i : 0)) { const int64_t c = v - 1; row[labels[c]] -= beta * fwd_w[c].x; }   // W: its E
+      if (j + 1 < W) row[labels[v + 1]] -= beta * own.x;                                              // E
+      if (i + 1 < H) {
+        if (j - 1 >= jlo_dn) row[labels[dn + j - 1]] -= beta * own.y;                                 // SW
+        if (j >= jlo_dn) row[labels[dn + j]] -= beta * own.z;                                         // S
+        if (j + 1 < W) row[labels[dn + j + 1]] -= beta * own.w;                                       // SE
+      }
+      const int cur = labels[v];
+      float best = 3.0e38f;
+      int bk = cur;
+      for (int k = 0; k < K; ++k) {
+        const float x = row[k];
+        if (k != cur && x < best) { best = x; bk = k; }
+      }
+      prop[v] = (uint8_t)bk;
+    }
+  }
+}
+
 inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 }  // namespace
@@ -1177,6 +1238,13 @@ int launch_propose(phmrf_block* b, float beta) {
   const size_t lds = (size_t)TB * Kp * sizeof(float);
   int64_t g64 = (b->n + TB - 1) / TB;
   const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
+  if (b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->D == 8) {
+    hipLaunchKernelGGL(propose_grid_kernel, dim3(grid), dim3(TB), lds, b->stream, b->uT, b->n, K, Kp, b->H, b->W, b->diagonal,
+                       b->fwd_w, b->labels, beta, b->labels_tmp, b->stamp, since);
+    PHMRF_HIP(hipGetLastError());
+    b->prop_tick = b->tick ? b->tick : -1;
+    return PHMRF_OK;
+  }
 #define PHMRF_LAUNCH_PROP(VEC_)                                                                                     \
   hipLaunchKernelGGL((propose_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
                      b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since)
