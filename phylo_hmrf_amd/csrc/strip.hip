@@ -365,21 +365,25 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
       float4 ef[NEP];
 #pragma unroll
       for (int q = 0; q < NEP; ++q) {               // ... then every load of the wave in flight at once
-        // (absent cells read node 0 and drop it below: no divergent branch, hence no wait, between the loads)
-        const int node = enode[q] < 0 ? 0 : enode[q];
-        elab[q] = labels[node];
-        epl[q] = prop ? (int)prop[node] : alpha;
-        ef[q] = fwd_w[node];
+        const int node = enode[q];
+        elab[q] = 0;
+        epl[q] = alpha;
+        ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node >= 0) {
+          elab[q] = labels[node];
+          if (prop) epl[q] = prop[node];
+          ef[q] = fwd_w[node];
+        }
       }
 #pragma unroll
       for (int q = 0; q < NEP; ++q) {
         const int e = eidx[q];
         if (e >= 0) {
           const bool present = enode[q] >= 0;
-          tab[e * REC + 0] = present ? ef[q].x * beta : 0.f;
-          tab[e * REC + 1] = present ? ef[q].y * beta : 0.f;
-          tab[e * REC + 2] = present ? ef[q].z * beta : 0.f;
-          tab[e * REC + 3] = present ? ef[q].w * beta : 0.f;
+          tab[e * REC + 0] = ef[q].x * beta;
+          tab[e * REC + 1] = ef[q].y * beta;
+          tab[e * REC + 2] = ef[q].z * beta;
+          tab[e * REC + 3] = ef[q].w * beta;
           tab[e * REC + 4] = __builtin_bit_cast(float, (int)(present ? (elab[q] | (epl[q] << 8)) : 0));
         }
       }
@@ -745,22 +749,24 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
           float4 ef[NEP];
 #pragma unroll
           for (int q = 0; q < NEP; ++q) {
-            // (absent cells read node 0 and drop it below: no divergent branch, hence no wait, between the loads)
-            const int node = enode[q] < 0 ? 0 : enode[q];
-            elab[q] = labels[node];
-            ef[q] = fwd_w[node];
+            const int node = enode[q];
+            elab[q] = 0;
+            ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (node >= 0) {
+              elab[q] = labels[node];
+              ef[q] = fwd_w[node];
+            }
           }
           __builtin_amdgcn_wave_barrier();        // (the slab may still hold the tables of the previous label's DP)
 #pragma unroll
           for (int q = 0; q < NEP; ++q) {
             const int e = eidx[q];
             if (e >= 0) {
-              const bool present = enode[q] >= 0;
-              tab[e * REC + 0] = present ? ef[q].x * beta : 0.f;
-              tab[e * REC + 1] = present ? ef[q].y * beta : 0.f;
-              tab[e * REC + 2] = present ? ef[q].z * beta : 0.f;
-              tab[e * REC + 3] = present ? ef[q].w * beta : 0.f;
-              tab[e * REC + 4] = __builtin_bit_cast(float, (int)(present ? elab[q] : 0));
+              tab[e * REC + 0] = ef[q].x * beta;
+              tab[e * REC + 1] = ef[q].y * beta;
+              tab[e * REC + 2] = ef[q].z * beta;
+              tab[e * REC + 3] = ef[q].w * beta;
+              tab[e * REC + 4] = __builtin_bit_cast(float, (int)(enode[q] >= 0 ? elab[q] : 0));
             }
           }
         }
