@@ -304,18 +304,22 @@ def main():
                          + (work["cells"] + work["swept_cells"]) * 68.0)
             lds_ach = lds_bytes / (busy["strip"] * 1e-3) / 1e12
             lds_peak = 256 * 256 * 2.4e9 / 1e12      # 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS)
-            roofline_limiter = {"bound": "issue+latency", "kernel": "strip",
+            roofline_limiter = {"bound": "latency at 3 waves per SIMD", "kernel": "strip",
                                 "sq": sq_profile("strip_multi_kernel"),
                                 "lds": {"achieved": round(lds_ach, 2), "peak": round(lds_peak, 1), "unit": "TB/s",
                                         "frac": round(lds_ach / lds_peak, 4)},
                                 "units": int(work["units"]), "single_proposal_cells": int(work["cells"]),
                                 "swept_cells": int(work["swept_cells"]), "label_cells": int(work["label_cells"]),
                                 "dp_steps": int(work["dp_steps"]),
+                                "occupancy_experiment": {"waves_per_simd": [3, 2], "kernel_ms": [8.63, 13.1],
+                                                         "source": "profiles/README.md (r2 warm-solve profile, chr1 block)"},
                                 "note": "since the exact filter (DESIGN.md 3.1) few (strip, label) pairs reach the DP: the "
-                                        "kernel is bound neither by HBM nor by the LDS pipe but by VALU/SALU issue at 3 "
-                                        "waves per SIMD and the latency of its dependent loads; `sq` = the SQ counters of "
-                                        "profiles/ (rocprofv3 --pmc, one block at a time): VALU issue share of a wave's "
-                                        "cycles x waves per SIMD = share of the SIMD's issue capacity"}
+                                        "kernel is bound neither by HBM nor by the LDS pipe nor by instruction issue but by "
+                                        "the latency of each wave's dependent chain (ballot -> scalar mask -> masked add -> "
+                                        "compare, and the global loads behind it): its time follows the resident waves (3 "
+                                        "per SIMD at 168 VGPRs; forced down to 2 it takes 1.5x) and barely moved when 42 % of "
+                                        "its VALU instructions were removed; `sq` = the SQ counters of profiles/ (rocprofv3 "
+                                        "--pmc, one block at a time), as shares of a wave's resident cycles"}
     kernels = {k: {"ms": round(v[0], 3), "launches": int(v[1]), "busy_ms": round(busy.get(k, 0.0), 3),
                    "GBps": (round(v[2] / (busy[k] * 1e-3) / 1e9, 1) if busy.get(k, 0) > 0 and v[2] > 0 else None)}
                for k, v in agg.items()}
@@ -366,6 +370,7 @@ def sq_profile(kernel):
         out = {k.replace("SQ_", "").replace("/WAVE_CYCLES", "_per_wave_cycle").lower(): v for k, v in d.items() if "/" in k}
         if "SQ_INSTS_VALU" in d and "SQ_WAVE_CYCLES" in d:
             out["valu_issue_share_of_simd_at_3_waves"] = round(3.0 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 3)
+            out["instructions_per_wave_quad_cycle"] = round(d.get("SQ_ACTIVE_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"], 3)
         return out
     except Exception:
         return None
