@@ -315,6 +315,47 @@ def test_moves_never_raise_energy_and_solver_converges():
     b.close()
 
 
+@pytest.mark.parametrize("H,W,diagonal", [(70, 70, True), (37, 90, False)])
+def test_unary_planes_written_by_the_emission_kernel(H, W, diagonal):
+    """From a block's second E-step on, the emission kernel writes the label-major unary planes itself and the grid
+    energy, the proposals and the strip moves read them: same energy as from the node-major rows, same solve as a
+    block that transposes the rows."""
+    blk = synth.make_block(3, H, W, 4, 6, diagonal)
+    X = blk["X"]
+    n = X.shape[0]
+    w, eid = R.edge_weights_from_distance(blk["edges"], 0.5)
+    rng = np.random.default_rng(1)
+    init = rng.integers(0, 6, n)
+    means2, covars2 = blk["means"] * 1.05, blk["covars"] * 1.1
+
+    def fresh():
+        b = _block(n, 4, 6)
+        b.set_observations(X)
+        b.set_graph(eid, w)
+        b.set_grid(H, W, diagonal, 8)
+        return b
+
+    a = fresh()
+    a.emission(blk["means"], blk["covars"])
+    a.set_labels(init)
+    a.solve(1.0)                                   # first solve: the planes are allocated and transposed from the rows
+    a.emission(means2, covars2)                    # second emission: the kernel writes rows and planes
+    a.set_labels(init)
+    e_planes = a.energy(1.0)
+    lp = a.get_logprob()
+    ra = a.solve(1.0)
+    la = a.get_labels()
+    b = fresh()
+    b.set_logprob(lp)                              # rows only: energy from the rows, planes by the transpose kernel
+    b.set_labels(init)
+    e_rows = b.energy(1.0)
+    rb = b.solve(1.0)
+    assert abs(e_planes[0] - e_rows[0]) <= 1e-12 * abs(e_rows[0]) and abs(e_planes[1] - e_rows[1]) <= 1e-12 * abs(e_rows[1])
+    assert np.array_equal(la, b.get_labels()) and ra["energy"] == rb["energy"] and ra["rounds"] == rb["rounds"]
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("tag,H,W,diagonal", [("diag", 11, 11, True), ("offdiag", 40, 50, False)])
 def test_energy_parity_with_reference_gco_golden(tag, H, W, diagonal):
     """north_star: final MRF energy <= the reference's (gco alpha-beta swap through pygco's quantisation),
