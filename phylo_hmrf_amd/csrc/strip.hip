@@ -1343,7 +1343,9 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
   if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
   const int WPB = PHMRF_MULTI_WPB, TB = 64 * WPB;
   int grid = (nstrips + WPB - 1) / WPB;
-  if (grid > 256 * 96 / WPB) grid = 256 * 96 / WPB;   // (beyond 8 resident sets of waves they stride over the strips)
+  // one workgroup per strip up to 4 M strips: the dispatcher hands a free slot the next strip, which balances the
+  // uneven strips better than waves striding over them (measured against a cap of 8 resident sets: -3 % on the rows cut)
+  if (grid > (1 << 22)) grid = 1 << 22;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
 #define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
   hipLaunchKernelGGL((strip_multi_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
