@@ -1315,7 +1315,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
   const int WPB = PHMRF_STRIP_WPB, TB = 64 * WPB;
   int grid = (nstrips + WPB - 1) / WPB;
-  if (grid > 256 * 128 / WPB) grid = 256 * 128 / WPB;
+  if (grid > (1 << 22)) grid = 1 << 22;          // one workgroup per strip (see launch_strip_multi)
   const bool use_memo = b->tick && geom >= 0 && b->memo && (int64_t)nstrips <= b->memo_strips;
 #define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
   hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
