@@ -173,4 +173,47 @@ int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
 
+// ---- grid geometry for the kernels that find a node's neighbours by arithmetic (device code) ---------------------
+// Diagonal blocks hold the upper triangle row-major: row i starts at start(i) = i W - i (i - 1) / 2 with column i.
+__device__ __forceinline__ void grid_coords(int64_t v, int W, int diagonal, int* i, int* j) {
+  if (!diagonal) {
+    *i = (int)(v / W);
+    *j = (int)(v - (int64_t)(*i) * W);
+    return;
+  }
+  const double bq = 2.0 * W + 1.0;
+  int r = (int)((bq - sqrt(bq * bq - 8.0 * (double)v)) * 0.5);     // the largest i with start(i) <= v, up to rounding
+  r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
+  while (r > 0 && (int64_t)r * W - ((int64_t)r * (r - 1)) / 2 > v) --r;
+  while (r + 1 < W && (int64_t)(r + 1) * W - ((int64_t)(r + 1) * r) / 2 <= v) ++r;
+  *i = r;
+  *j = r + (int)(v - ((int64_t)r * W - ((int64_t)r * (r - 1)) / 2));
+}
+// node of (i, j) = grid_row_base(i) + j
+__device__ __forceinline__ int64_t grid_row_base(int i, int W, int diagonal) {
+  return diagonal ? (int64_t)i * W - ((int64_t)i * (i - 1)) / 2 - i : (int64_t)i * W;
+}
+// f(c, w) for every grid neighbour c of node v = (i, j) with the weight w of the edge, in the order of the adjacency
+// rows (ascending ids: NW N NE W E SW S SE).  The weights come from the forward-edge records (E, SW, S, SE of a node):
+// the node's own for its forward edges, its backward neighbours' for the others.
+template <class F>
+__device__ __forceinline__ void grid_for_each_neighbour(int64_t v, int i, int j, int H, int W, int diagonal,
+                                                        const float4* __restrict__ fwd_w, F&& f) {
+  const int64_t up = grid_row_base(i - 1, W, diagonal), dn = grid_row_base(i + 1, W, diagonal);
+  const int jlo_dn = diagonal ? i + 1 : 0;            // first column of the row below (the row above starts further left)
+  const float4 own = fwd_w[v];
+  if (i > 0) {
+    if (j - 1 >= 0) { const int64_t c = up + j - 1; f(c, fwd_w[c].w); }          // NW holds the edge as its SE
+    { const int64_t c = up + j; f(c, fwd_w[c].z); }                                // N: its S
+    if (j + 1 < W) { const int64_t c = up + j + 1; f(c, fwd_w[c].y); }           // NE: its SW
+  }
+  if (j - 1 >= (diagonal ? i : 0)) { const int64_t c = v - 1; f(c, fwd_w[c].x); }  // W: its E
+  if (j + 1 < W) f(v + 1, own.x);                                                   // E
+  if (i + 1 < H) {
+    if (j - 1 >= jlo_dn) f(dn + j - 1, own.y);                                      // SW
+    if (j >= jlo_dn) f(dn + j, own.z);                                              // S
+    if (j + 1 < W) f(dn + j + 1, own.w);                                            // SE
+  }
+}
+
 }  // namespace phmrf

@@ -1187,35 +1187,8 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
       float* row = tile + threadIdx.x * Kp;
       for (int k = 0; k < K; ++k) row[k] = uT[(int64_t)k * n + v];
       int i, j;
-      if (!diagonal) {
-        i = (int)(v / W);
-        j = (int)(v - (int64_t)i * W);
-      } else {                      // start(i) = i W - i (i - 1) / 2: the largest i with start(i) <= v
-        const double bq = 2.0 * W + 1.0;
-        int r = (int)((bq - sqrt(bq * bq - 8.0 * (double)v)) * 0.5);
-        r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
-        while (r > 0 && (int64_t)r * W - ((int64_t)r * (r - 1)) / 2 > v) --r;
-        while (r + 1 < W && (int64_t)(r + 1) * W - ((int64_t)(r + 1) * r) / 2 <= v) ++r;
-        i = r;
-        j = r + (int)(v - ((int64_t)r * W - ((int64_t)r * (r - 1)) / 2));
-      }
-      // rows above / below: node of (i2, j2) = start(i2) + j2 - (diagonal ? i2 : 0)
-      const int64_t up = diagonal ? (int64_t)(i - 1) * W - ((int64_t)(i - 1) * (i - 2)) / 2 - (i - 1) : (int64_t)(i - 1) * W;
-      const int64_t dn = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
-      const int jlo_dn = diagonal ? i + 1 : 0;          // first column of the row below (the row above starts further left)
-      const float4 own = fwd_w[v];
-      if (i > 0) {
-        if (j - 1 >= 0) { const int64_t c = up + j - 1; row[labels[c]] -= beta * fwd_w[c].w; }     // NW holds me as its SE
-        { const int64_t c = up + j; row[labels[c]] -= beta * fwd_w[c].z; }                            // N: its S
-        if (j + 1 < W) { const int64_t c = up + j + 1; row[labels[c]] -= beta * fwd_w[c].y; }      // NE: its SW
-      }
-      if (j - 1 >= (diagonal ? i : 0)) { const int64_t c = v - 1; row[labels[c]] -= beta * fwd_w[c].x; }   // W: its E
-      if (j + 1 < W) row[labels[v + 1]] -= beta * own.x;                                              // E
-      if (i + 1 < H) {
-        if (j - 1 >= jlo_dn) row[labels[dn + j - 1]] -= beta * own.y;                                 // SW
-        if (j >= jlo_dn) row[labels[dn + j]] -= beta * own.z;                                         // S
-        if (j + 1 < W) row[labels[dn + j + 1]] -= beta * own.w;                                       // SE
-      }
+      grid_coords(v, W, diagonal, &i, &j);
+      grid_for_each_neighbour(v, i, j, H, W, diagonal, fwd_w, [&](int64_t c, float w) { row[labels[c]] -= beta * w; });
       const int cur = labels[v];
       float best = 3.0e38f;
       int bk = cur;
