@@ -216,4 +216,28 @@ __device__ __forceinline__ void grid_for_each_neighbour(int64_t v, int i, int j,
   }
 }
 
+// The same as arrays, every load issued before any use (absent neighbours: node v itself with weight 0): ids c[8] and
+// weights w[8] in adjacency order.  For kernels whose work per neighbour is a dependent scatter -- with the callback
+// form each neighbour's loads wait for the one before.
+__device__ __forceinline__ void grid_gather_neighbours(int64_t v, int i, int j, int H, int W, int diagonal,
+                                                       const float4* __restrict__ fwd_w, int64_t (&c)[8], float (&w)[8]) {
+  const int64_t up = grid_row_base(i - 1, W, diagonal), dn = grid_row_base(i + 1, W, diagonal);
+  const int jlo_dn = diagonal ? i + 1 : 0;
+  const bool has[8] = {i > 0 && j - 1 >= 0, i > 0, i > 0 && j + 1 < W, j - 1 >= (diagonal ? i : 0), j + 1 < W,
+                       i + 1 < H && j - 1 >= jlo_dn, i + 1 < H && j >= jlo_dn, i + 1 < H && j + 1 < W};
+  const int64_t id[8] = {up + j - 1, up + j, up + j + 1, v - 1, v + 1, dn + j - 1, dn + j, dn + j + 1};
+#pragma unroll
+  for (int d = 0; d < 8; ++d) c[d] = has[d] ? id[d] : v;
+  const float4 own = fwd_w[v];
+  const float4 f0 = fwd_w[c[0]], f1 = fwd_w[c[1]], f2 = fwd_w[c[2]], f3 = fwd_w[c[3]];
+  w[0] = has[0] ? f0.w : 0.f;      // NW holds the edge as its SE
+  w[1] = has[1] ? f1.z : 0.f;      // N: its S
+  w[2] = has[2] ? f2.y : 0.f;      // NE: its SW
+  w[3] = has[3] ? f3.x : 0.f;      // W: its E
+  w[4] = has[4] ? own.x : 0.f;
+  w[5] = has[5] ? own.y : 0.f;
+  w[6] = has[6] ? own.z : 0.f;
+  w[7] = has[7] ? own.w : 0.f;
+}
+
 }  // namespace phmrf

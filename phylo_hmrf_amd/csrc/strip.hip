@@ -1185,11 +1185,25 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
     if ((int)threadIdx.x < rows) {
       const int64_t v = base + threadIdx.x;
       float* row = tile + threadIdx.x * Kp;
-      for (int k = 0; k < K; ++k) row[k] = uT[(int64_t)k * n + v];
+      // (loads first, uses after: a loop of load -> LDS store per label is one memory round trip per label and thread)
       int i, j;
       grid_coords(v, W, diagonal, &i, &j);
-      grid_for_each_neighbour(v, i, j, H, W, diagonal, fwd_w, [&](int64_t c, float w) { row[labels[c]] -= beta * w; });
+      int64_t nc[8];
+      float nw[8];
+      grid_gather_neighbours(v, i, j, H, W, diagonal, fwd_w, nc, nw);
+      int nl[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) nl[d] = labels[nc[d]];
       const int cur = labels[v];
+      int k0 = 0;
+      for (; k0 + 4 <= K; k0 += 4) {
+        const float a0 = uT[(int64_t)k0 * n + v], a1 = uT[(int64_t)(k0 + 1) * n + v];
+        const float a2 = uT[(int64_t)(k0 + 2) * n + v], a3 = uT[(int64_t)(k0 + 3) * n + v];
+        row[k0] = a0; row[k0 + 1] = a1; row[k0 + 2] = a2; row[k0 + 3] = a3;
+      }
+      for (; k0 < K; ++k0) row[k0] = uT[(int64_t)k0 * n + v];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) row[nl[d]] -= beta * nw[d];      // (an absent neighbour subtracts 0 from some entry)
       float best = 3.0e38f;
       int bk = cur;
       for (int k = 0; k < K; ++k) {
