@@ -376,6 +376,72 @@ __global__ __launch_bounds__(256) void comp_table_kernel(const float* __restrict
   }
 }
 
+// The same table on a grid block from the tables of the strip moves: the unary terms from the label-major planes
+// (column k of the tile is a coalesced read, no transposition), the boundary weights from the forward-edge records by
+// geometry; every load of a thread is issued before its uses (planes four at a time, the eight neighbours gathered
+// first).  The neighbours come in the order of the adjacency rows, so the two kernels agree up to the order of the atomics.
+__global__ __launch_bounds__(256) void comp_table_grid_kernel(const float* __restrict__ uT, int64_t n, int K, int Kp, int H,
+                                                              int W, int diagonal, const float4* __restrict__ fwd_w,
+                                                              const uint8_t* __restrict__ labels,
+                                                              const int32_t* __restrict__ comp, float beta,
+                                                              float* __restrict__ tab) {
+  extern __shared__ float lds[];
+  const int TB = blockDim.x;
+  float* tile = lds;                                          // [TB][Kp]
+  int32_t* roots = reinterpret_cast<int32_t*>(lds + TB * Kp);  // [TB]
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+    const int64_t rem = n - base;
+    const int rows = rem < TB ? (int)rem : TB;
+    if ((int)threadIdx.x < rows) {
+      const int64_t v = base + threadIdx.x;
+      float* row = tile + threadIdx.x * Kp;
+      int i, j;
+      grid_coords(v, W, diagonal, &i, &j);
+      int64_t nc[8];
+      float nw[8];
+      grid_gather_neighbours(v, i, j, H, W, diagonal, fwd_w, nc, nw);
+      int nl[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) nl[d] = labels[nc[d]];
+      const int li = labels[v];
+      roots[threadIdx.x] = comp[v];
+      int k0 = 0;
+      for (; k0 + 4 <= K; k0 += 4) {
+        const float a0 = uT[(int64_t)k0 * n + v], a1 = uT[(int64_t)(k0 + 1) * n + v];
+        const float a2 = uT[(int64_t)(k0 + 2) * n + v], a3 = uT[(int64_t)(k0 + 3) * n + v];
+        row[k0] = a0; row[k0 + 1] = a1; row[k0 + 2] = a2; row[k0 + 3] = a3;
+      }
+      for (; k0 < K; ++k0) row[k0] = uT[(int64_t)k0 * n + v];
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        if (nl[d] != li) row[nl[d]] -= beta * nw[d];      // (an absent neighbour is the node itself: same label, skipped)
+    }
+    __syncthreads();
+    // column k, row slice s: walk the slice, flush one atomic per run of equal root
+    const int nslice = TB / K;
+    const int k = threadIdx.x % K, s = threadIdx.x / K;
+    if (s < nslice) {
+      const int per = (rows + nslice - 1) / nslice;
+      const int r0 = s * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+      if (r0 < r1) {
+        int root = roots[r0];
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+          const int rr = roots[r];
+          if (rr != root) {
+            atomicAdd(tab + (int64_t)root * K + k, acc);
+            acc = 0.f;
+            root = rr;
+          }
+          acc += tile[r * Kp + k];
+        }
+        atomicAdd(tab + (int64_t)root * K + k, acc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // best strictly-improving label per component (computed at the root node); gain = dE < 0 or 0
 __global__ void comp_decide_kernel(const float* __restrict__ tab, int64_t n, int K, const uint8_t* __restrict__ labels,
                                    const int32_t* __restrict__ comp, int32_t* __restrict__ best,
@@ -508,7 +574,13 @@ int launch_component_pass(phmrf_block* b, float beta) {
   hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels);
   hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0);
   hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move);
-  {
+  const bool grid_tables = b->has_grid && b->num_neighbor == 8 && D == 8 && b->fwd_w && b->uT && b->uT_valid;
+  if (grid_tables) {
+    const int TB = tile_threads(K);
+    const size_t lds = (size_t)TB * Kp * sizeof(float) + (size_t)TB * sizeof(int32_t);
+    hipLaunchKernelGGL(comp_table_grid_kernel, dim3(grid1d(n, TB)), dim3(TB), lds, st, b->uT, n, K, Kp, b->H, b->W, b->diagonal,
+                       b->fwd_w, b->labels, b->comp, beta, b->comp_tab);
+  } else {
     const int TB = tile_threads(K);
     const size_t lds = (size_t)TB * Kp * sizeof(float) + (size_t)TB * sizeof(int32_t);
     const int grid = grid1d(n, TB);
