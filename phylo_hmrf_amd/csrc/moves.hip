@@ -184,6 +184,18 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* __restrict__ lo
   if (lane == 0 && s) atomicAdd(changed, (unsigned long long)s);
 }
 
+// an adjacency row into registers: two 16-byte loads when D == 8 (the reference's stencil), so that the loop over the
+// row is not one memory round trip per entry
+__device__ __forceinline__ void load_row(const int32_t* __restrict__ nbr, int64_t i, int D, int (&nb)[8]) {
+  if (D == 8) {
+    const int4 a = *reinterpret_cast<const int4*>(nbr + i * 8), b = *reinterpret_cast<const int4*>(nbr + i * 8 + 4);
+    nb[0] = a.x; nb[1] = a.y; nb[2] = a.z; nb[3] = a.w; nb[4] = b.x; nb[5] = b.y; nb[6] = b.z; nb[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nb[j] = j < D ? nbr[i * D + j] : -1;
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // connected components of equal label
 // -------------------------------------------------------------------------------------------------
@@ -203,10 +215,19 @@ __global__ __launch_bounds__(256) void cc_init_kernel(int32_t* __restrict__ comp
     const int64_t i = base + lane;
     bool linked = false;
     if (i < n && i > 0) {
-      const int l = labels[i];
-      const int32_t* nb = nbr + i * D;
-      for (int j = 0; j < D; ++j)
-        if (nb[j] == (int)(i - 1)) linked = labels[i - 1] == l;
+      const int l = labels[i], lw = labels[i - 1];
+      if (D <= 8) {
+        int nb[8];
+        load_row(nbr, i, D, nb);
+        bool adj = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) adj = adj || nb[j] == (int)(i - 1);
+        linked = adj && lw == l;
+      } else {
+        const int32_t* nb = nbr + i * D;
+        for (int j = 0; j < D; ++j)
+          if (nb[j] == (int)(i - 1)) linked = lw == l;
+      }
     }
     const unsigned long long starts = ~__ballot(linked);              // lanes that begin a run (or are out of range)
     const unsigned long long below = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
@@ -232,10 +253,59 @@ __device__ __forceinline__ int cc_find(int32_t* comp, int x) {
 // (they are that mate's up and up-right), so it only has to union with its LARGEST remaining smaller neighbour
 // (up-right in an 8-neighbourhood, up in a 4-neighbourhood).  This removes two thirds of the finds and most of the
 // atomics that would all hit the same pair of roots.
+__device__ __forceinline__ void cc_hook(int32_t* comp, int& ri, int i, int c) {
+  if (ri < 0) ri = cc_find(comp, i);
+  int rc = cc_find(comp, c);
+  while (ri != rc) {
+    int hi = ri > rc ? ri : rc, lo = ri > rc ? rc : ri;
+    const int old = atomicCAS(comp + hi, hi, lo);
+    if (old == hi) {            // hooked: both ends now share the root lo
+      ri = lo;
+      rc = lo;
+    } else {                    // hi was no longer a root: continue from where it points
+      if (hi == ri) ri = cc_find(comp, old); else rc = cc_find(comp, old);
+    }
+  }
+}
+
 __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, const int32_t* __restrict__ nbr,
                                 const uint8_t* __restrict__ labels, int grid) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int l = labels[i];
+    if (D <= 8) {
+      // the row and the labels of its smaller entries in registers, all loads side by side (the general form below
+      // walks the row entry by entry: one memory round trip each)
+      int nb[8], ln[8];
+      load_row(nbr, i, D, nb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ln[j] = (nb[j] >= 0 && nb[j] < (int)i) ? (int)labels[nb[j]] : -1;
+      bool linked = false;
+      int last = -1, n_above = 0, lab_last = -1, lab_before = -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = nb[j];
+        if (c >= 0 && c == (int)i - 1) linked = ln[j] == l;
+        if (c >= 0 && c < (int)i - 1) {              // rows are ascending: the largest smaller neighbour below i-1
+          lab_before = lab_last;
+          lab_last = ln[j];
+          last = j;
+          ++n_above;
+        }
+      }
+      const bool only_last = grid && linked;
+      if (only_last && grid == 8) {                  // (see the general form for why)
+        if (n_above < 3) continue;
+        if (lab_before == l) continue;
+      }
+      const int first = only_last ? (last < 0 ? 8 : last) : 0;
+      int ri = -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = nb[j];
+        if (j >= first && c >= 0 && c < (int)i - 1 && ln[j] == l) cc_hook(comp, ri, (int)i, c);
+      }
+      continue;
+    }
     const int32_t* nb = nbr + i * D;
     bool linked = false;
     int last = -1, n_above = 0;
@@ -263,18 +333,7 @@ __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, co
       const int c = nb[j];
       if (c < 0 || c >= (int)i - 1) { if (c >= (int)i - 1) break; continue; }
       if (labels[c] != l) continue;
-      if (ri < 0) ri = cc_find(comp, (int)i);
-      int rc = cc_find(comp, c);
-      while (ri != rc) {
-        int hi = ri > rc ? ri : rc, lo = ri > rc ? rc : ri;
-        const int old = atomicCAS(comp + hi, hi, lo);
-        if (old == hi) {            // hooked: both ends now share the root lo
-          ri = lo;
-          rc = lo;
-        } else {                    // hi was no longer a root: continue from where it points
-          if (hi == ri) ri = cc_find(comp, old); else rc = cc_find(comp, old);
-        }
-      }
+      cc_hook(comp, ri, (int)i, c);
     }
   }
 }
@@ -454,7 +513,15 @@ __global__ void comp_decide_kernel(const float* __restrict__ tab, int64_t n, int
       const int cur = labels[i];
       const float tc = row[cur];
       float bv = tc;
-      for (int k = 0; k < K; ++k) {
+      int k = 0;
+      for (; k + 4 <= K; k += 4) {                  // (four loads side by side; same scan order)
+        const float v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
+        if (v0 < bv) { bv = v0; bk = k; }
+        if (v1 < bv) { bv = v1; bk = k + 1; }
+        if (v2 < bv) { bv = v2; bk = k + 2; }
+        if (v3 < bv) { bv = v3; bk = k + 3; }
+      }
+      for (; k < K; ++k) {
         const float v = row[k];
         if (v < bv) { bv = v; bk = k; }
       }
@@ -474,6 +541,19 @@ __global__ void comp_block_kernel(int64_t n, int D, const int32_t* __restrict__ 
     const int ci = comp[i];
     const float gi = gain[ci];
     if (gi >= 0.f) continue;
+    if (D <= 8) {
+      int nb[8], cj[8];
+      load_row(nbr, i, D, nb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cj[j] = nb[j] >= 0 ? comp[nb[j]] : ci;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (cj[j] == ci) continue;
+        const float gj = gain[cj[j]];
+        if (gj < gi || (gj == gi && cj[j] < ci)) blocked[ci] = 1;
+      }
+      continue;
+    }
     const int32_t* nb = nbr + i * D;
     for (int j = 0; j < D; ++j) {
       const int c = nb[j];
@@ -498,9 +578,17 @@ __global__ void comp_apply_kernel(int64_t n, const int32_t* __restrict__ comp, c
       labels[i] = (uint8_t)bk;
       if (stamp) {
         stamp[i] = (uint16_t)tick;
-        const int32_t* nb2 = nbr + i * D;
-        for (int j = 0; j < D; ++j)
-          if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick;
+        if (D <= 8) {
+          int nb[8];
+          load_row(nbr, i, D, nb);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (nb[j] >= 0) stamp[nb[j]] = (uint16_t)tick;
+        } else {
+          const int32_t* nb2 = nbr + i * D;
+          for (int j = 0; j < D; ++j)
+            if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick;
+        }
       }
       ++mine;
     }
