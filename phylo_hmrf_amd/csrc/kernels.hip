@@ -45,12 +45,11 @@ __device__ __forceinline__ void rows_to_tile(const float* __restrict__ mat, cons
                                              float tile_scale) {
   const int KV = K / VEC;
   const int total = rows * KV;
-  for (int q = threadIdx.x; q < total; q += blockDim.x) {
+  auto ld = [&](int q, float (&v)[VEC]) {
     const int r = q / KV;
     const int c = (q - r * KV) * VEC;
     const int64_t node = nodes ? (int64_t)nodes[base + r] : base + r;
     const float* src = mat + node * K + c;
-    float v[VEC];
     if (VEC == 4) {
       const float4 t = *reinterpret_cast<const float4*>(src);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -60,9 +59,27 @@ __device__ __forceinline__ void rows_to_tile(const float* __restrict__ mat, cons
     } else {
       v[0] = src[0];
     }
+  };
+  auto st = [&](int q, const float (&v)[VEC]) {
+    const int r = q / KV;
+    const int c = (q - r * KV) * VEC;
     float* dst = tile + r * Kp + c;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dst[j] = ACCUM ? fmaf(tile_scale, dst[j], scale * v[j]) : scale * v[j];
+  };
+  // four pieces per lane and trip, their loads side by side (one load -> one LDS store per trip is a memory round trip
+  // per piece and lane)
+  const int step = blockDim.x;
+  int q = threadIdx.x;
+  for (; q + 3 * step < total; q += 4 * step) {
+    float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+    ld(q, v0); ld(q + step, v1); ld(q + 2 * step, v2); ld(q + 3 * step, v3);
+    st(q, v0); st(q + step, v1); st(q + 2 * step, v2); st(q + 3 * step, v3);
+  }
+  for (; q < total; q += step) {
+    float v[VEC];
+    ld(q, v);
+    st(q, v);
   }
 }
 
@@ -401,11 +418,14 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
         const float4 wv = *reinterpret_cast<const float4*>(wg + j);
         const int cc[4] = {c.x, c.y, c.z, c.w};
         const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+        int ll[4];                       // (the four labels side by side; absent entries read the node's own)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ll[t] = labels[cc[t] >= 0 ? (int64_t)cc[t] : i];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if (cc[t] >= 0) {
             const float w = use_w ? ww[t] : 1.f;
-            const int l = labels[cc[t]];
+            const int l = ll[t];
             row[l] += w;
             wtot += w;
             if (l != li) diff += w;
