@@ -284,7 +284,8 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
   __syncthreads();
 
   // waves are independent: every wave walks strips of the cut
-  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
+  for (int strip_v = blockIdx.x * WPB + wave; strip_v < nstrips; strip_v += gridDim.x * WPB) {
+    const int strip = __builtin_amdgcn_readfirstlane(strip_v);     // the wave's strip: its geometry in SGPRs
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
     const int rs0 = bnd * (SH + 1) - g.shift_r;
@@ -643,7 +644,10 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
 #define PH(K_)
 #endif
 
-  for (int strip = blockIdx.x * WPB + wave; strip < nstrips; strip += gridDim.x * WPB) {
+  for (int strip_v = blockIdx.x * WPB + wave; strip_v < nstrips; strip_v += gridDim.x * WPB) {
+    // (the strip is the wave's, not the lane's: as scalars the geometry below lives in SGPRs instead of VGPRs that
+    //  ended up in scratch and were reloaded sixteen times per staging)
+    const int strip = __builtin_amdgcn_readfirstlane(strip_v);
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
     const int rs0 = bnd * (SH + 1) - g.shift_r;
