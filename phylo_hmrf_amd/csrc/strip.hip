@@ -679,9 +679,9 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
       int nw = 0;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p)
-        if (nodev[p] >= 0) {
-          const int st = stamp[nodev[p]];
-          nw = st > nw ? st : nw;
+        {                                   // (absent cells read node 0: the five loads go out together)
+          const int st = stamp[nodev[p] >= 0 ? nodev[p] : 0];
+          nw = (nodev[p] >= 0 && st > nw) ? st : nw;
         }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
@@ -791,9 +791,10 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
           asm volatile("" : "+v"(t));
           const int cc = t / SH, rr = t - cc * SH;
           const int e0 = (cc + 1) * EH + (rr + 1);
-          const bool have = nodev[p] >= 0;
+          const int nd = node_tab[wave][t];           // (from LDS: kept in registers across the label loop they spill)
+          const bool have = nd >= 0;
           const int l = have ? __builtin_bit_cast(int, tab[have ? e0 * REC + 4 : 4]) & 255 : 0;
-          ucl[p] = uT[(int64_t)l * n + (have ? nodev[p] : 0)];
+          ucl[p] = uT[(int64_t)l * n + (have ? nd : 0)];
         }
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
           float hs = 0.f, uc = 0.f;
 #pragma unroll
           for (int d = 0; d < 8; ++d) v8[p][d] = 0.f;
-          if (nodev[p] >= 0) {
+          if (node_tab[wave][t] >= 0) {
             const int cc = t / SH, rr = t - cc * SH;
             const int e0 = (cc + 1) * EH + (rr + 1);
             const int l = __builtin_bit_cast(int, tab[e0 * REC + 4]) & 255;
