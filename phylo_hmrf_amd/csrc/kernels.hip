@@ -337,21 +337,31 @@ __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restric
       un[u] = uT ? uT[(int64_t)lab[u] * n + node[u]] : -logprob[node[u] * K + lab[u]];
       w[u] = fwd_w[node[u]];
     }
+    // the four forward neighbours' labels of all rows, side by side (an absent neighbour reads the node itself: equal
+    // label, no contribution)
+    int ln[UR][4];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int i = i0 + u * stride;
+      const int64_t row2 = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
+      const int jlo = diagonal ? i + 1 : 0;
+      const bool below = on[u] && i + 1 < H;
+      const int64_t me = node[u];
+      ln[u][0] = labels[(on[u] && j + 1 < W) ? me + 1 : me];                             // E
+      ln[u][1] = labels[(below && j - 1 >= jlo) ? row2 + j - 1 : me];                      // SW
+      ln[u][2] = labels[(below && j >= jlo) ? row2 + j : me];                              // S
+      ln[u][3] = labels[(below && j + 1 < W) ? row2 + j + 1 : me];                         // SE
+    }
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       if (!on[u]) continue;
-      const int i = i0 + u * stride;
       const int l = lab[u];
       eu += (double)un[u];
       float s = 0.f;
-      if (j + 1 < W && labels[node[u] + 1] != l) s += w[u].x;                                   // E
-      if (i + 1 < H) {
-        const int64_t row2 = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
-        const int jlo = diagonal ? i + 1 : 0;
-        if (j - 1 >= jlo && labels[row2 + j - 1] != l) s += w[u].y;                        // SW
-        if (j >= jlo && labels[row2 + j] != l) s += w[u].z;                                // S
-        if (j + 1 < W && labels[row2 + j + 1] != l) s += w[u].w;                            // SE
-      }
+      if (ln[u][0] != l) s += w[u].x;
+      if (ln[u][1] != l) s += w[u].y;
+      if (ln[u][2] != l) s += w[u].z;
+      if (ln[u][3] != l) s += w[u].w;
       ep += (double)s;
     }
   }
@@ -413,6 +423,26 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
       const float* wg = wgt + i * D;
       float diff = 0.f;
       int deg = 0;
+      if (D == 8) {                      // the reference's stencil: the whole row and the labels behind it side by side
+        const int4 c0 = *reinterpret_cast<const int4*>(nb), c1 = *reinterpret_cast<const int4*>(nb + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(wg), w1 = *reinterpret_cast<const float4*>(wg + 4);
+        const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        int ll[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ll[t] = labels[cc[t] >= 0 ? (int64_t)cc[t] : i];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (cc[t] >= 0) {
+            const float w = use_w ? ww[t] : 1.f;
+            const int l = ll[t];
+            row[l] += w;
+            wtot += w;
+            if (l != li) diff += w;
+            ++deg;
+          }
+        }
+      } else
       for (int j = 0; j < D; j += 4) {
         const int4 c = *reinterpret_cast<const int4*>(nb + j);
         const float4 wv = *reinterpret_cast<const float4*>(wg + j);
