@@ -6,7 +6,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphmrf.so")
+# PHMRF_LIB: development builds (tools/variant.sh writes them under variants/) are loaded from their own path; the
+# product library is never overwritten
+LIB_PATH = os.environ.get("PHMRF_LIB") or os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
 NUM_KERNEL_CLASSES = 9

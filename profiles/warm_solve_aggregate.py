@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Warm-solve part of a tests/_trace.py run: per-kernel time in launch order (kernel trace) and SQ counters (pmc pass).
+"""Warm-solve part of a tools/trace.py run: per-kernel time in launch order (kernel trace) and SQ counters (pmc pass).
 usage: warm_solve_aggregate.py KT_DIR PMC_DIR OUT.json   (the warm part = everything after the 2nd emission_kernel)"""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

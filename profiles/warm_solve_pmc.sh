@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the warm part of tests/_trace.py on the chr1 block; usage: warm_solve_pmc.sh TAG "COUNTER ..." ["COUNTER ..." ...]
+# SQ counters of the warm part of tools/trace.py on the chr1 block; usage: warm_solve_pmc.sh TAG "COUNTER ..." ["COUNTER ..." ...]
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -8,7 +8,7 @@ export PHMRF_TRACE_PERT=0.05
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/wp_$i -- python3 tests/_trace.py 20 4980 1000 > /dev/null 2> $O/${TAG}_pmc$i.err
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/wp_$i -- python3 tools/trace.py 20 4980 1000 > /dev/null 2> $O/${TAG}_pmc$i.err
   mkdir -p $O/wp_empty
   python3 profiles/warm_solve_aggregate.py $O/wp_empty $O/wp_$i $O/${TAG}_pmc$i.json > /dev/null 2>&1
   python3 -c "

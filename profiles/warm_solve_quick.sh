@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 export PHMRF_TRACE_PERT=0.05
-rocprofv3 --kernel-trace --output-format csv -d $O/ws_kt -- python3 tests/_trace.py 20 4980 1000 > $O/${TAG}_warm_trace.out 2> $O/${TAG}_warm_trace.err
+rocprofv3 --kernel-trace --output-format csv -d $O/ws_kt -- python3 tools/trace.py 20 4980 1000 > $O/${TAG}_warm_trace.out 2> $O/${TAG}_warm_trace.err
 mkdir -p $O/ws_empty
 python3 profiles/warm_solve_aggregate.py $O/ws_kt $O/ws_empty $O/${TAG}_warm_solve.json > /dev/null
 rm -rf $O/ws_kt

@@ -1,5 +1,5 @@
 """Development helper (GPU): the bench's EM loop on a workload, printing per EM iteration the cost, whether labels_local
-was renewed, and how far the warm-started solves moved.  usage: python tests/_em_diag.py [workload] [iterations]"""
+was renewed, and how far the warm-started solves moved.  usage: python tools/em_diag.py [workload] [iterations]"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch

@@ -1,5 +1,5 @@
 """Development helper (GPU only): final energy of the label solver on the cfg2-size synthetic block from different starts.
-usage: python tests/_exp_energy.py [seed N K]   (gco reference energies for seed 13, N 2000, K 10 are known constants)"""
+usage: python tools/exp_energy.py [seed N K]   (gco reference energies for seed 13, N 2000, K 10 are known constants)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np

@@ -1,5 +1,5 @@
 """Per-round trace of one solve on a synthetic diagonal block (development helper, GPU only).
-usage: PHMRF_SOLVE_TRACE=1 python tests/_trace.py K N [tol_ppb]"""
+usage: PHMRF_SOLVE_TRACE=1 python tools/trace.py K N [tol_ppb]"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
