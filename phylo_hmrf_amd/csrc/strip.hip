@@ -1099,6 +1099,716 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// strip_cols_kernel (round 3): the same launch -- every alpha-expansion of a strip in one wave, behind the exact
+// filter -- with the FILTER in a lane <-> strip COLUMN layout and the rare DP fed from the staged slab.
+//
+// Filter (lane c owns the five cells of strip column c): the set U is five 64-bit scalars, one per strip row, bit c =
+// column c.  "Is my neighbour (r + dr, c + dc) in U" is bit c of U[r + dr] shifted by dc: ten scalar shifts per sweep
+// instead of a funnel shift, an AND with a row pattern and a pass-boundary fix-up per (pass, direction) -- a sweep is
+// ~110 instructions where the cell-order layout of strip_multi_kernel needs ~300.  Sweeps are Jacobi (five independent
+// chains per wave).  A label that occurs nowhere in the strip's rectangle (most labels: a 64-bit presence mask formed at
+// staging) needs no neighbour-label compare at all, and its first sweep is the compare of the single-site cost with a
+// label-independent cap.  The label's unary terms are 5 row loads per wave, contiguous in orientation 0.
+// Flagged (label, U) pairs wait in a small LDS buffer; then the wave turns to the DP in cell order (lane <-> cell
+// t = 64 p + lane as before): records straight from the slab (which the filter never overwrites), only for the passes
+// the window touches, tables built and walked in chunks of 18 cells (2.6 KB instead of a 9.2 KB slab per pass).
+// The order of events is that of strip_multi_kernel: labels ascending, and after a move on the strip everything later
+// is filtered again on the new labels -- so the launch still equals the single-label passes of the move model.
+// the staged rectangle of strip_cols_kernel: the four forward weights of the cells of rows -1 .. 4 plus the one weight of the
+// bottom rim row that the strip needs (orientation 1: the edge to strip row 4 of the next column): 24 + 1 words per column
+// (odd stride: lane <-> column reads are conflict-free), and one label byte per cell of all seven rows: 7 KB where the
+// 20-byte records of strip_kernel take 9.1
+constexpr int SWC = 25;                      // words per column in the weight slab
+constexpr int SLABW = (63 + 2) * SWC;        // floats
+constexpr int SLABL = ((63 + 2) * EH + 3) / 4 * 4;   // label bytes
+constexpr int CH = 18;                       // cells per table chunk: three groups of six DP steps
+constexpr int NBUF = 8;                      // flagged labels buffered before the wave turns to the DP
+
+template <int P, int C, int... TT>
+__device__ __forceinline__ void dp_chunk_steps(float& m, unsigned long long& took, int lane, const char* tabc,
+                                               std::integer_sequence<int, TT...>) {
+  (([&] {
+     constexpr int T = C * CH + TT;
+     if constexpr (T < 64) {
+       constexpr int Q = (4 * P + T) % 6;
+       const float2 tv = *reinterpret_cast<const float2*>(tabc + TT * (TAB * 4) + tab_offset<Q>(state_of_lane(lane)));
+       unsigned long long dec;
+       dp_step<Q>(m, took, tv.x, tv.y, &dec);
+     }
+   }()),
+   ...);
+}
+
+template <int P, int C, int... TT>
+__device__ __forceinline__ void dp_chunk_steps_rec(float& m, unsigned long long& took, int lane, const char* tabc,
+                                                   unsigned int& dlo, unsigned int& dhi, std::integer_sequence<int, TT...>) {
+  (([&] {
+     constexpr int T = C * CH + TT;
+     if constexpr (T < 64) {
+       constexpr int Q = (4 * P + T) % 6;
+       const float2 tv = *reinterpret_cast<const float2*>(tabc + TT * (TAB * 4) + tab_offset<Q>(state_of_lane(lane)));
+       unsigned long long dec;
+       dp_step<Q>(m, took, tv.x, tv.y, &dec);
+       write_lane(dlo, (unsigned int)(dec & 0xffffffffull), T);
+       write_lane(dhi, (unsigned int)(dec >> 32), T);
+     }
+   }()),
+   ...);
+}
+
+// chunk C of pass P: the chunk's cells build their tables (lanes C*18 .. C*18+17 hold their records), then every state
+// walks them.  [t_lo, t_end] is wave-uniform and aligned to chunks.
+template <int P, int C, bool RECORD>
+__device__ __forceinline__ void dp_chunk(float& m, unsigned long long& took, int lane, float* tabch, float c0, float c1,
+                                         float wu, float wlu, float wl, float wld, int bits, int t_lo, int t_end,
+                                         unsigned int& dlo, unsigned int& dhi) {
+  constexpr int T0 = C * CH, T1 = (T0 + CH - 1 < 63) ? T0 + CH - 1 : 63;
+  if (P * 64 + T0 > t_end || P * 64 + T1 < t_lo) return;
+  if (lane >= T0 && lane <= T1) build_table(tabch, lane - T0, c0, c1, wu, wlu, wl, wld, bits);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const char* tabc = reinterpret_cast<const char*>(tabch);
+  if (RECORD) dp_chunk_steps_rec<P, C>(m, took, lane, tabc, dlo, dhi, std::make_integer_sequence<int, CH>{});
+  else dp_chunk_steps<P, C>(m, took, lane, tabc, std::make_integer_sequence<int, CH>{});
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int P, bool RECORD>
+__device__ __forceinline__ void dp_pass_chunked(float& m, unsigned long long& took, int lane, float* tabch, float c0, float c1,
+                                                float wu, float wlu, float wl, float wld, int bits, int t_lo, int t_end,
+                                                unsigned int& dlo, unsigned int& dhi) {
+  if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
+  dp_chunk<P, 0, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
+  dp_chunk<P, 1, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
+  dp_chunk<P, 2, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
+  dp_chunk<P, 3, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
+}
+
+// cell record of the DP for cell t of the strip, straight from the staged slab (strip_kernel's step B with a constant
+// proposal alpha and the cells outside U pinned)
+template <int ORIENT>
+__device__ __forceinline__ void slab_record(const float* slabw, const unsigned char* slabl, int t, int ncols, int ncell, int alpha, bool in_u, float u0,
+                                            float u1, bool have, float& c0, float& c1, float (&w4)[4], int& bits) {
+  c0 = 0.f;
+  c1 = BIG;
+  w4[0] = w4[1] = w4[2] = w4[3] = 0.f;
+  bits = 0;
+  if (!have) return;
+  const int cc = t / SH, rr = t - cc * SH;
+  const int e0 = (cc + 1) * EH + (rr + 1), w0 = (cc + 1) * SWC + (rr + 1) * 4;
+  const int l = slabl[e0];
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    const int dr = DR[d], dc = DC[d];
+    const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;
+    const bool fwd = di > 0 || (di == 0 && dj > 0);
+    const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
+    const int en = e0 + dc * EH + dr, wn = w0 + dc * SWC + dr * 4;
+    // (a backward neighbour in the bottom rim row -- orientation 1, left-down -- keeps its one needed weight in word 24)
+    const int wb = (ORIENT == 1 && dr > 0 && !fwd) ? wn + comp - (rr == SH - 1 ? 1 : 0) : wn + comp;
+    const float w = fwd ? slabw[w0 + comp] : slabw[wb];
+    const int lj = slabl[en];
+    const int r2 = rr + dr, c2 = cc + dc;
+    const bool inside = r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols;
+    constexpr int QOF[8] = {1, 0, -1, 2, -1, 3, -1, -1};
+    if (QOF[d] >= 0 && inside) {
+      w4[QOF[d] >= 0 ? QOF[d] : 0] = w;
+      const int nib = (l != lj ? 1 : 0) | (l != alpha ? 2 : 0) | (alpha != lj ? 4 : 0);
+      bits |= nib << (4 * (QOF[d] >= 0 ? QOF[d] : 0));
+    }
+    if (!inside) {
+      if (l != lj) a0 += w;
+      if (alpha != lj) a1 += w;
+    }
+  }
+  const bool can = in_u && l != alpha && u1 < 1.0e29f;
+  c0 = u0 + a0;
+  c1 = can ? u1 + a1 : BIG;
+}
+
+// The DP of ONE flagged label on the wave's strip, lane <-> cell t = 64 p + lane (column-major), cells outside U pinned;
+// everything it needs is in LDS (the staged slab, U as five row words).  Returns the number of cells it moved.
+#ifndef PHMRF_DP_INLINE
+#define PHMRF_DP_INLINE __noinline__
+#endif
+template <int ORIENT>
+__device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const float* slabw, const unsigned char* slabl, float* tabch, const unsigned long long* ub,
+                                                   int rs0, int ca, int ncols, int ncell, int alpha, int tick_a, int64_t n, int D,
+                                                   const int32_t* __restrict__ nbr, const float* __restrict__ uT,
+                                                   uint8_t* __restrict__ labels, uint16_t* __restrict__ stamp, uint16_t* mrow,
+                                                   unsigned long long* __restrict__ changed, unsigned int* wk) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long Ut[NPASS];
+    bool inu[NPASS];
+    int t_lo = NCELL_MAX, t_hi = -1;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      int t = p * 64 + lane;
+      asm volatile("" : "+v"(t));
+      const int cc = t / SH, rr = t - cc * SH;
+      const unsigned long long ur = ub[rr];
+      inu[p] = t < ncell && ((ur >> cc) & 1ull);
+      Ut[p] = __ballot(inu[p]);
+      if (Ut[p]) {
+        const int first = p * 64 + __ffsll((long long)Ut[p]) - 1;
+        const int last = p * 64 + 63 - __clzll((long long)Ut[p]);
+        t_lo = first < t_lo ? first : t_lo;
+        t_hi = last > t_hi ? last : t_hi;
+      }
+    }
+    if (t_hi < 0) {
+      if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+      return 0u;
+    }
+    int t_end = t_hi + SH + 1;
+    if (t_end > NPASS * 64 - 1) t_end = NPASS * 64 - 1;
+    {   // widen to whole table chunks
+      const int pe = t_end >> 6, re = t_end & 63;
+      int r1 = (re / CH) * CH + CH - 1;
+      if (r1 > 63) r1 = 63;
+      t_end = pe * 64 + r1;
+      const int pl = t_lo >> 6, rl = t_lo & 63;
+      t_lo = pl * 64 + (rl / CH) * CH;
+    }
+#ifndef PHMRF_PHASE_CLOCK
+    if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
+#endif
+    // the unary terms of the passes the window touches (own label, alpha): all loads in flight together.  The records
+    // themselves are formed pass by pass, right in front of the pass's table chunks: seven live registers, not 35.
+    float ru0[NPASS], ru1[NPASS];
+    unsigned int havem = 0u;                      // bit p: my cell of pass p is a node; bit 8 + p: ... and in U
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      ru0[p] = 0.f; ru1[p] = BIG;
+      if (p * 64 > t_end || p * 64 + 63 < t_lo) continue;
+      int t = p * 64 + lane;
+      asm volatile("" : "+v"(t));
+      const int cc = t / SH, rr = t - cc * SH;
+      const int nd = t < ncell ? strip_node(g, rs0 + rr, ca + cc) : -1;
+      const int e0 = (cc + 1) * EH + (rr + 1);
+      const int l = nd >= 0 ? (int)slabl[e0] : 0;
+      ru0[p] = uT[(int64_t)l * n + (nd >= 0 ? nd : 0)];
+      ru1[p] = (uT + (int64_t)alpha * n)[nd >= 0 ? nd : 0];
+      havem |= (nd >= 0 ? 1u : 0u) << p;
+      havem |= (inu[p] ? 1u : 0u) << (8 + p);
+    }
+#define PHMRF_DP_PASS(P_, REC_)                                                                                          \
+  if (!(P_ * 64 > t_end || P_ * 64 + 63 < t_lo)) {                                                                     \
+    int t = P_ * 64 + lane;                                                                                            \
+    asm volatile("" : "+v"(t));                                                                                        \
+    float w4[4], c0, c1;                                                                                               \
+    int bits;                                                                                                          \
+    slab_record<ORIENT>(slabw, slabl, t, ncols, ncell, alpha, (havem >> (8 + P_)) & 1u, ru0[P_], ru1[P_], (havem >> P_) & 1u,   \
+                        c0, c1, w4, bits);                                                                             \
+    dp_pass_chunked<P_, REC_>(m, took, lane, tabch, c0, c1, w4[0], w4[1], w4[2], w4[3], bits, t_lo, t_end, dlo[P_],     \
+                              dhi[P_]);                                                                                \
+  }
+
+    float m = lane == 0 ? 0.f : BIG;
+    unsigned long long took = 0ull;
+    unsigned int dlo[NPASS], dhi[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) dlo[p] = dhi[p] = 0u;
+    PHMRF_DP_PASS(0, false) PHMRF_DP_PASS(1, false) PHMRF_DP_PASS(2, false) PHMRF_DP_PASS(3, false) PHMRF_DP_PASS(4, false)
+    const float mmin = wave_min_f32(m);
+    if (!(took & 1ull) && PHMRF_RL(m, 0) == mmin) {
+      if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+      return 0u;
+    }
+    // a move exists: walk again, this time recording the decision ballots
+    const int q_end = t_end % 6;
+    int sidx = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sidx |= ((state_of_lane(lane) >> ((q_end - j + 6) % 6)) & 1) << j;
+    m = lane == 0 ? 0.f : BIG;
+    PHMRF_DP_PASS(0, true) PHMRF_DP_PASS(1, true) PHMRF_DP_PASS(2, true) PHMRF_DP_PASS(3, true) PHMRF_DP_PASS(4, true)
+#undef PHMRF_DP_PASS
+    const float mmin2 = wave_min_f32(m);
+    const float cand = (m == mmin2) ? (float)sidx : 127.f;
+    const float best = wave_min_f32(cand);
+    int s = state_of_lane(__ffsll((long long)__ballot(cand == best)) - 1);
+    unsigned int xsel[NPASS];
+    s = __builtin_amdgcn_readfirstlane(s);
+    backtrack_pass<4>(s, t_lo, t_end, dlo[4], dhi[4], xsel[4]);
+    backtrack_pass<3>(s, t_lo, t_end, dlo[3], dhi[3], xsel[3]);
+    backtrack_pass<2>(s, t_lo, t_end, dlo[2], dhi[2], xsel[2]);
+    backtrack_pass<1>(s, t_lo, t_end, dlo[1], dhi[1], xsel[1]);
+    backtrack_pass<0>(s, t_lo, t_end, dlo[0], dhi[0], xsel[0]);
+
+    __builtin_amdgcn_wave_barrier();
+    unsigned int my_changed = 0;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int t = p * 64 + lane;
+      if (xsel[p] && t < ncell) {
+        const int cc = t / SH, rr = t - cc * SH;
+        const int node = strip_node(g, rs0 + rr, ca + cc);
+        if (node >= 0) {
+          labels[node] = (uint8_t)alpha;
+          if (stamp) {
+            stamp[node] = (uint16_t)tick_a;
+            const int32_t* nb2 = nbr + (int64_t)node * D;
+            for (int j = 0; j < D; ++j)
+              if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick_a;
+          }
+          ++my_changed;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_changed += __shfl_xor(my_changed, off, 64);
+    if (lane == 0) {
+      if (my_changed) atomicAdd(changed + alpha, (unsigned long long)my_changed);
+      if (mrow) mrow[alpha] = my_changed ? (uint16_t)0 : (uint16_t)tick_a;
+    }
+    return my_changed;
+}
+
+// The filter over the labels of `todo` on the wave's staged strip, lane <-> strip column.  Quiet labels get their memo
+// entry; flagged ones go to ubuf / abuf (at most NBUF, then the caller turns to the DP).  Returns the labels not looked at
+// yet; *nbuf_out (LDS) = how many are flagged.  Out of line: its ~80 registers of per-cell state and the DP's tables must
+// not share one register allocation (inlined, the compiler kept them alive across each other and spilled 100+ VGPRs).
+#ifndef PHMRF_FILTER_INLINE
+#define PHMRF_FILTER_INLINE __noinline__
+#endif
+template <int ORIENT>
+__device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, const float* slabw, const unsigned char* slabl, unsigned long long (*ubuf)[SH], int* abuf,
+                                                             int* nbuf_out, int rs0_, int ca_, int ncols_, int ncell_,
+                                                             unsigned long long v0_, unsigned long long v1_, unsigned long long v2_,
+                                                             unsigned long long v3_, unsigned long long v4_, unsigned long long todo_,
+                                                             int64_t n, const float* __restrict__ uT, uint16_t* mrow, int tick0_,
+                                                             int peel_max_, unsigned int* wk) {
+    const int lane = threadIdx.x & 63;
+#define PHMRF_UNI64(x) (((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)((x) >> 32)) << 32) | \
+                        (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(x)))
+    // (arguments arrive in vector registers; everything here is wave-uniform)
+    const int rs0 = __builtin_amdgcn_readfirstlane(rs0_), ca = __builtin_amdgcn_readfirstlane(ca_);
+    const int ncols = __builtin_amdgcn_readfirstlane(ncols_), ncell = __builtin_amdgcn_readfirstlane(ncell_);
+    const int tick0 = __builtin_amdgcn_readfirstlane(tick0_), peel_max = __builtin_amdgcn_readfirstlane(peel_max_);
+    g.H = __builtin_amdgcn_readfirstlane(g.H); g.W = __builtin_amdgcn_readfirstlane(g.W);
+    g.diagonal = __builtin_amdgcn_readfirstlane(g.diagonal); g.orient = __builtin_amdgcn_readfirstlane(g.orient);
+    g.Hs = __builtin_amdgcn_readfirstlane(g.Hs); g.Ws = __builtin_amdgcn_readfirstlane(g.Ws);
+    unsigned long long valid[SH] = {PHMRF_UNI64(v0_), PHMRF_UNI64(v1_), PHMRF_UNI64(v2_), PHMRF_UNI64(v3_), PHMRF_UNI64(v4_)};
+    unsigned long long todo = PHMRF_UNI64(todo_);
+#undef PHMRF_UNI64
+#ifdef PHMRF_PHASE_CLOCK
+    // development build: cycles of the extraction (slot 1), the single-site costs (3), the sweeps (5 is the DP: the
+    // caller's), sweeps run (0)
+    unsigned int fpc[4] = {0u, 0u, 0u, 0u};
+    unsigned long long fpt = __builtin_amdgcn_s_memtime();
+#define FPH(K_)                                                           \
+  {                                                                       \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();          \
+    fpc[K_] += (unsigned int)(tn_ - fpt);                                 \
+    fpt = tn_;                                                            \
+  }
+#else
+#define FPH(K_)
+#endif
+    // ---- extraction, lane <-> column: per cell the eight neighbour terms  v8 = w (2 - [l != l_d])  (= the discount
+    //      of an in-strip edge; a neighbour labelled alpha differs from l, so the same register is the plain weight
+    //      the single-site cost needs), the neighbour labels, the own-label unary term, the weight sum of the
+    //      neighbours that share the label, and the cap over ALL in-strip neighbours (first sweep of absent labels)
+    float v8[SH][8];
+    unsigned int laba[SH], labb[SH];
+    int ownl[SH];
+    float ucur[SH], hs[SH], capf[SH];
+    unsigned long long pres;
+    int ndx[SH];                 // my column's nodes (absent cells: node 0, whose value is never used)
+    {
+      // (the column index through an opaque copy: otherwise the compiler keeps the whole extracted state in registers
+      //  across the DP phase, to save the re-extraction on the path where the slab was not restaged -- and spills it)
+      int lc = lane;
+      asm volatile("" : "+v"(lc));
+      const bool act = lc < ncols;
+      unsigned long long pm = 0ull;
+#pragma unroll
+      for (int r = 0; r < SH; ++r) {
+        const int e0 = (lc + 1) * EH + (r + 1);
+        const bool have = (valid[r] >> lc) & 1ull;
+        ownl[r] = have ? (int)slabl[act ? e0 : 0] : 0;
+        ndx[r] = have ? strip_node(g, rs0 + r, ca + lc) : 0;
+        ucur[r] = uT[(int64_t)ownl[r] * n + ndx[r]];
+      }
+#pragma unroll
+      for (int r = 0; r < SH; ++r) {
+        const bool have = (valid[r] >> lc) & 1ull;
+        unsigned int la = 0u, lb = 0u;
+        float h = 0.f, cf = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) v8[r][d] = 0.f;
+        if (have) {
+          const int e0 = (lc + 1) * EH + (r + 1), w0 = (lc + 1) * SWC + (r + 1) * 4;
+          const int l = ownl[r];
+          pm |= 1ull << (l & 63);
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+            constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+            const int dr = DR[d], dc = DC[d];
+            const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;
+            const bool fwd = di > 0 || (di == 0 && dj > 0);
+            const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
+            const int en = e0 + dc * EH + dr, wn = w0 + dc * SWC + dr * 4;
+            const int wb = (ORIENT == 1 && dr > 0 && !fwd && r == SH - 1) ? wn + comp - 1 : wn + comp;
+            const float w = fwd ? slabw[w0 + comp] : slabw[wb];
+            const int lj = slabl[en];
+            const bool inside = (r + dr >= 0) && (r + dr < SH) && (lc + dc >= 0) && (lc + dc < ncols);
+            const bool eq = lj == l;
+            h += eq ? w : 0.f;
+            const float v = eq ? w + w : w;
+            v8[r][d] = v;
+            cf += inside ? v : 0.f;
+            pm |= 1ull << (lj & 63);
+            if (d < 4) la |= (unsigned int)lj << (8 * d);
+            else lb |= (unsigned int)lj << (8 * (d - 4));
+          }
+        }
+        laba[r] = la; labb[r] = lb; hs[r] = h;
+        capf[r] = __builtin_fmaf(cf, 1.0001f, 1e-6f);
+        __builtin_amdgcn_sched_barrier(0);       // keep the rows apart: interleaving their LDS reads only costs registers
+      }
+      unsigned int p0 = (unsigned int)pm, p1 = (unsigned int)(pm >> 32);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        p0 |= (unsigned int)__shfl_xor((int)p0, off, 64);
+        p1 |= (unsigned int)__shfl_xor((int)p1, off, 64);
+      }
+      pres = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)p1) << 32) |
+             (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)p0);
+    }
+    
+    FPH(0)
+    // ---- the filter over the labels still to do; flagged ones wait in ubuf
+        int nbuf = 0;
+    float u1[SH];
+    int alpha_cur = __ffsll((long long)todo) - 1;
+    {
+      const float* plane = uT + (int64_t)alpha_cur * n;
+#pragma unroll
+      for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
+    }
+    while (todo && nbuf < NBUF) {
+      const int alpha = alpha_cur;
+      todo &= todo - 1ull;
+      if (lane == 0) {
+        atomicAdd(&wk[0], 1u);
+#ifndef PHMRF_PHASE_CLOCK
+        atomicAdd(&wk[5], (unsigned int)ncell);
+#endif
+      }
+      const bool present = (pres >> alpha) & 1ull;
+      float sc[SH];
+      unsigned long long U[SH];
+#pragma unroll
+      for (int r = 0; r < SH; ++r) {
+        float hist = 0.f;
+        bool ne = true;
+        if (present) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            const int lj = (int)(((d < 4 ? laba[r] : labb[r]) >> (8 * (d & 3))) & 255u);
+            hist += lj == alpha ? v8[r][d] : 0.f;
+          }
+          ne = ownl[r] != alpha;
+        }
+        sc[r] = (u1[r] - ucur[r]) + (hs[r] - hist);
+        // (a cell whose unary term for alpha is "infinite" -- no proposal -- fails the first keep test; the DP tests it itself)
+        U[r] = present ? (valid[r] & __ballot(ne)) : valid[r];
+      }
+        FPH(1)
+      if (todo) {                                  // the next label's terms, in flight during the sweeps
+        alpha_cur = __ffsll((long long)todo) - 1;
+        const float* plane = uT + (int64_t)alpha_cur * n;
+#pragma unroll
+        for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
+      }
+      bool quiet = false;
+      FPH(3)
+      for (int it = 0; it < peel_max; ++it) {
+#ifdef PHMRF_PHASE_CLOCK
+        if (!(it == 0 && !present) && lane == 0) atomicAdd(&wk[0], 1u << 12);     // general sweeps, in units of 4096 next to the pair count
+#endif
+        unsigned long long nu[SH];
+        unsigned long long seeds = 0ull;
+        if (it == 0 && !present) {
+          // no cell or neighbour of the rectangle carries alpha: U is every node, the cap of the first sweep is the
+          // label-independent sum over all in-strip neighbours
+#pragma unroll
+          for (int r = 0; r < SH; ++r) {
+            const unsigned long long keep = __ballot(sc[r] <= capf[r]);
+            const unsigned long long sd = __ballot(sc[r] < 0.5f * capf[r]);
+            nu[r] = U[r] & keep;
+            seeds |= nu[r] & sd;
+          }
+        } else {
+          // One basic block, five independent chains: the membership of the three columns c - 1, c, c + 1 of every row
+          // as 0 / 1 floats (15 selects), then cap_r = sum_d  fm[r + dr][dc] * v8[r][d]  as fused multiply-adds -- the
+          // product with 0 or 1 is exact, so this is the masked sum, at one vector instruction per term instead of two.
+          float fm[SH][3];
+#pragma unroll
+          for (int r = 0; r < SH; ++r) {
+            fm[r][0] = __builtin_amdgcn_inverse_ballot_w64(U[r] << 1) ? 1.f : 0.f;      // column c - 1 is in U
+            fm[r][1] = __builtin_amdgcn_inverse_ballot_w64(U[r]) ? 1.f : 0.f;
+            fm[r][2] = __builtin_amdgcn_inverse_ballot_w64(U[r] >> 1) ? 1.f : 0.f;      // column c + 1 is in U
+          }
+#pragma unroll
+          for (int r = 0; r < SH; ++r) {
+            float cap = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+              constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+              constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+              const int rr = r + DR[d];
+              if (rr < 0 || rr >= SH) continue;
+              const int rc = rr < 0 ? 0 : (rr >= SH ? SH - 1 : rr);
+              cap = __builtin_fmaf(fm[rc][DC[d] + 1], v8[r][d], cap);
+            }
+            const float capx = __builtin_fmaf(cap, 1.0001f, 1e-6f);
+            const unsigned long long keep = __ballot(sc[r] <= capx);
+            const unsigned long long sd = __ballot(sc[r] < 0.5f * capx);
+            nu[r] = U[r] & keep;
+            seeds |= nu[r] & sd;
+          }
+        }
+        bool shrunk = false;
+#pragma unroll
+        for (int r = 0; r < SH; ++r) {
+          shrunk = shrunk || nu[r] != U[r];
+          U[r] = nu[r];
+        }
+        if (!seeds) {
+          quiet = true;
+          break;
+        }
+        if (!shrunk) break;
+      }
+      FPH(2)
+      if (quiet) {
+        if (mrow && lane == 0) mrow[alpha] = (uint16_t)(tick0 + alpha);
+        continue;
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < SH; ++r) ubuf[nbuf][r] = U[r];
+        abuf[nbuf] = alpha;
+      }
+      ++nbuf;
+    }
+#ifdef PHMRF_PHASE_CLOCK
+    if (lane == 0) {
+      atomicAdd(&wk[1], fpc[0] >> 4);      // extraction
+      atomicAdd(&wk[3], fpc[1] >> 4);      // single-site costs
+      atomicAdd(&wk[5], (fpc[2] + fpc[3]) >> 4);      // sweeps (+ prefetch issue)
+    }
+#endif
+#undef FPH
+    if (lane == 0) *nbuf_out = nbuf;
+    return todo;
+}
+
+#ifndef PHMRF_COLS_WPE
+#define PHMRF_COLS_WPE 4
+#endif
+template <int ORIENT>
+__global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeom g, int64_t n, int K, int D,
+                                                                         const int32_t* __restrict__ nbr,
+                                                                         const float4* __restrict__ fwd_w,
+                                                                         const float* __restrict__ uT, uint8_t* __restrict__ labels,
+                                                                         float beta, unsigned long long label_mask,
+                                                                         unsigned long long* __restrict__ changed,
+                                                                         uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
+                                                                         int tick0, unsigned long long* __restrict__ work, int peel_max) {
+  __shared__ __attribute__((aligned(16))) float slabw[SLABW];               // the staged rectangle (7 KB), never overwritten:
+  __shared__ __attribute__((aligned(4))) unsigned char slabl[SLABL];        //   forward weights, label bytes
+  __shared__ __attribute__((aligned(16))) float tabch[CH * TAB];            // DP tables of one chunk (2.6 KB)
+  __shared__ unsigned long long ubuf[NBUF][SH];                             // U of the flagged labels, one word per strip row
+  __shared__ int abuf[NBUF];                                                // ... and which labels they are
+  __shared__ int nbuf_s;
+#ifdef PHMRF_COLS_LDS_PAD        // development: occupancy experiments
+  __shared__ volatile float lds_pad[PHMRF_COLS_LDS_PAD / 4];
+  lds_pad[(threadIdx.x * 61) % (PHMRF_COLS_LDS_PAD / 4)] = 1.f;
+#endif
+  __shared__ unsigned int wk[WORK_SLOTS];
+  const int lane = threadIdx.x & 63;
+  const int nstrips = g.nbands * g.nsegs;
+  if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
+  __syncthreads();
+#ifdef PHMRF_PHASE_CLOCK
+  unsigned int phc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned long long pht = __builtin_amdgcn_s_memtime();
+#define PH(K_)                                                            \
+  {                                                                       \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();          \
+    phc[K_] += (unsigned int)(tn_ - pht);                                 \
+    pht = tn_;                                                            \
+  }
+#else
+#define PH(K_)
+#endif
+
+  for (int strip_v = blockIdx.x; strip_v < nstrips; strip_v += gridDim.x) {
+    const int strip = __builtin_amdgcn_readfirstlane(strip_v);
+    const int bnd = strip / g.nsegs;
+    const int seg = strip - bnd * g.nsegs;
+    const int rs0 = bnd * (SH + 1) - g.shift_r;
+    const int cs0 = seg * 64 - g.shift_c;
+    const int ca = cs0 > 0 ? cs0 : 0;
+    const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
+    const int ncols = cb > ca ? cb - ca : 0;
+    const int ncell = ncols * SH;
+    if (ncell <= 0) continue;
+    PH(1)
+
+    // ---- column layout: lane c <-> strip column c; the node of row r is nodec[r] (-1: none)
+    unsigned long long valid[SH];
+    unsigned long long todo = label_mask;
+    uint16_t* mrow = memo ? memo + (int64_t)strip * (K + 1) : nullptr;
+    {
+      int nw = 0;
+      int nd[SH];
+#pragma unroll
+      for (int r = 0; r < SH; ++r) nd[r] = lane < ncols ? strip_node(g, rs0 + r, ca + lane) : -1;
+      if (mrow) {
+#pragma unroll
+        for (int r = 0; r < SH; ++r) {
+          const int st = stamp[nd[r] >= 0 ? nd[r] : 0];
+          nw = (nd[r] >= 0 && st > nw) ? st : nw;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const int o2 = __shfl_xor(nw, off, 64);
+          nw = o2 > nw ? o2 : nw;
+        }
+        const int lq = lane < K ? (int)mrow[lane] : 0;
+        todo &= __ballot(lane < K && !(lq && nw < lq));
+      }
+#pragma unroll
+      for (int r = 0; r < SH; ++r) valid[r] = __ballot(nd[r] >= 0);
+    }
+    todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
+           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
+    if (!todo) continue;
+    bool staged = false;
+
+    while (todo) {
+      if (!staged) {
+        // ---- staging (as strip_kernel, step A): labels and forward weights of the strip's rectangle and rim -> LDS
+        constexpr int NEP = (ECELLS + 63) / 64;
+        int enode[NEP], eidx[NEP];
+#pragma unroll
+        for (int q = 0; q < NEP; ++q) {
+          int er, ec;
+          if (ORIENT == 0) {
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));
+            er = q < EH ? q : l2;
+            ec = q < EH ? l2 : 64;
+            if (q >= EH && l2 >= EH) ec = 1 << 20;
+          } else {
+            int e = q * 64 + lane;
+            asm volatile("" : "+v"(e));
+            ec = e / EH;
+            er = e - ec * EH;
+          }
+          const bool have = ec < ncols + 2;
+          eidx[q] = have ? ec * EH + er : -1;
+          enode[q] = have ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
+        }
+        int elab[NEP];
+        float4 ef[NEP];
+#pragma unroll
+        for (int q = 0; q < NEP; ++q) {
+          const int node = enode[q];
+          elab[q] = 0;
+          ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (node >= 0) {
+            elab[q] = labels[node];
+            ef[q] = fwd_w[node];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NEP; ++q) {
+          const int e = eidx[q];
+          if (e >= 0) {
+            const int ec = e / EH, er = e - ec * EH;
+            float* wr = slabw + ec * SWC + er * 4;
+            if (er < EH - 1) {
+              wr[0] = ef[q].x * beta;
+              wr[1] = ef[q].y * beta;
+              wr[2] = ef[q].z * beta;
+              wr[3] = ef[q].w * beta;
+            } else {
+              // the bottom rim row holds one edge the strip needs, and only in orientation 1: its cells' grid edge (+1, -1),
+              // which runs to strip row 4 of the next column; it lives in the column's 25th word
+              wr[0] = ef[q].y * beta;
+            }
+            slabl[e] = (unsigned char)(enode[q] >= 0 ? elab[q] : 0);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+#ifndef PHMRF_PHASE_CLOCK
+          atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
+          atomicAdd(&wk[4], (unsigned int)ncell);
+#endif
+        }
+        staged = true;
+      }
+
+      PH(2)
+      const unsigned long long todo_in = todo;       // (after a move every later label of this set is filtered again)
+      todo = filter_phase<ORIENT>(g, slabw, slabl, ubuf, abuf, &nbuf_s, rs0, ca, ncols, ncell, valid[0], valid[1], valid[2], valid[3], valid[4],
+                                  todo, n, uT, mrow, tick0, peel_max, wk);
+      todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
+             (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
+      PH(0)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      // ---- the DP of the flagged labels, lane <-> cell t = 64 p + lane (column-major), cells outside U pinned
+      const int nbuf = __builtin_amdgcn_readfirstlane(nbuf_s);
+#ifdef PHMRF_COLS_NO_DP
+      nbuf = 0;
+#endif
+      for (int kb = 0; kb < nbuf; ++kb) {
+        const int alpha = __builtin_amdgcn_readfirstlane(abuf[kb]);
+        const unsigned int my_changed = dp_flagged<ORIENT>(g, slabw, slabl, tabch, ubuf[kb], rs0, ca, ncols, ncell, alpha, tick0 + alpha, n, D,
+                                                           nbr, uT, labels, stamp, mrow, changed, wk);
+        PH(4)
+        if (my_changed) {
+          // the labels of this strip have changed: everything later is filtered again on the new labelling
+          __threadfence();
+          staged = false;
+          todo = todo_in & ~((2ull << alpha) - 1ull);
+          break;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#ifdef PHMRF_PHASE_CLOCK
+  // slots: 0 pairs + 4096 x general sweeps, 1 extraction, 2 ids/memo/staging, 3 single-site costs, 4 DP, 5 sweeps
+  if (lane == 0) {
+    wk[2] += (phc[1] + phc[2]) >> 4;
+    wk[4] += phc[4] >> 4;
+  }
+#endif
+#undef PH
+  __syncthreads();
+  if (work && threadIdx.x < WORK_SLOTS) {
+    const unsigned int v = wk[threadIdx.x];
+    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + threadIdx.x, (unsigned long long)v);
+  }
+}
+
 // uT[k][i] = -logprob[i][k]: one plane per label, so an expansion of label a reads its unary terms contiguously
 __global__ __launch_bounds__(256) void unary_planes_kernel(const float* __restrict__ logprob, int64_t n, int K, int Kp,
                                                            float* __restrict__ uT) {
@@ -1270,6 +1980,15 @@ static int peel_sweeps() {   // PHMRF_PEEL_SWEEPS=0 switches the filter off (tim
   return v;
 }
 
+static int multi_version() {   // PHMRF_MULTI_V=1: strip_multi_kernel (round 2) instead of strip_cols_kernel
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PHMRF_MULTI_V");
+    v = e ? atoi(e) : 2;
+  }
+  return v;
+}
+
 static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int shift_c) {
   StripGeom g;
   g.H = b->H;
@@ -1339,13 +2058,18 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
   // uneven strips better than waves striding over them (measured against a cap of 8 resident sets: -3 % on the rows cut)
   if (grid > (1 << 22)) grid = 1 << 22;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
-#define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
-  hipLaunchKernelGGL((strip_multi_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
+#define PHMRF_LAUNCH_MULTI(KERN_, O_)                                                                                 \
+  hipLaunchKernelGGL((KERN_<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,           \
                      b->uT, b->labels, beta, label_mask, b->counters + 8, b->tick ? b->stamp : nullptr,               \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
                      b->tick, b->work_acc, peel_sweeps())
-  if (orient) PHMRF_LAUNCH_MULTI(1);
-  else PHMRF_LAUNCH_MULTI(0);
+  if (multi_version() == 1) {          // development: the round-2 kernel (cell-order filter), for A/B timing
+    if (orient) PHMRF_LAUNCH_MULTI(strip_multi_kernel, 1);
+    else PHMRF_LAUNCH_MULTI(strip_multi_kernel, 0);
+  } else {
+    if (orient) PHMRF_LAUNCH_MULTI(strip_cols_kernel, 1);
+    else PHMRF_LAUNCH_MULTI(strip_cols_kernel, 0);
+  }
 #undef PHMRF_LAUNCH_MULTI
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
