@@ -41,6 +41,27 @@ __device__ __forceinline__ int strip_node(const StripGeom& g, int sr, int sc) {
   return i * g.W + j;
 }
 
+// lane of the wavefront (workgroups are whole waves here), without threadIdx: inside an out-of-line device function the
+// work-item id is a library call
+__device__ __forceinline__ int wave_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// an LDS object from its 32-bit LDS address: pointers handed to an out-of-line function arrive as generic pointers and
+// every access through them is a flat_load / flat_store (slow, and it waits on both counters); through the address-space
+// cast the compiler recovers ds_read / ds_write
+template <class T>
+__device__ __forceinline__ T* lds_object(unsigned int lds_address) {
+  return (T*)(__attribute__((address_space(3))) T*)(unsigned long)lds_address;
+}
+// ... and a global-memory pointer argument of an out-of-line function as such (global_load instead of flat_load)
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
+template <class T>
+__device__ __forceinline__ unsigned int lds_address_of(T* p) {
+  return (unsigned int)(unsigned long)(__attribute__((address_space(3))) T*)p;
+}
+
 #define PHMRF_DPP_MIN(v, ctrl, rmask)                                                                            \
   v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),                 \
                                                                      __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false)))
@@ -80,10 +101,10 @@ __device__ __forceinline__ float xor_exchange(float v) {
   if (Q == 3) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xf, 0xf, true));   // lane ^ 15
   if (Q == 4) {  // lane ^ 16: odd rows of vdst <-> even rows of vsrc
     auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
-    return __builtin_bit_cast(float, (int)((threadIdx.x & 16) ? r[0] : r[1]));
+    return __builtin_bit_cast(float, (int)((wave_lane() & 16) ? r[0] : r[1]));
   }
   auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);   // lane ^ 32
-  return __builtin_bit_cast(float, (int)((threadIdx.x & 32) ? r[0] : r[1]));
+  return __builtin_bit_cast(float, (int)((wave_lane() & 32) ? r[0] : r[1]));
 }
 
 // ---- per-cell cost tables (LDS, one pass of 64 cells at a time) ---------------------------------------------------
@@ -102,27 +123,37 @@ constexpr int ECELLS = EH * (63 + 2);   // ... times its columns plus the fixed 
 constexpr int SLAB = 64 * TAB;           // floats per wave (9216 B): the tables of one pass; >= the staging area
 static_assert(SLAB >= ECELLS * REC && SLAB % 4 == 0, "LDS slab too small");
 
+// w where bit k of `bits` is set, else 0 (a sign-extended one-bit field as an AND mask: two vector instructions, no compare)
+__device__ __forceinline__ float bit_masked(float w, int bits, int k) {
+  const int m = (int)((unsigned int)bits << (31 - k)) >> 31;
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, w) & m);
+}
+
 __device__ __forceinline__ void build_table(float* tab, int lane, float c0, float c1, float wu, float wlu, float wl,
                                             float wld, int bits) {
   float4* dst = reinterpret_cast<float4*>(tab + lane * TAB);
-  // lu[b][self], lu[b][other]
-  const float lu0s = ((bits >> 4) & 1) ? wlu : 0.f, lu0o = ((bits >> 5) & 1) ? wlu : 0.f;
-  const float lu1s = ((bits >> 7) & 1) ? wlu : 0.f, lu1o = ((bits >> 6) & 1) ? wlu : 0.f;
+  // cost(b, bu, bl, bld) = ((c_b + wu N_u[b][bu]) + wl N_l[b][bl]) + wld N_ld[b][bld], built as a tree over the three
+  // neighbours (2 + 4 + 8 additions per b instead of 3 per combination; the same sums in the same order), then the two
+  // left-up variants lu[b][self], lu[b][other]
 #pragma unroll
-  for (int g2 = 0; g2 < 8; ++g2) {       // two combinations per 16-byte store
-    float v[4];
+  for (int b = 0; b < 2; ++b) {
+    const float cb = b ? c1 : c0;
+    const float lus = bit_masked(wlu, bits, b ? 7 : 4), luo = bit_masked(wlu, bits, b ? 6 : 5);
+    float cA[2], cAB[2][2];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int idx = g2 * 2 + e;
-      const int b = idx >> 3, bu = (idx >> 2) & 1, bl = (idx >> 1) & 1, bld = idx & 1;
-      float x = b ? c1 : c0;
-      if ((bits >> (0 + b * 2 + bu)) & 1) x += wu;
-      if ((bits >> (8 + b * 2 + bl)) & 1) x += wl;
-      if ((bits >> (12 + b * 2 + bld)) & 1) x += wld;
-      v[2 * e] = x + (b ? lu1s : lu0s);
-      v[2 * e + 1] = x + (b ? lu1o : lu0o);
-    }
-    dst[g2] = make_float4(v[0], v[1], v[2], v[3]);
+    for (int bu = 0; bu < 2; ++bu) cA[bu] = cb + bit_masked(wu, bits, 0 + b * 2 + bu);
+#pragma unroll
+    for (int bu = 0; bu < 2; ++bu)
+#pragma unroll
+      for (int bl = 0; bl < 2; ++bl) cAB[bu][bl] = cA[bu] + bit_masked(wl, bits, 8 + b * 2 + bl);
+    const float C0 = bit_masked(wld, bits, 12 + b * 2), C1 = bit_masked(wld, bits, 12 + b * 2 + 1);
+#pragma unroll
+    for (int bu = 0; bu < 2; ++bu)
+#pragma unroll
+      for (int bl = 0; bl < 2; ++bl) {
+        const float x0 = cAB[bu][bl] + C0, x1 = cAB[bu][bl] + C1;      // bld = 0, 1: combinations idx, idx + 1
+        dst[b * 4 + bu * 2 + bl] = make_float4(x0 + lus, x0 + luo, x1 + lus, x1 + luo);
+      }
   }
 }
 
@@ -159,7 +190,7 @@ __device__ __forceinline__ void dp_step(float& m, unsigned long long& took, floa
 
 // one uniform value into one lane of a VGPR as a plain select (v_cmp + v_cndmask, no exec juggling)
 __device__ __forceinline__ void write_lane(unsigned int& dst, unsigned int value, int lane_sel) {
-  dst = ((int)(threadIdx.x & 63) == lane_sel) ? value : dst;
+  dst = (wave_lane() == lane_sel) ? value : dst;
 }
 
 // One step at a compile-time position: the table addresses are a per-lane register plus an immediate offset.
@@ -1125,6 +1156,16 @@ constexpr int SLABW = (63 + 2) * SWC;        // floats
 constexpr int SLABL = ((63 + 2) * EH + 3) / 4 * 4;   // label bytes
 constexpr int CH = 18;                       // cells per table chunk: three groups of six DP steps
 constexpr int NBUF = 8;                      // flagged labels buffered before the wave turns to the DP
+// everything strip_cols_kernel keeps in LDS (one wave per workgroup): 9.9 KB
+struct ColsLds {
+  alignas(16) float tabch[CH * 36];          // DP tables of one chunk (2.6 KB; 36 = TAB)
+  alignas(16) float slabw[SLABW];            // the staged rectangle, never overwritten: forward weights ...
+  unsigned long long ubuf[NBUF][SH];         // U of the flagged labels, one word per strip row
+  int abuf[NBUF];                            // ... and which labels they are
+  unsigned int wk[WORK_SLOTS];
+  int nbuf;
+  unsigned char slabl[SLABL];                // ... and label bytes of the staged rectangle
+};
 
 template <int P, int C, int... TT>
 __device__ __forceinline__ void dp_chunk_steps(float& m, unsigned long long& took, int lane, const char* tabc,
@@ -1160,30 +1201,50 @@ __device__ __forceinline__ void dp_chunk_steps_rec(float& m, unsigned long long&
 
 // chunk C of pass P: the chunk's cells build their tables (lanes C*18 .. C*18+17 hold their records), then every state
 // walks them.  [t_lo, t_end] is wave-uniform and aligned to chunks.
+#ifdef PHMRF_PHASE_DP
+// development build: shader-clock cycles of the DP's sub-phases into the work counters (1 U conversion + unary loads,
+// 2 records, 3 table builds, 4 walks, 5 everything after a move was found)
+#define DPH(K_)                                                              \
+  {                                                                          \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();             \
+    if (wave_lane() == 0) atomicAdd(&dp_wk[K_], (unsigned int)(tn_ - dp_t0) >> 4); \
+    dp_t0 = tn_;                                                             \
+  }
+__device__ unsigned int* dp_wk_dummy;
+#else
+#define DPH(K_)
+#endif
 template <int P, int C, bool RECORD>
 __device__ __forceinline__ void dp_chunk(float& m, unsigned long long& took, int lane, float* tabch, float c0, float c1,
                                          float wu, float wlu, float wl, float wld, int bits, int t_lo, int t_end,
-                                         unsigned int& dlo, unsigned int& dhi) {
+                                         unsigned int& dlo, unsigned int& dhi, unsigned int live, unsigned int* dp_wk,
+                                         unsigned long long& dp_t0) {
   constexpr int T0 = C * CH, T1 = (T0 + CH - 1 < 63) ? T0 + CH - 1 : 63;
   if (P * 64 + T0 > t_end || P * 64 + T1 < t_lo) return;
+  // A chunk none of whose cells, nor the six before it, is in U: every cell it holds is pinned and the profile it starts
+  // from is 000000 in every finite state -- walking it would only add the same constant to the one finite state.
+  if (!((live >> (P * 4 + C)) & 1u)) return;
   if (lane >= T0 && lane <= T1) build_table(tabch, lane - T0, c0, c1, wu, wlu, wl, wld, bits);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  DPH(3)
   const char* tabc = reinterpret_cast<const char*>(tabch);
   if (RECORD) dp_chunk_steps_rec<P, C>(m, took, lane, tabc, dlo, dhi, std::make_integer_sequence<int, CH>{});
   else dp_chunk_steps<P, C>(m, took, lane, tabc, std::make_integer_sequence<int, CH>{});
   __builtin_amdgcn_wave_barrier();
+  DPH(4)
 }
 
 template <int P, bool RECORD>
 __device__ __forceinline__ void dp_pass_chunked(float& m, unsigned long long& took, int lane, float* tabch, float c0, float c1,
                                                 float wu, float wlu, float wl, float wld, int bits, int t_lo, int t_end,
-                                                unsigned int& dlo, unsigned int& dhi) {
+                                                unsigned int& dlo, unsigned int& dhi, unsigned int live, unsigned int* dp_wk,
+                                                unsigned long long& dp_t0) {
   if (P * 64 > t_end || P * 64 + 63 < t_lo) return;
-  dp_chunk<P, 0, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
-  dp_chunk<P, 1, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
-  dp_chunk<P, 2, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
-  dp_chunk<P, 3, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi);
+  dp_chunk<P, 0, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi, live, dp_wk, dp_t0);
+  dp_chunk<P, 1, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi, live, dp_wk, dp_t0);
+  dp_chunk<P, 2, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi, live, dp_wk, dp_t0);
+  dp_chunk<P, 3, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi, live, dp_wk, dp_t0);
 }
 
 // cell record of the DP for cell t of the strip, straight from the staged slab (strip_kernel's step B with a constant
@@ -1237,12 +1298,27 @@ __device__ __forceinline__ void slab_record(const float* slabw, const unsigned c
 #define PHMRF_DP_INLINE __noinline__
 #endif
 template <int ORIENT>
-__device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const float* slabw, const unsigned char* slabl, float* tabch, const unsigned long long* ub,
+__device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds, int kb, int lane,
                                                    int rs0, int ca, int ncols, int ncell, int alpha, int tick_a, int64_t n, int D,
-                                                   const int32_t* __restrict__ nbr, const float* __restrict__ uT,
-                                                   uint8_t* __restrict__ labels, uint16_t* __restrict__ stamp, uint16_t* mrow,
-                                                   unsigned long long* __restrict__ changed, unsigned int* wk) {
-    const int lane = threadIdx.x & 63;
+                                                   const int32_t* nbr_, const float* uT_, uint8_t* labels_, uint16_t* stamp_,
+                                                   uint16_t* mrow_, unsigned long long* changed_) {
+    const int32_t* __restrict__ nbr = as_global(nbr_);
+    const float* __restrict__ uT = as_global(uT_);
+    uint8_t* __restrict__ labels = as_global(labels_);
+    uint16_t* __restrict__ stamp = as_global(stamp_);
+    uint16_t* mrow = as_global(mrow_);
+    unsigned long long* __restrict__ changed = as_global(changed_);
+    ColsLds* L = lds_object<ColsLds>(lds);
+    const float* slabw = L->slabw;
+    const unsigned char* slabl = L->slabl;
+    float* tabch = L->tabch;
+    const unsigned long long* ub = L->ubuf[kb];
+    unsigned int* wk = L->wk;
+    unsigned int* dp_wk = wk;
+    unsigned long long dp_t0 = 0ull;
+#ifdef PHMRF_PHASE_DP
+    dp_t0 = __builtin_amdgcn_s_memtime();
+#endif
     unsigned long long Ut[NPASS];
     bool inu[NPASS];
     int t_lo = NCELL_MAX, t_hi = -1;
@@ -1277,7 +1353,25 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const flo
     }
 #ifndef PHMRF_PHASE_CLOCK
     if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
+#else
+    if (lane == 0) {                     // development build: solver-trace counters (PHMRF_SOLVE_TRACE)
+      atomicAdd(changed - 8 + 100, 1ull);
+      atomicAdd(changed - 8 + 102, 1ull);
+      atomicAdd(changed - 8 + 103, (unsigned long long)(t_end - t_lo + 1));
+    }
 #endif
+    // which table chunks hold, or directly follow, a cell of U (see dp_chunk)
+    unsigned int live = 0u;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int T0 = c * CH, T1 = (T0 + CH - 1 < 63) ? T0 + CH - 1 : 63;
+        const int lo = T0 - SH - 1 > 0 ? T0 - SH - 1 : 0;
+        unsigned long long hit = Ut[p] & ((~0ull >> (63 - T1)) & (~0ull << lo));
+        if (T0 < SH + 1 && p > 0) hit |= Ut[p > 0 ? p - 1 : 0] >> (64 - (SH + 1 - T0));
+        live |= (hit ? 1u : 0u) << (p * 4 + c);
+      }
     // the unary terms of the passes the window touches (own label, alpha): all loads in flight together.  The records
     // themselves are formed pass by pass, right in front of the pass's table chunks: seven live registers, not 35.
     float ru0[NPASS], ru1[NPASS];
@@ -1297,6 +1391,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const flo
       havem |= (nd >= 0 ? 1u : 0u) << p;
       havem |= (inu[p] ? 1u : 0u) << (8 + p);
     }
+    DPH(1)
 #define PHMRF_DP_PASS(P_, REC_)                                                                                          \
   if (!(P_ * 64 > t_end || P_ * 64 + 63 < t_lo)) {                                                                     \
     int t = P_ * 64 + lane;                                                                                            \
@@ -1305,8 +1400,9 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const flo
     int bits;                                                                                                          \
     slab_record<ORIENT>(slabw, slabl, t, ncols, ncell, alpha, (havem >> (8 + P_)) & 1u, ru0[P_], ru1[P_], (havem >> P_) & 1u,   \
                         c0, c1, w4, bits);                                                                             \
+    DPH(2)                                                                                                             \
     dp_pass_chunked<P_, REC_>(m, took, lane, tabch, c0, c1, w4[0], w4[1], w4[2], w4[3], bits, t_lo, t_end, dlo[P_],     \
-                              dhi[P_]);                                                                                \
+                              dhi[P_], live, dp_wk, dp_t0);                                                               \
   }
 
     float m = lane == 0 ? 0.f : BIG;
@@ -1320,6 +1416,10 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const flo
       if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
       return 0u;
     }
+#ifdef PHMRF_PHASE_CLOCK
+    if (lane == 0) atomicAdd(changed - 8 + 104, 1ull);
+#endif
+    DPH(4)
     // a move exists: walk again, this time recording the decision ballots
     const int q_end = t_end % 6;
     int sidx = 0;
@@ -1366,6 +1466,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const flo
       if (my_changed) atomicAdd(changed + alpha, (unsigned long long)my_changed);
       if (mrow) mrow[alpha] = my_changed ? (uint16_t)0 : (uint16_t)tick_a;
     }
+    DPH(5)
     return my_changed;
 }
 
@@ -1377,13 +1478,19 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(const StripGeom& g, const flo
 #define PHMRF_FILTER_INLINE __noinline__
 #endif
 template <int ORIENT>
-__device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, const float* slabw, const unsigned char* slabl, unsigned long long (*ubuf)[SH], int* abuf,
-                                                             int* nbuf_out, int rs0_, int ca_, int ncols_, int ncell_,
+__device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsigned int lds, int lane, int rs0_, int ca_, int ncols_, int ncell_,
                                                              unsigned long long v0_, unsigned long long v1_, unsigned long long v2_,
                                                              unsigned long long v3_, unsigned long long v4_, unsigned long long todo_,
-                                                             int64_t n, const float* __restrict__ uT, uint16_t* mrow, int tick0_,
-                                                             int peel_max_, unsigned int* wk) {
-    const int lane = threadIdx.x & 63;
+                                                             int64_t n, const float* uT_, uint16_t* mrow_, int tick0_, int peel_max_) {
+    const float* __restrict__ uT = as_global(uT_);
+    uint16_t* mrow = as_global(mrow_);
+    ColsLds* L = lds_object<ColsLds>(lds);
+    const float* slabw = L->slabw;
+    const unsigned char* slabl = L->slabl;
+    unsigned long long (*ubuf)[SH] = L->ubuf;
+    int* abuf = L->abuf;
+    int* nbuf_out = &L->nbuf;
+    unsigned int* wk = L->wk;
 #define PHMRF_UNI64(x) (((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)((x) >> 32)) << 32) | \
                         (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(x)))
     // (arguments arrive in vector registers; everything here is wave-uniform)
@@ -1493,15 +1600,14 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, cons
 #pragma unroll
       for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
     }
+    // (quiet labels and the pair count are kept on the scalar side and written once at the end: a global store per
+    //  label put a store round trip into every label's s_waitcnt vmcnt(0), next to the prefetched unary terms)
+    unsigned long long quiet_mask = 0ull;
+    unsigned int n_pairs = 0u;
     while (todo && nbuf < NBUF) {
       const int alpha = alpha_cur;
       todo &= todo - 1ull;
-      if (lane == 0) {
-        atomicAdd(&wk[0], 1u);
-#ifndef PHMRF_PHASE_CLOCK
-        atomicAdd(&wk[5], (unsigned int)ncell);
-#endif
-      }
+      ++n_pairs;
       const bool present = (pres >> alpha) & 1ull;
       float sc[SH];
       unsigned long long U[SH];
@@ -1590,7 +1696,7 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, cons
       }
       FPH(2)
       if (quiet) {
-        if (mrow && lane == 0) mrow[alpha] = (uint16_t)(tick0 + alpha);
+        quiet_mask |= 1ull << alpha;
         continue;
       }
       if (lane == 0) {
@@ -1600,7 +1706,7 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, cons
       }
       ++nbuf;
     }
-#ifdef PHMRF_PHASE_CLOCK
+#if defined(PHMRF_PHASE_CLOCK) && !defined(PHMRF_PHASE_DP)
     if (lane == 0) {
       atomicAdd(&wk[1], fpc[0] >> 4);      // extraction
       atomicAdd(&wk[3], fpc[1] >> 4);      // single-site costs
@@ -1608,7 +1714,14 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, cons
     }
 #endif
 #undef FPH
-    if (lane == 0) *nbuf_out = nbuf;
+    if (mrow && ((quiet_mask >> lane) & 1ull)) mrow[lane] = (uint16_t)(tick0 + lane);      // lane <-> label
+    if (lane == 0) {
+      *nbuf_out = nbuf;
+      atomicAdd(&wk[0], n_pairs);
+#ifndef PHMRF_PHASE_CLOCK
+      atomicAdd(&wk[5], n_pairs * (unsigned int)ncell);
+#endif
+    }
     return todo;
 }
 
@@ -1624,17 +1737,16 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
                                                                          unsigned long long* __restrict__ changed,
                                                                          uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                                          int tick0, unsigned long long* __restrict__ work, int peel_max) {
-  __shared__ __attribute__((aligned(16))) float slabw[SLABW];               // the staged rectangle (7 KB), never overwritten:
-  __shared__ __attribute__((aligned(4))) unsigned char slabl[SLABL];        //   forward weights, label bytes
-  __shared__ __attribute__((aligned(16))) float tabch[CH * TAB];            // DP tables of one chunk (2.6 KB)
-  __shared__ unsigned long long ubuf[NBUF][SH];                             // U of the flagged labels, one word per strip row
-  __shared__ int abuf[NBUF];                                                // ... and which labels they are
-  __shared__ int nbuf_s;
+  __shared__ ColsLds lds_pool;
+  float* slabw = lds_pool.slabw;
+  unsigned char* slabl = lds_pool.slabl;
+  int* abuf = lds_pool.abuf;
+  unsigned int* wk = lds_pool.wk;
+  const unsigned int lds = lds_address_of(&lds_pool);
 #ifdef PHMRF_COLS_LDS_PAD        // development: occupancy experiments
   __shared__ volatile float lds_pad[PHMRF_COLS_LDS_PAD / 4];
   lds_pad[(threadIdx.x * 61) % (PHMRF_COLS_LDS_PAD / 4)] = 1.f;
 #endif
-  __shared__ unsigned int wk[WORK_SLOTS];
   const int lane = threadIdx.x & 63;
   const int nstrips = g.nbands * g.nsegs;
   if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
@@ -1765,8 +1877,8 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 
       PH(2)
       const unsigned long long todo_in = todo;       // (after a move every later label of this set is filtered again)
-      todo = filter_phase<ORIENT>(g, slabw, slabl, ubuf, abuf, &nbuf_s, rs0, ca, ncols, ncell, valid[0], valid[1], valid[2], valid[3], valid[4],
-                                  todo, n, uT, mrow, tick0, peel_max, wk);
+      todo = filter_phase<ORIENT>(g, lds, lane, rs0, ca, ncols, ncell, valid[0], valid[1], valid[2], valid[3], valid[4], todo, n, uT,
+                                  mrow, tick0, peel_max);
       todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
              (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
       PH(0)
@@ -1774,14 +1886,14 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
       __builtin_amdgcn_wave_barrier();
 
       // ---- the DP of the flagged labels, lane <-> cell t = 64 p + lane (column-major), cells outside U pinned
-      const int nbuf = __builtin_amdgcn_readfirstlane(nbuf_s);
+      const int nbuf = __builtin_amdgcn_readfirstlane(lds_pool.nbuf);
 #ifdef PHMRF_COLS_NO_DP
       nbuf = 0;
 #endif
       for (int kb = 0; kb < nbuf; ++kb) {
         const int alpha = __builtin_amdgcn_readfirstlane(abuf[kb]);
-        const unsigned int my_changed = dp_flagged<ORIENT>(g, slabw, slabl, tabch, ubuf[kb], rs0, ca, ncols, ncell, alpha, tick0 + alpha, n, D,
-                                                           nbr, uT, labels, stamp, mrow, changed, wk);
+        const unsigned int my_changed = dp_flagged<ORIENT>(g, lds, kb, lane, rs0, ca, ncols, ncell, alpha, tick0 + alpha, n, D, nbr, uT,
+                                                           labels, stamp, mrow, changed);
         PH(4)
         if (my_changed) {
           // the labels of this strip have changed: everything later is filtered again on the new labelling
@@ -1796,10 +1908,12 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
   }
 #ifdef PHMRF_PHASE_CLOCK
   // slots: 0 pairs + 4096 x general sweeps, 1 extraction, 2 ids/memo/staging, 3 single-site costs, 4 DP, 5 sweeps
+#ifndef PHMRF_PHASE_DP
   if (lane == 0) {
     wk[2] += (phc[1] + phc[2]) >> 4;
     wk[4] += phc[4] >> 4;
   }
+#endif
 #endif
 #undef PH
   __syncthreads();
