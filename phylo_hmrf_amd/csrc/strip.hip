@@ -54,8 +54,10 @@ __device__ __forceinline__ T* lds_object(unsigned int lds_address) {
 }
 // ... and a global-memory pointer argument of an out-of-line function as such (global_load instead of flat_load)
 template <class T>
-__device__ __forceinline__ T* as_global(T* p) {
-  return (T*)(__attribute__((address_space(1))) T*)p;
+using global_ptr = __attribute__((address_space(1))) T*;
+template <class T>
+__device__ __forceinline__ global_ptr<T> as_global(T* p) {
+  return (global_ptr<T>)p;
 }
 template <class T>
 __device__ __forceinline__ unsigned int lds_address_of(T* p) {
@@ -1302,12 +1304,12 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
                                                    int rs0, int ca, int ncols, int ncell, int alpha, int tick_a, int64_t n, int D,
                                                    const int32_t* nbr_, const float* uT_, uint8_t* labels_, uint16_t* stamp_,
                                                    uint16_t* mrow_, unsigned long long* changed_) {
-    const int32_t* __restrict__ nbr = as_global(nbr_);
-    const float* __restrict__ uT = as_global(uT_);
-    uint8_t* __restrict__ labels = as_global(labels_);
-    uint16_t* __restrict__ stamp = as_global(stamp_);
-    uint16_t* mrow = as_global(mrow_);
-    unsigned long long* __restrict__ changed = as_global(changed_);
+    const global_ptr<const int32_t> nbr = as_global(nbr_);
+    const global_ptr<const float> uT = as_global(uT_);
+    const global_ptr<uint8_t> labels = as_global(labels_);
+    const global_ptr<uint16_t> stamp = as_global(stamp_);
+    const global_ptr<uint16_t> mrow = as_global(mrow_);
+    unsigned long long* __restrict__ changed = changed_;
     ColsLds* L = lds_object<ColsLds>(lds);
     const float* slabw = L->slabw;
     const unsigned char* slabl = L->slabl;
@@ -1353,7 +1355,8 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
     }
 #ifndef PHMRF_PHASE_CLOCK
     if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
-#else
+#endif
+#ifdef PHMRF_DP_COUNT
     if (lane == 0) {                     // development build: solver-trace counters (PHMRF_SOLVE_TRACE)
       atomicAdd(changed - 8 + 100, 1ull);
       atomicAdd(changed - 8 + 102, 1ull);
@@ -1416,7 +1419,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
       if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
       return 0u;
     }
-#ifdef PHMRF_PHASE_CLOCK
+#ifdef PHMRF_DP_COUNT
     if (lane == 0) atomicAdd(changed - 8 + 104, 1ull);
 #endif
     DPH(4)
@@ -1452,7 +1455,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
           labels[node] = (uint8_t)alpha;
           if (stamp) {
             stamp[node] = (uint16_t)tick_a;
-            const int32_t* nb2 = nbr + (int64_t)node * D;
+            const global_ptr<const int32_t> nb2 = nbr + (int64_t)node * D;
             for (int j = 0; j < D; ++j)
               if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick_a;
           }
@@ -1482,8 +1485,8 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
                                                              unsigned long long v0_, unsigned long long v1_, unsigned long long v2_,
                                                              unsigned long long v3_, unsigned long long v4_, unsigned long long todo_,
                                                              int64_t n, const float* uT_, uint16_t* mrow_, int tick0_, int peel_max_) {
-    const float* __restrict__ uT = as_global(uT_);
-    uint16_t* mrow = as_global(mrow_);
+    const global_ptr<const float> uT = as_global(uT_);
+    const global_ptr<uint16_t> mrow = as_global(mrow_);
     ColsLds* L = lds_object<ColsLds>(lds);
     const float* slabw = L->slabw;
     const unsigned char* slabl = L->slabl;
@@ -1577,7 +1580,7 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
           }
         }
         laba[r] = la; labb[r] = lb; hs[r] = h;
-        capf[r] = __builtin_fmaf(cf, 1.0001f, 1e-6f);
+        capf[r] = cf;
         __builtin_amdgcn_sched_barrier(0);       // keep the rows apart: interleaving their LDS reads only costs registers
       }
       unsigned int p0 = (unsigned int)pm, p1 = (unsigned int)(pm >> 32);
@@ -1596,7 +1599,7 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
     float u1[SH];
     int alpha_cur = __ffsll((long long)todo) - 1;
     {
-      const float* plane = uT + (int64_t)alpha_cur * n;
+      const global_ptr<const float> plane = uT + (int64_t)alpha_cur * n;
 #pragma unroll
       for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
     }
@@ -1630,70 +1633,76 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
         FPH(1)
       if (todo) {                                  // the next label's terms, in flight during the sweeps
         alpha_cur = __ffsll((long long)todo) - 1;
-        const float* plane = uT + (int64_t)alpha_cur * n;
+        const global_ptr<const float> plane = uT + (int64_t)alpha_cur * n;
 #pragma unroll
         for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
       }
+      // ---- the filter, incrementally: cap_r (the discount sum over the in-strip neighbours that are still in U) lives in
+      //      a register per row; a pass tests every row against its cap and SUBTRACTS the contributions of the cells it
+      //      deletes from the caps of the rows around them (three selects and at most eight multiply-adds per row that
+      //      lost a cell; a row that lost none costs nothing, and the pass that confirms the fixed point is twenty
+      //      instructions).  Rows from the outside in (0, 4, 1, 3, 2): a strip's edge rows have the fewest in-strip
+      //      neighbours, the peeling runs from them towards the middle row and gets there within one pass.  Any order and
+      //      any stale (too large) cap is sound: U only ever loses cells that cannot be in a switching set.
+      //      The caps start from the label-independent sum over ALL in-strip neighbours, minus -- for a label that
+      //      occurs in the rectangle -- the cells that carry it.
       bool quiet = false;
       FPH(3)
+      float cap[SH];
+#pragma unroll
+      for (int r = 0; r < SH; ++r) cap[r] = capf[r];
+      // the cells of row R_ in the mask DEL_ leave U: their discounts come off the caps of the rows R_ - 1, R_, R_ + 1
+      // (a cell of row r' is the d = 5 / 6 / 7 neighbour of row r' - 1, the d = 3 / 4 neighbour of row r', the d = 0 / 1 / 2
+      //  neighbour of row r' + 1; (dr, dc) of d: 0 (-1,-1) 1 (-1,0) 2 (-1,+1) 3 (0,-1) 4 (0,+1) 5 (+1,-1) 6 (+1,0) 7 (+1,+1))
+#define PHMRF_DROP(R_, DEL_)                                                                                      \
+  if ((DEL_) != 0ull) {                                                                                           \
+    const float gl = __builtin_amdgcn_inverse_ballot_w64((DEL_) << 1) ? -1.f : 0.f;   /* column c - 1 leaves */   \
+    const float gc = __builtin_amdgcn_inverse_ballot_w64(DEL_) ? -1.f : 0.f;                                      \
+    const float gr = __builtin_amdgcn_inverse_ballot_w64((DEL_) >> 1) ? -1.f : 0.f;   /* column c + 1 leaves */   \
+    if (R_ > 0) {                                                                                                 \
+      cap[R_ > 0 ? R_ - 1 : 0] = __builtin_fmaf(gl, v8[R_ > 0 ? R_ - 1 : 0][5], cap[R_ > 0 ? R_ - 1 : 0]);       \
+      cap[R_ > 0 ? R_ - 1 : 0] = __builtin_fmaf(gc, v8[R_ > 0 ? R_ - 1 : 0][6], cap[R_ > 0 ? R_ - 1 : 0]);       \
+      cap[R_ > 0 ? R_ - 1 : 0] = __builtin_fmaf(gr, v8[R_ > 0 ? R_ - 1 : 0][7], cap[R_ > 0 ? R_ - 1 : 0]);       \
+    }                                                                                                             \
+    cap[R_] = __builtin_fmaf(gl, v8[R_][3], cap[R_]);                                                             \
+    cap[R_] = __builtin_fmaf(gr, v8[R_][4], cap[R_]);                                                             \
+    if (R_ < SH - 1) {                                                                                            \
+      cap[R_ < SH - 1 ? R_ + 1 : 0] = __builtin_fmaf(gl, v8[R_ < SH - 1 ? R_ + 1 : 0][0], cap[R_ < SH - 1 ? R_ + 1 : 0]); \
+      cap[R_ < SH - 1 ? R_ + 1 : 0] = __builtin_fmaf(gc, v8[R_ < SH - 1 ? R_ + 1 : 0][1], cap[R_ < SH - 1 ? R_ + 1 : 0]); \
+      cap[R_ < SH - 1 ? R_ + 1 : 0] = __builtin_fmaf(gr, v8[R_ < SH - 1 ? R_ + 1 : 0][2], cap[R_ < SH - 1 ? R_ + 1 : 0]); \
+    }                                                                                                             \
+  }
+      if (present) {
+        PHMRF_DROP(0, valid[0] & ~U[0]) PHMRF_DROP(1, valid[1] & ~U[1]) PHMRF_DROP(2, valid[2] & ~U[2])
+        PHMRF_DROP(3, valid[3] & ~U[3]) PHMRF_DROP(4, valid[4] & ~U[4])
+      }
       for (int it = 0; it < peel_max; ++it) {
 #ifdef PHMRF_PHASE_CLOCK
-        if (!(it == 0 && !present) && lane == 0) atomicAdd(&wk[0], 1u << 12);     // general sweeps, in units of 4096 next to the pair count
+        if (lane == 0) atomicAdd(&wk[0], 1u << 12);     // passes, in units of 4096 next to the pair count
 #endif
-        unsigned long long nu[SH];
-        unsigned long long seeds = 0ull;
-        if (it == 0 && !present) {
-          // no cell or neighbour of the rectangle carries alpha: U is every node, the cap of the first sweep is the
-          // label-independent sum over all in-strip neighbours
-#pragma unroll
-          for (int r = 0; r < SH; ++r) {
-            const unsigned long long keep = __ballot(sc[r] <= capf[r]);
-            const unsigned long long sd = __ballot(sc[r] < 0.5f * capf[r]);
-            nu[r] = U[r] & keep;
-            seeds |= nu[r] & sd;
-          }
-        } else {
-          // One basic block, five independent chains: the membership of the three columns c - 1, c, c + 1 of every row
-          // as 0 / 1 floats (15 selects), then cap_r = sum_d  fm[r + dr][dc] * v8[r][d]  as fused multiply-adds -- the
-          // product with 0 or 1 is exact, so this is the masked sum, at one vector instruction per term instead of two.
-          float fm[SH][3];
-#pragma unroll
-          for (int r = 0; r < SH; ++r) {
-            fm[r][0] = __builtin_amdgcn_inverse_ballot_w64(U[r] << 1) ? 1.f : 0.f;      // column c - 1 is in U
-            fm[r][1] = __builtin_amdgcn_inverse_ballot_w64(U[r]) ? 1.f : 0.f;
-            fm[r][2] = __builtin_amdgcn_inverse_ballot_w64(U[r] >> 1) ? 1.f : 0.f;      // column c + 1 is in U
-          }
-#pragma unroll
-          for (int r = 0; r < SH; ++r) {
-            float cap = 0.f;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-              constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-              constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-              const int rr = r + DR[d];
-              if (rr < 0 || rr >= SH) continue;
-              const int rc = rr < 0 ? 0 : (rr >= SH ? SH - 1 : rr);
-              cap = __builtin_fmaf(fm[rc][DC[d] + 1], v8[r][d], cap);
-            }
-            const float capx = __builtin_fmaf(cap, 1.0001f, 1e-6f);
-            const unsigned long long keep = __ballot(sc[r] <= capx);
-            const unsigned long long sd = __ballot(sc[r] < 0.5f * capx);
-            nu[r] = U[r] & keep;
-            seeds |= nu[r] & sd;
-          }
-        }
-        bool shrunk = false;
-#pragma unroll
-        for (int r = 0; r < SH; ++r) {
-          shrunk = shrunk || nu[r] != U[r];
-          U[r] = nu[r];
-        }
+        unsigned long long seeds = 0ull, gone = 0ull;
+        // (a hair of slack for the f32 sums: the caps are carried by subtraction, so the slack has an absolute part that
+        //  covers eight roundings at the largest cap a strip can have)
+#define PHMRF_ROW(R_)                                                                                   \
+  {                                                                                                     \
+    const float capx = __builtin_fmaf(cap[R_], 1.0001f, 2e-5f);                                         \
+    const unsigned long long keep = __ballot(sc[R_] <= capx);                                           \
+    const unsigned long long sd = __ballot(sc[R_] < 0.5f * capx);                                       \
+    const unsigned long long del = U[R_] & ~keep;                                                       \
+    U[R_] &= keep;                                                                                      \
+    seeds |= U[R_] & sd;                                                                                \
+    gone |= del;                                                                                        \
+    PHMRF_DROP(R_, del)                                                                                 \
+  }
+        PHMRF_ROW(0) PHMRF_ROW(4) PHMRF_ROW(1) PHMRF_ROW(3) PHMRF_ROW(2)
+#undef PHMRF_ROW
         if (!seeds) {
           quiet = true;
           break;
         }
-        if (!shrunk) break;
+        if (!gone) break;
       }
+#undef PHMRF_DROP
       FPH(2)
       if (quiet) {
         quiet_mask |= 1ull << alpha;

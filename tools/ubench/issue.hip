@@ -51,8 +51,8 @@ int main() {
   const char* names[6] = {"16 valu add, 4 chains", "16 valu add, 1 chain", "8x(s_shift, select, add) 1 chain", "4x(add, cmp->sgpr, s_and, select+add)", "8x(exec window add) 4 chains", "16 salu"};
   const int ninstr[6] = {16, 16, 32, 24, 26, 32};
   for (int mix = 0; mix < 6; ++mix)
-    for (int wps : {1, 2, 3, 4, 6, 8}) {
-      const int waves_per_cu = wps * 4, grid = 256;            // one workgroup of wps*4 waves per CU
+    for (int wps : {1, 2, 4, 5, 6, 8}) {
+      const int waves_per_cu = 4, grid = 256 * wps;            // wps workgroups of 4 waves per CU
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       auto launch = [&]() {
         switch (mix) {
