@@ -54,8 +54,9 @@ PHMRF_API int phmrf_set_device(int device);
 
 /* ---- block lifetime --------------------------------------------------------------------------- */
 /* n nodes (Hi-C bin pairs), S species (leaves), K states.  K <= 64, S <= 16, n < 2^31 - 64.
- * Limits per entry point: the emission (b1) covers S <= 16; phmrf_posterior_stats (b3) covers S <= 8 and
- * K*(1+S+S*S) <= 4608 and returns PHMRF_ERR_UNSUPPORTED beyond that; node degree <= 64 (phmrf_block_set_graph). */
+ * Limits per entry point: the emission (b1) covers S <= 16; phmrf_posterior_stats (b3) covers S <= 8 at every K <= 64
+ * (its LDS tile, 64 rows x (K + 1 + S + S*S) floats plus K (1 + S + S*S) doubles, is at most 72 KB of the CU's 160) and
+ * returns PHMRF_ERR_UNSUPPORTED for S > 8; node degree <= 64 (phmrf_block_set_graph). */
 PHMRF_API int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out);
 PHMRF_API int phmrf_block_destroy(phmrf_block_t b);
 /* Run this block's kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
@@ -126,13 +127,15 @@ typedef struct phmrf_solve_opts {
   int min_changed;     /* a round that changes at most this many labels counts as quiet (default 0)             */
   int use_coarse;      /* 1: coarse alpha-expansions (super-cells of 2 x 2, 4 x 4 and 8 x 8 nodes switch to a label as a whole,
                           solved exactly on 5 x 63 windows of super-cells by the strip kernel; needs the grid).  They
-                          run in verification rounds and while the labelling is still moving at large (the previous
-                          round changed at least 5 % of the labels: cold or far-off starts); a solve that moved that
-                          much does not stop on the tolerance before they have had a last say                     */
+                          run while the labelling is still moving at large (the previous round changed at least 25 %
+                          of the labels: a cold start), and in the verification rounds of a solve that has moved at
+                          least 12.5 % of the labels in all (a far-off start); such a solve does not stop on the
+                          tolerance before they have had a last say                                                */
   int energy_tol_ppb;  /* > 0: stop as soon as a round lowers the energy by less than this many parts per billion
-                          of |E| (no verification round).  Move types whose last runs were, taken together, worth at
-                          most a quarter of that are rested meanwhile, so what a tolerance stop leaves undone in one
-                          round is bounded by 1.25 x the tolerance.  0: run to the exact fixed point              */
+                          of |E| (no verification round).  Move types whose LAST RUNS were, taken together, worth at
+                          most a quarter of that are rested meanwhile (a type that did not run in a round keeps the
+                          count of its last run), so what a tolerance stop leaves undone in one round of the types
+                          that have run is bounded by 1.25 x the tolerance.  0: run to the exact fixed point       */
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {

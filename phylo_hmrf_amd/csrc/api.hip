@@ -1045,6 +1045,11 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   bool coarse_checked = false;
   std::vector<char> active(128, 0);
   for (int sl : slots) active[sl] = 1;
+  // labels changed by each move type in its LAST RUN (a type that did not run in a round -- chain families and ICM outside
+  // verification rounds, the component pass in mop-up rounds, coarse scales that are off -- keeps that count: the resting
+  // budget below must not read "did not run" as "changed nothing"); -1: has not run in this solve
+  std::vector<long long> last_count(128, -1);
+  std::vector<char> ran(128, 0);
   bool all_active = true;
   bool verifying = false;
   // change stamps + per-strip memo of quiet expansions (exact skip of strips whose inputs did not change)
@@ -1117,6 +1122,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   while (rounds < o.max_rounds && b->tick < 60000) {      // (the change stamps are 16-bit launch ticks)
     const int r = rounds;
     PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
+    std::fill(ran.begin(), ran.end(), 0);
     {
       // Chain moves (exact 1-D Viterbi over all K labels): with the strip expansions in place they run in verification
       // rounds only.  Measured (round 2, live-gco parity cases and the whole-genome bench): in ordinary rounds they make
@@ -1133,6 +1139,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         for (int f = 0; f < n_fam; ++f)
           if (active[72 + f] && (f < n_ord_fams || verifying)) {
             b->counter_slot = 72 + f;
+            ran[72 + f] = 1;
             // cut phase 0 in ordinary rounds (so the segment memo applies from the second round on); the other set of
             // separators is used by the verification rounds
             PHMRF_TRY(chain_sweep_nocount(b, bf, f, verifying ? 1 : 0, false));
@@ -1144,6 +1151,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     // launches on the fixed separator cells; it runs in verification rounds and on graphs without grid moves
     if (active[76] && (verifying || !(chains || strips))) {
       b->counter_slot = 76;
+      ran[76] = 1;
       PHMRF_TRY(icm_sweep_nocount(b, bf));
     }
     // component moves: a full pass over the block (seven kernels) whatever the number of labels that changed.  On grid
@@ -1151,8 +1159,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     // rounds; the mop-up rounds in between (a few hundred changed labels, of which the pass would take a dozen) skip
     // them.  On general graphs, where they are one of two move types, they run in every round.
     const bool comp_round = rounds == 0 || verifying || prev_moving || !(chains || strips);
-    if (o.use_components && active[77] && comp_round) {
+    // (after a round that moved the labelling at large the pass runs whether or not it was rested: its last count is old)
+    if (o.use_components && (active[77] || prev_moving) && comp_round) {
       b->counter_slot = 77;
+      ran[77] = 1;
       if (b->tick) ++b->tick;
       tic(b);
       PHMRF_TRY(launch_component_pass(b, bf));
@@ -1162,6 +1172,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
       for (int orient = 0; orient < 2; ++orient) {
         if (active[78 + orient]) {
           b->counter_slot = 78 + orient;
+          ran[78 + orient] = 1;
           // the fusion pass runs on a cut of its own that moves with the expansions' (so that its memo of quiet strips
           // applies while the cut stays): the expansion cut shifted by half a band / half a segment
           PHMRF_TRY(strip_pass_nocount(b, bf, orient, (GEOM_R[geom] + 3) % 6, (GEOM_C[geom] + 31) % 64, -1, geom));
@@ -1171,7 +1182,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
           // labels back to back behind the exact filter (strip_multi_kernel)
           unsigned long long lmask = 0ull;
           for (int a = 0; a < K; ++a)
-            if (active[8 + a]) lmask |= 1ull << a;
+            if (active[8 + a]) {
+              lmask |= 1ull << a;
+              ran[8 + a] = 1;
+            }
           if (lmask) {
             if (!b->uT_valid) {
               tic(b);
@@ -1188,9 +1202,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         }
       }
     }
-    // coarse alpha-expansions: in verification rounds, and while the labelling is still moving at large (the previous
-    // round changed at least 0.5 % of the labels) -- a warm start that is nearly converged never pays for them
-    // Coarse scales switch on while the labelling is still moving at large (the previous round changed >= 25 % of the
+    // coarse alpha-expansions.  Coarse scales switch on while the labelling is still moving at large (the previous round changed >= 25 % of the
     // labels: a cold start).  A solve that has moved >= 12.5 % of the labels in all (a far-off warm start of an EM
     // iteration) gets them once at the end, before the tolerance may stop it (force_coarse below); the warm start of a
     // later EM iteration, which moves 1-3 %, does not pay for them at all.
@@ -1207,6 +1219,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         coarse_ran[lv] = on;
         if (!on) continue;
         b->counter_slot = 80 + lv;
+        ran[80 + lv] = 1;
         for (int off = 0; off < s; ++off)
           if (verify_coarse || off == r % s)
             PHMRF_TRY(coarse_sweep_nocount(b, bf, lv, off, (2 * r + lv + off) % 6, (17 * r + 5 * lv + 13 * off) % 64, 0, K));
@@ -1220,7 +1233,10 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     PHMRF_TRY(energy_now(b, beta, &eu, &ep));       // synchronises the stream
     const double e_now = eu + ep;
     int64_t ch = 0;
-    for (int sl : slots) ch += (int64_t)b->counters_host[sl];
+    for (int sl : slots) {
+      ch += (int64_t)b->counters_host[sl];
+      if (ran[sl]) last_count[sl] = (long long)b->counters_host[sl];
+    }
     total += ch;
     last_changed = ch;
     // "this round moved the labelling at large" (the cut advances, the component pass runs again): >= 1/64 of the labels
@@ -1310,17 +1326,19 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     for (int sl : slots) active[sl] = 1;
     if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0) {
       const double budget_labels = 1e-9 * o.energy_tol_ppb * std::fabs(e_prev) / 4.0 / (gain / (double)ch);
-      std::vector<int> by_count(slots);
-      std::sort(by_count.begin(), by_count.end(),
-                [&](int a, int c) { return b->counters_host[a] < b->counters_host[c]; });
+      // (only types that have run in this solve can be rested, on the count of their last run)
+      std::vector<int> by_count;
+      for (int sl : slots)
+        if (last_count[sl] >= 0) by_count.push_back(sl);
+      std::sort(by_count.begin(), by_count.end(), [&](int a, int c) { return last_count[a] < last_count[c]; });
       double used = 0.0;
       for (int sl : by_count) {
-        used += (double)b->counters_host[sl];
+        used += (double)last_count[sl];
         if (used > budget_labels) break;
         active[sl] = 0;
       }
     } else {
-      for (int sl : slots) active[sl] = b->counters_host[sl] > 0 ? 1 : 0;
+      for (int sl : slots) active[sl] = last_count[sl] != 0 ? 1 : 0;
     }
     for (int sl : slots) n_act += active[sl];
     all_active = n_act == (int)slots.size();

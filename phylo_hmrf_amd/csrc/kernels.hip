@@ -571,20 +571,25 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   const int K = b->K, Kp = padded_k(K);
   int TB = 256;
   const size_t acc_bytes = (size_t)K * M * sizeof(double);            // the workgroup's f64 statistics
+  // (the tile prefers 64 KB, which leaves two workgroups per CU; K and S at their limits -- K = 64, S = 8: 72 KB at 64 rows --
+  //  take a larger share of the CU's 160 KB instead of being refused)
   while (TB > 64 && (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes > 64 * 1024 - 256) TB >>= 1;
-  PHMRF_CHECK((size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes <= 64 * 1024 - 256, PHMRF_ERR_UNSUPPORTED,
+  PHMRF_CHECK((size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes <= 158 * 1024, PHMRF_ERR_UNSUPPORTED,
               "posterior_stats: K and S too large for the LDS tile");
   const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes;
   const int grid = grid_for(b->n, TB, 256 * 8);
   const int use_w = estimate_type == 3 ? 1 : 0;
 #define PHMRF_LAUNCH_POST(VEC_, WP_)                                                                                \
+  if (lds > 64 * 1024 - 256)                                                                                        \
+    PHMRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&posterior_kernel<S, VEC_, WP_>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
   hipLaunchKernelGGL((posterior_kernel<S, VEC_, WP_>), dim3(grid), dim3(TB), lds, b->stream, b->X, b->logprob, b->n, \
                      K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, use_w, b->posteriors, b->accum)
   const int v = vec_of(K);
   if (write_post) {
-    if (v == 4) PHMRF_LAUNCH_POST(4, true); else if (v == 2) PHMRF_LAUNCH_POST(2, true); else PHMRF_LAUNCH_POST(1, true);
+    if (v == 4) { PHMRF_LAUNCH_POST(4, true); } else if (v == 2) { PHMRF_LAUNCH_POST(2, true); } else { PHMRF_LAUNCH_POST(1, true); }
   } else {
-    if (v == 4) PHMRF_LAUNCH_POST(4, false); else if (v == 2) PHMRF_LAUNCH_POST(2, false); else PHMRF_LAUNCH_POST(1, false);
+    if (v == 4) { PHMRF_LAUNCH_POST(4, false); } else if (v == 2) { PHMRF_LAUNCH_POST(2, false); } else { PHMRF_LAUNCH_POST(1, false); }
   }
 #undef PHMRF_LAUNCH_POST
   PHMRF_HIP(hipGetLastError());

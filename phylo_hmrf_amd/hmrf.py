@@ -40,6 +40,9 @@ class phyloHMRF(_BaseGraph):
                             init_params=init_params)
         if covariance_type not in COVARIANCE_TYPES:
             raise ValueError("covariance_type must be one of {0}".format(COVARIANCE_TYPES))
+        if n_components < 1 or n_components > 64:
+            # one byte per label on the device and one bit per label in the 64-bit label masks (phmrf_block_create)
+            raise ValueError("phyloHMRF on the GPU supports 1..64 states (n_components = %d)" % n_components)
         if n_features > 8:
             # the posterior / statistics kernel holds a node's [1 | x | x x^T] features in LDS for S <= 8 (kernels.hip);
             # the emission kernel alone goes to S = 16 (phmrf_emission_dev)
@@ -330,7 +333,8 @@ class phyloHMRF(_BaseGraph):
         self._covars_ = packed[K * P + K * S:].reshape(K, S, S).copy()
 
     def close(self):
-        _mstep.close_pool()
+        # (the M-step's worker pool is process-wide and forked once, before HIP is up: a second fit in the same process
+        #  reuses it, so it is NOT ended here -- the CLI and bench.py end it with mstep.close_pool(), otherwise atexit does)
         self.runner.close()
         for b in self.blocks.values():
             b.close()

@@ -19,6 +19,7 @@ The NumPy implementation below stays as the fall-back for an ill-conditioned V (
 reference) and as the oracle of the native one (tests/test_mstep.py).
 """
 import ctypes
+import atexit
 import multiprocessing as mp
 import os
 import warnings
@@ -309,6 +310,7 @@ def _solve_state(args):
 
 _POOL = None
 _POOL_SIZE = 0
+_WARNED_SERIAL = False
 
 
 def _pool(workers):
@@ -322,8 +324,20 @@ def _pool(workers):
         # exec-ing an interpreter, which rocprofv3 wraps and breaks, and which the GPU pool forbids once HIP is up.)
         # An existing pool serves every later request, whatever its size (fewer tasks than workers leave some idle,
         # more tasks queue): it is never re-forked; close_pool() ends it.
+        from . import _lib
+        if _lib._lib is not None:
+            # HIP is (or may be) up in this process already: no fork from here.  The states are then fitted one after
+            # the other in this process (same results, K x the time); callers that want the pool create it first
+            # (phylo_hmrf.py, bench.py: mstep._pool(K) before anything touches the GPU)
+            global _WARNED_SERIAL
+            if not _WARNED_SERIAL:
+                warnings.warn("M-step worker pool requested after the GPU library was loaded: fitting the states "
+                              "serially (fork after HIP initialisation is not safe)", RuntimeWarning)
+                _WARNED_SERIAL = True
+            return None
         _POOL = mp.get_context("fork").Pool(workers)
         _POOL_SIZE = workers
+        atexit.register(close_pool)
     return _POOL
 
 
