@@ -394,9 +394,9 @@ def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, p
 
     The reference's result is gco's swap THROUGH PYGCO'S QUANTISATION (phylo_hmrf.py:496-498): the GPU labelling must
     be at or below it STRICTLY -- both labellings are scored by the same float64 function, no slack.  gco at its finest
-    safe quantisation is not what the reference computes; the gap to it is printed and bounded by 5e-5 (neither local
-    optimum dominates the other in theory: global swap moves vs window-restricted expansion / fusion / chain moves at
-    four scales).  Measured (end of round 2, profiles/r2_y_live_gco_energy_gaps.txt): BELOW fine-quantised swap in every
+    safe quantisation is not what the reference computes; the GPU labelling is required to be at or below it as well
+    (neither local optimum dominates the other in theory -- global swap moves vs window-restricted expansion / fusion /
+    chain moves at four scales -- but every case measured so far is below).  Measured (end of round 2, profiles/r2_y_live_gco_energy_gaps.txt): BELOW fine-quantised swap in every
     case, -1.0e-5 ... -3.5e-3, the 2,001,000-node K = 10 block from uniformly random labels included (-1.5e-5 at the
     stopping tolerance, -1.9e-5 at the exact fixed point)."""
     from oracle import gco_ref
@@ -427,7 +427,8 @@ def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, p
                  (e_mine - e_ref["fine"]) / abs(e_ref["fine"]), res["rounds"]))
         assert res["converged"]
         assert e_mine <= e_ref["pygco"], (tol_ppb, e_mine, e_ref)
-        assert e_mine <= e_ref["fine"] + 5e-5 * abs(e_ref["fine"]), (tol_ppb, e_mine, e_ref)
+        # (at the stopping tolerance a solve may leave 1.25e-6 of |E| undone by construction: that, and nothing else, is allowed)
+        assert e_mine <= e_ref["fine"] + (1.25e-6 * abs(e_ref["fine"]) if tol_ppb else 0.0), (tol_ppb, e_mine, e_ref)
     b.close()
 
 
@@ -708,17 +709,17 @@ def test_degenerate_sizes(H, W, diagonal, K, nn):
     b.close()
 
 
-@pytest.mark.parametrize("N", [4980, 24896])
-def test_full_size_largest_block_of_the_metric_config(N):
+@pytest.mark.parametrize("N,S,K", [(4980, 4, 20), (24896, 4, 20), (4980, 8, 30)])
+def test_full_size_largest_block_of_the_metric_config(N, S, K):
     """The largest block of the metric configuration (hg38 chr1 at 50 kb: 4980 x 4980 diagonal block, 12,402,690
-    nodes, S=4, K=20) and of BASELINE's config 5 (chr1 at 10 kb: 24896 x 24896, 309,917,856 nodes: the biggest single
-    MRF the path holds on one GPU, 64-bit offsets everywhere) through properties that need no host copy of the big arrays: the solver lowers the energy and
+    nodes, S=4, K=20), of BASELINE's config 5 (chr1 at 10 kb: 24896 x 24896, 309,917,856 nodes: the biggest single
+    MRF the path holds on one GPU, 64-bit offsets everywhere) and of config 4 (the same 50 kb block with 8 species on
+    the deeper tree and K=30) through properties that need no host copy of the big arrays: the solver lowers the energy and
     converges; the energy kernel, the solver's own report and the posterior kernel's cost numerators agree (three
     different kernels); statistics identities against torch reductions of X; a second solve changes (almost) nothing."""
     import torch
     from phylo_hmrf_amd import Block, synthetic
     from phylo_hmrf_amd.tree import PhyloTree
-    S, K = 4, 20
     n = N * (N + 1) // 2
     tree = PhyloTree(synthetic.tree_for(S))
     rng = np.random.default_rng(1)

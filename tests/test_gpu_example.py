@@ -62,8 +62,7 @@ def test_energy_below_the_reference_on_real_hic(ex, it, tol_ppb):
 
 
 def test_live_gco_fine_quantisation_on_real_hic(ex):
-    """The same inputs with gco at its finest safe quantisation (not what the reference runs): the gap is reported and
-    bounded, the claim above is the strict one."""
+    """The same inputs with gco at its finest safe quantisation (not what the reference runs): also strictly below."""
     from oracle import gco_ref
     if not gco_ref.available():
         pytest.skip("oracle/_ref/libgco_ref.so not present")
@@ -80,7 +79,7 @@ def test_live_gco_fine_quantisation_on_real_hic(ex):
     e_mine = R.mrf_energy(b.get_labels(), lp, ex["eid"], ex["w"], beta)[0]
     b.close()
     print("real Hi-C, iteration 2: GPU %.3f  gco swap (fine quantisation) %.3f  gap %.2e" % (e_mine, e_fine, (e_mine - e_fine) / abs(e_fine)))
-    assert e_mine <= e_fine + 1e-4 * abs(e_fine)
+    assert e_mine <= e_fine          # strictly: every measured gap has been negative (-4.8e-4 here), so no allowance
 
 
 @pytest.mark.parametrize("it", [0, 3])
@@ -121,39 +120,50 @@ import os, sys, json
 import numpy as np
 sys.path.insert(0, os.environ["PHMRF_ROOT"])
 from phylo_hmrf_amd.hmrf import phyloHMRF
+from phylo_hmrf_amd import mstep
 g = np.load(os.path.join(os.environ["PHMRF_ROOT"], "tests", "golden", "example_chr22_em.npz"))
 X, K = g["X"], int(g["K"])
 tree = [[0, 1], [1, 2], [1, 3], [3, 4], [4, 5], [4, 6], [3, 7]]
-m = phyloHMRF(n_components=K, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree,
-              len_vec=g["len_vec"].tolist(), type_id=1, branch_list=[0, 32, 20, 6, 6, 6, 12], edge_list_1=[g["edges"]],
-              cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1,
-              initial_magnitude=1.0, learning_rate=0.001, estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7,
-              random_state=22, quiet=True)                      # mstep_workers=None: the default worker pool
-from phylo_hmrf_amd import mstep
-assert mstep._POOL is not None                                    # forked in __init__, before the first block
-res = m.fit_accumulate_test(X, g["len_vec"].tolist(), 0.001, "t", int(g["m_iter"]))
-out = dict(general=m.general_graph_regions, cost_vec=res[5].tolist(), tmax=int(res[6].max()), tn=int(res[6].shape[0]))
-m.close()
+runs = []
+for seed in (22, 23, 24):
+    m = phyloHMRF(n_components=K, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree,
+                  len_vec=g["len_vec"].tolist(), type_id=1, branch_list=[0, 32, 20, 6, 6, 6, 12], edge_list_1=[g["edges"]],
+                  cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1,
+                  initial_magnitude=1.0, learning_rate=0.001, estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7,
+                  random_state=seed, quiet=True)                    # mstep_workers=None: the default worker pool
+    assert mstep._POOL is not None        # forked by the first constructor, before the first block; later fits reuse it
+    res = m.fit_accumulate_test(X, g["len_vec"].tolist(), 0.001, "t", int(g["m_iter"]))
+    runs.append(dict(general=m.general_graph_regions, cost_vec=res[5].tolist(), tmax=int(res[6].max()), tn=int(res[6].shape[0])))
+    m.close()
+    assert mstep._POOL is not None        # the pool is the process's, not the model's
+mstep.close_pool()
 assert mstep._POOL is None
-print("RESULT " + json.dumps(out))
+print("RESULT " + json.dumps(runs))
 """
+
+# how far above the reference's best cost1 (1.418 on this block) a fit may end: 3.5 % of it.  (Measured: the fits end
+# near 0.78, well below the reference's own run -- the labellings have lower energy and the M-step uses exact gradients.)
+COST1_MARGIN = 0.05
 
 
 def test_fit_on_real_hic_reaches_the_reference_cost(ex):
     """The whole drop-in: phyloHMRF.fit_accumulate_test on the same real block, same K and --miter, with the DEFAULT
-    M-step worker pool (run in a fresh process: the pool is forked before that process touches the GPU).  EM
-    trajectories are not comparable step by step (other initial clustering, other labellings); judged: it runs, costs are
-    finite, and the best cost1 is in the range of the reference's own run."""
+    M-step worker pool (run in a fresh process: the pool is forked before that process touches the GPU), from three
+    seeds.  EM trajectories are not comparable step by step (other initial clustering, other labellings); judged best
+    to best: EVERY seed's best cost1 is at most the reference's best cost1 plus a stated margin."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PHMRF_ROOT=root)
-    out = subprocess.run([sys.executable, "-c", FIT_SCRIPT], capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run([sys.executable, "-c", FIT_SCRIPT], capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
-    cost_vec = np.array(r["cost_vec"])
-    assert r["general"] == [] and cost_vec.shape == (5, 4) and np.all(np.isfinite(cost_vec))
-    assert r["tn"] == ex["X"].shape[0] and r["tmax"] < int(ex["K"])
-    print("cost1 per iteration: GPU fit", np.round(cost_vec[:, 3], 4), " reference", np.round(ex["cost_vec"][:, 3], 4))
-    assert cost_vec[:, 3].min() < ex["cost_vec"][:, 3].max()
+    runs = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    ref_best = float(ex["cost_vec"][:, 3].min())
+    assert len(runs) == 3
+    for r in runs:
+        cost_vec = np.array(r["cost_vec"])
+        assert r["general"] == [] and cost_vec.shape == (5, 4) and np.all(np.isfinite(cost_vec))
+        assert r["tn"] == ex["X"].shape[0] and r["tmax"] < int(ex["K"])
+        print("cost1 per iteration: GPU fit", np.round(cost_vec[:, 3], 4), " reference", np.round(ex["cost_vec"][:, 3], 4))
+        assert cost_vec[:, 3].min() <= ref_best + COST1_MARGIN

@@ -167,7 +167,9 @@ def test_fit_warns_when_a_region_is_not_a_grid_block():
 
 def test_cli_runs_from_raw_hic_text(tmp_path):
     """Row f4: `python phylo_hmrf.py -n 6 --chromvec 22 -p <dir>` on example_input-style raw files (a 120-bin window of
-    the example's chr22 rows, tests/golden/example_loader.npz) -> cache files + the .mat."""
+    the example's chr22 rows, tests/golden/example_loader.npz) -> cache files + the .mat.  (The diffusion filter on this
+    path is the build's own Perona-Malik restatement, medpy being absent; tests/test_preprocess.py checks it against the
+    published update rule.)"""
     import phylo_hmrf as cli
     from tests.test_preprocess import SPECIES, _write_dir
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_loader.npz"))

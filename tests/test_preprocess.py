@@ -93,6 +93,11 @@ def loader_golden():
 
 
 def test_loader_chr22_window(tmp_path, loader_golden):
+    """The raw loader on a window of example_input's chr22 against the reference's own loader run: bit-exact for the
+    'none' and 'gauss' settings.  The 'diffusion' arrays of the fixture are SELF-GENERATED as far as the filter goes (the
+    reference's loader was run with this build's Perona-Malik restatement plugged in for the absent medpy,
+    tests/golden/make_golden_example.py:103-106): that case pins the pipeline around the filter; the filter itself is
+    checked by test_anisotropic_diffusion_against_the_published_update_rule."""
     g = loader_golden
     first = int(g["first_bin"])
     d, flist = _write_dir(tmp_path, g, "22", first, 120, 0, g["a_synteny"])
@@ -149,6 +154,46 @@ def test_loader_errors(tmp_path, loader_golden):
         preprocess.quantile_contact_vec([7], RES, sizes, flist, SPECIES)           # chr7 not in the sizes file
     with pytest.raises(NotImplementedError):
         preprocess.load_data_chromosome2([22], 100.0, 0, RES, 8, 1, 0.25, 0, sizes, flist, SPECIES, d)
+
+
+def _perona_malik_by_the_book(img, niter, kappa, gamma):
+    """Perona & Malik 1990, eq. (7)-(8) as published, pixel by pixel: I <- I + gamma * sum over the four neighbours q of
+    g(I_q - I_p) (I_q - I_p) with g(d) = exp(-(d / kappa)^2); a missing neighbour (image border) contributes no flux.
+    Written independently of preprocess.anisotropic_diffusion (which works on forward-difference / flux arrays)."""
+    cur = np.array(img, dtype=np.float64)
+    H, W = cur.shape
+    for _ in range(niter):
+        nxt = cur.copy()
+        for i in range(H):
+            for j in range(W):
+                acc = 0.0
+                for di, dj in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    a, b = i + di, j + dj
+                    if 0 <= a < H and 0 <= b < W:
+                        d = cur[a, b] - cur[i, j]
+                        acc += np.exp(-(d / kappa) ** 2) * d
+                nxt[i, j] = cur[i, j] + gamma * acc
+        cur = nxt
+    return cur
+
+
+@pytest.mark.parametrize("shape,niter,kappa", [((3, 3), 1, 50.0), ((5, 5), 5, 50.0), ((5, 5), 10, 50.0), ((4, 7), 5, 2.0)])
+def test_anisotropic_diffusion_against_the_published_update_rule(shape, niter, kappa):
+    """An independent check of the Perona-Malik restatement (option 1; the reference's parameters are niter 5 or 10,
+    kappa 50, gamma 0.1: utility.py:1566-1573): the published per-pixel update rule written out by hand in the test,
+    on small images, one case with kappa near the data's differences so that the edge-stopping function matters.
+    (The `a_diffusion_*` arrays of tests/golden/example_loader.npz were recorded from the reference's loader WITH THIS
+    BUILD'S filter plugged in where medpy is missing, so they pin everything around the filter and nothing of it.)"""
+    rng = np.random.default_rng(5)
+    img = rng.random(shape) * 6.0
+    want = _perona_malik_by_the_book(img, niter, kappa, 0.1)
+    got = preprocess.anisotropic_diffusion(img, niter=niter, kappa=kappa, gamma=0.1, option=1)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)          # the filter works in float32 like medpy
+    if shape == (3, 3):
+        # the centre pixel of a 3 x 3 image after one step, written out
+        c, nb = img[1, 1], (img[0, 1], img[2, 1], img[1, 0], img[1, 2])
+        by_hand = c + 0.1 * sum(np.exp(-((q - c) / kappa) ** 2) * (q - c) for q in nb)
+        assert abs(float(got[1, 1]) - by_hand) < 2e-6
 
 
 def test_anisotropic_diffusion_properties():
