@@ -112,16 +112,25 @@ def main():
     from phylo_hmrf_amd.block import unpack_stats
     from phylo_hmrf_amd.tree import PhyloTree
     _lib.require_gpu()
+    # PHMRF_ONE_GPU=1 (tests): every rank on device 0 -- the sharded path on one card, with PHMRF_DIST_BACKEND=gloo (RCCL
+    # refuses two ranks on one device); the production launch is one rank per GPU over RCCL
+    if os.environ.get("PHMRF_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.load().phmrf_set_device(local_rank))
     dev = torch.device("cuda", local_rank)
     # PHMRF_FORCE_DIST=1 exercises the RCCL path (all-reduce, broadcast, barrier) with a single rank
     use_dist = world > 1 or os.environ.get("PHMRF_FORCE_DIST") == "1"
+    backend = os.environ.get("PHMRF_DIST_BACKEND", "nccl")
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")     # where the collectives' tensors live
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- synthetic multi-species Hi-C, generated on the device ----------------------------
     from phylo_hmrf_amd import synthetic
@@ -189,15 +198,18 @@ def main():
         b.posterior_stats_dev(a.beta, 3, stats_dev[i].data_ptr())
         b.sync()
 
+    cost1_log = []                                             # cost1 of every EM iteration (warm-up included)
+
     def em_step():
         t0 = time.time()
         runner.map(estep_block, order)
-        tot = stats_dev.sum(dim=0)
+        tot = stats_dev.sum(dim=0).to(coll_dev)
         if use_dist:
             dist.all_reduce(tot)                               # RCCL: K(1+S+S^2)+4 doubles
         tot = tot.cpu().numpy()
         stats = unpack_stats(tot[:n_stats], K, S)
         cost1 = tot[n_stats + 3] / n_global
+        cost1_log.append(float(cost1))
         if cost1 < state["min_cost"]:                          # base.py:416-420
             state["min_cost"] = cost1
             for b in blocks:
@@ -210,7 +222,7 @@ def main():
         else:
             packed = np.zeros(K * (tree.n_params + S + S * S))
         if use_dist:
-            t = torch.from_numpy(packed).to(dev)
+            t = torch.from_numpy(packed).to(coll_dev)
             dist.broadcast(t, src=0)
             packed = t.cpu().numpy()
         P = tree.n_params
@@ -242,7 +254,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -340,6 +352,7 @@ def main():
                        "step": "full EM iteration: GPU E-step of every block + stats reduction + host M-step (SLSQP, %d workers)" % workers,
                        "mrf_solver": solver},
             "estep_ms": float(np.mean(t_e) * 1e3), "mstep_ms": float(np.mean(t_m) * 1e3),
+            "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "value_estep_only": n_global * a.steps / float(np.sum(t_e)),
             "setup_s": setup_s, "block_threads": runner.n_threads, "kernels": kernels, "roofline": roofline,
             "roofline_limiter": roofline_limiter,
