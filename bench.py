@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-threads", type=int, default=12,
                     help="host threads driving blocks concurrently, each block on its own HIP stream (1 = sequential)")
+    ap.add_argument("--mstep-workers", type=int, default=0,
+                    help="processes fitting the states in the M-step (0 = min(K, cores); 1 = in this process, no fork: "
+                         "the setting for runs under rocprofv3 --pmc, whose preloaded library initialises the GPU first)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not record HIP events around the kernel launches (no per-kernel breakdown / roofline)")
     ap.add_argument("--cpu-sample", type=int, default=652,
@@ -70,7 +73,9 @@ def parse():
 
 def kernel_bytes(cls, n, K, S, D=8):
     """ALGORITHMIC HBM bytes of ONE launch of a kernel class on a block of n nodes (DESIGN.md section 4;
-    f32 data, int32 indices, u8 labels, explicit adjacency -- the accounting of SURVEY.md 8d)."""
+    f32 data, int32 indices, u8 labels, explicit adjacency -- the accounting of SURVEY.md 8d).  The strip classes
+    ("strip": the multi-label expansions, "fusion": strip_kernel) and the proposals are priced from the work the
+    launches actually did, counted on the device (strip_bytes / fusion_bytes / propose_bytes below)."""
     nbr = D * (4 + 4 + 1)                     # neighbour id + weight + neighbour label
     if cls == "emission":
         return n * (4 * S + 4 * K)
@@ -78,10 +83,6 @@ def kernel_bytes(cls, n, K, S, D=8):
         return n / 4.0 * (4 * K + nbr + 1 + 1)
     if cls == "chain":                        # one colour of one family: 4n nodes over 10 launches per round
         return 0.4 * n * (4 * K + nbr + 1 + 1)
-    if cls == "strip":                        # per strip CELL of one unit (bench multiplies by the device-counted
-        return 8 + nbr + 2 + 1                # cells): two unary entries, label, proposal, explicit adjacency = 83 B
-    if cls == "propose":
-        return n * (4 * K + nbr + 1 + 1)
     if cls == "posterior_stats":
         return n * (4 * S + 4 * K + nbr + 1)
     if cls == "energy":
@@ -89,6 +90,38 @@ def kernel_bytes(cls, n, K, S, D=8):
     if cls == "component":                    # one pass over the unary rows and the adjacency (move table), four over
         return n * (4 * K + nbr + 4 * (4 * D + 1) + 12)   # neighbour ids + labels (union-find, block test), roots / flags
     return None
+
+
+def strip_bytes(work, D=8):
+    """SURVEY.md 8d's "one MRF sweep = 4K + 9 deg + 1 bytes per node", with the K the launches actually ran: the
+    expansion kernel sweeps a strip's cells ONCE for all listed labels -- explicit adjacency + label + write, 73 B per
+    cell swept -- and reads one unary entry per cell and listed label (4 B).  Cells and label-cells counted on the device."""
+    return (9 * D + 1) * work["swept_cells"] + 4.0 * work["label_cells"]
+
+
+def fusion_bytes(work, D=8):
+    """a fusion / single-proposal strip unit re-decides its cells between two labels: two unary entries, label,
+    proposal, explicit adjacency = 83 B per cell of the unit (cells counted on the device)"""
+    return (8 + 9 * D + 2 + 1) * work["cells"]
+
+
+def propose_bytes(work, K, grid=True, D=8):
+    """proposals are recomputed only in node tiles that carry a new change stamp (nodes counted on the device): on a
+    grid block K unary entries from the planes, the forward-edge records of the node and of its four backward
+    neighbours' shares, nine labels, one write = 98 B per node at K = 20; explicit adjacency otherwise"""
+    per_node = (4 * K + 16 + 1 + 1) if grid else (4 * K + 9 * D + 1 + 1)
+    return per_node * work["proposal_nodes"]
+
+
+def source_hash():
+    """identifies the build a committed profile was taken with: SHA-1 over the device sources"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "phylo_hmrf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def main():
@@ -101,7 +134,7 @@ def main():
 
     from phylo_hmrf_amd import mstep, workloads
     blocks_def, S, K, nn, desc = workloads.workload(a.workload)
-    workers = min(K, os.cpu_count() or 1)
+    workers = a.mstep_workers if a.mstep_workers > 0 else min(K, os.cpu_count() or 1)
     if rank == 0:
         mstep._pool(workers)                  # fork the M-step workers BEFORE anything initialises the GPU
 
@@ -273,26 +306,47 @@ def main():
                 ce = e0
         return float(tot + ce - cs)
 
-    agg, work = {}, dict(units=0, cells=0, staged_cells=0, dp_steps=0, launches=0, swept_cells=0, label_cells=0)
-    for b in blocks:
-        for name, (ms, ln) in b.timing().items():
-            d = agg.setdefault(name, [0.0, 0, 0.0])
-            d[0] += ms
-            d[1] += ln
-            kb = kernel_bytes(name, b.n, K, S)
-            if kb is not None and name != "strip":
-                d[2] += kb * ln
-        for k, v in b.work().items():
-            work[k] += v
-    if "strip" in agg:
-        # SURVEY.md 8d, counted on the device: a fusion / single-proposal unit re-decides its cells between two labels
-        # (83 B per cell: two unary entries, label, proposal, explicit adjacency); strip_multi_kernel sweeps a strip's
-        # cells ONCE for all listed labels: explicit adjacency + label + write (73 B per cell swept) and one unary entry
-        # per cell and listed label (4 B) -- "one MRF sweep = 4K + 9 deg + 1 bytes per node" with the K it actually ran
-        agg["strip"][2] = (kernel_bytes("strip", 0, K, S) * work["cells"] + (9 * 8 + 1) * work["swept_cells"]
-                           + 4.0 * work["label_cells"])
+    def collect():
+        """per kernel class [stream ms, launches, algorithmic bytes] and the device-counted work, over this rank's blocks"""
+        agg_, work_ = {}, dict(units=0, cells=0, staged_cells=0, dp_steps=0, launches=0, swept_cells=0, label_cells=0,
+                               proposal_nodes=0)
+        for b in blocks:
+            for name, (ms, ln) in b.timing().items():
+                d = agg_.setdefault(name, [0.0, 0, 0.0])
+                d[0] += ms
+                d[1] += ln
+                kb = kernel_bytes(name, b.n, K, S)
+                if kb is not None:
+                    d[2] += kb * ln
+            for k, v in b.work().items():
+                work_[k] += v
+        if "strip" in agg_:
+            agg_["strip"][2] = strip_bytes(work_)
+        if "fusion" in agg_:
+            agg_["fusion"][2] = fusion_bytes(work_)
+        if "propose" in agg_:
+            agg_["propose"][2] = propose_bytes(work_, K)
+        return agg_, work_
+
+    agg, work = collect()
     busy = {name: union_ms(np.concatenate([b.intervals(name) for b in blocks] or [np.zeros((0, 2))]))
             for name in agg} if not a.no_kernel_timing and blocks else {}
+
+    # ---- the same E-step once more, ONE BLOCK AT A TIME (after the timed region; not part of `value`): with a single
+    #      stream in flight a launch's event time is the kernel's own duration, which the concurrent streams of the timed
+    #      region cannot give (there a launch shares the GPU with up to eleven others)
+    isolated = {}
+    if not a.no_kernel_timing and blocks:
+        for b in blocks:
+            b.reset_timing()
+        for i in order:
+            estep_block(i)
+        torch.cuda.synchronize()
+        agg_i, _ = collect()
+        isolated = {k: {"launches": int(v[1]), "avg_launch_us": round(v[0] * 1e3 / max(v[1], 1), 2),
+                        "GBps": (round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[2] > 0 else None)}
+                    for k, v in agg_i.items()}
+
     roofline = roofline_limiter = None
     # the dominant class among those with a byte model (the coarse expansions' gathers have none)
     with_model = {k: v for k, v in agg.items() if v[2] > 0}
@@ -300,38 +354,44 @@ def main():
     if dom_name and busy.get(dom_name, 0) > 0 and agg[dom_name][2] > 0:
         dom_ms, dom_launches, dom_bytes = agg[dom_name]
         ach = dom_bytes / (busy[dom_name] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a.workload, dom_name),
-                    "launches": int(dom_launches), "algorithmic_bytes_per_launch": int(dom_bytes / max(dom_launches, 1)),
+        kernel_names = {"strip": ["strip_cols_kernel"], "fusion": ["strip_kernel"], "propose": ["propose_grid_kernel", "propose_kernel"],
+                        "emission": ["emission_kernel"], "energy": ["energy_grid_kernel", "energy_kernel"],
+                        "posterior_stats": ["posterior_kernel"]}.get(dom_name, [])
+        traffic, traffic_note = pmc_traffic(a.workload, kernel_names)
+        roofline = {"bound": "hbm", "kernel": dom_name, "kernel_names": kernel_names, "achieved": round(ach, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_note, "launches": int(dom_launches),
+                    "algorithmic_bytes_per_launch": int(dom_bytes / max(dom_launches, 1)),
                     "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2),
                     "busy_ms_per_step": round(busy[dom_name] / a.steps, 3),
+                    "isolated": isolated.get(dom_name),
                     "note": "achieved = algorithmic bytes (SURVEY.md 8d accounting x the cells the launches processed, "
                             "counted on the device) / time during which >= 1 launch of the class was running (blocks "
-                            "run concurrently on their own streams); avg_launch_us = mean launch duration incl. the "
-                            "share of the GPU other streams took; traffic = PMC FETCH_SIZE + WRITE_SIZE per launch"}
-        if dom_name == "strip":
+                            "run concurrently on their own streams); avg_launch_us = mean launch duration in the timed "
+                            "region, incl. the share of the GPU other streams took; isolated = the same E-step run one "
+                            "block at a time right after the timed region (a launch's own duration, and the rate at "
+                            "it); traffic = PMC FETCH_SIZE + WRITE_SIZE per launch of the named kernels from the "
+                            "committed rocprofv3 passes, only if they were taken with this build (traffic_source)"}
+        if dom_name in ("strip", "fusion"):
             # what the strip kernels move through LDS (device counters): a DP step reads 64 lanes x 8 B and its cell's
-            # table (128 B) was written once; staging writes 5 words per staged cell and reads 17 back per strip cell
-            lds_bytes = (work["dp_steps"] * (512.0 + 128.0) + work["staged_cells"] * 20.0
-                         + (work["cells"] + work["swept_cells"]) * 68.0)
-            lds_ach = lds_bytes / (busy["strip"] * 1e-3) / 1e12
+            # table (128 B) was written once; staging writes 17 B per staged cell and reads 9 x 5 B back per strip cell
+            lds_bytes = (work["dp_steps"] * (512.0 + 128.0) + work["staged_cells"] * 17.0
+                         + (work["cells"] + work["swept_cells"]) * 45.0)
+            t_lds = (busy.get("strip", 0.0) + busy.get("fusion", 0.0)) * 1e-3
+            lds_ach = lds_bytes / t_lds / 1e12
             lds_peak = 256 * 256 * 2.4e9 / 1e12      # 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS)
-            roofline_limiter = {"bound": "latency at 3 waves per SIMD", "kernel": "strip",
-                                "sq": sq_profile("strip_multi_kernel"),
+            roofline_limiter = {"bound": "instruction issue of in-order waves (vector + scalar), 4 waves per SIMD",
+                                "kernel": dom_name,
                                 "lds": {"achieved": round(lds_ach, 2), "peak": round(lds_peak, 1), "unit": "TB/s",
                                         "frac": round(lds_ach / lds_peak, 4)},
                                 "units": int(work["units"]), "single_proposal_cells": int(work["cells"]),
                                 "swept_cells": int(work["swept_cells"]), "label_cells": int(work["label_cells"]),
-                                "dp_steps": int(work["dp_steps"]),
-                                "occupancy_experiment": {"waves_per_simd": [3, 2], "kernel_ms": [8.63, 13.1],
-                                                         "source": "profiles/README.md (r2 warm-solve profile, chr1 block)"},
-                                "note": "since the exact filter (DESIGN.md 3.1) few (strip, label) pairs reach the DP: the "
-                                        "kernel is bound neither by HBM nor by the LDS pipe nor by instruction issue but by "
-                                        "the latency of each wave's dependent chain (ballot -> scalar mask -> masked add -> "
-                                        "compare, and the global loads behind it): its time follows the resident waves (3 "
-                                        "per SIMD at 168 VGPRs; forced down to 2 it takes 1.5x) and barely moved when 42 % of "
-                                        "its VALU instructions were removed; `sq` = the SQ counters of profiles/ (rocprofv3 "
-                                        "--pmc, one block at a time), as shares of a wave's resident cycles"}
+                                "dp_steps": int(work["dp_steps"]), "proposal_nodes": int(work["proposal_nodes"]),
+                                "note": "device counters of this run only.  The expansion kernel is bound neither by HBM nor "
+                                        "by the LDS pipe: an exact filter settles most (strip, label) pairs in ~500 vector "
+                                        "and ~300 scalar instructions, and a SIMD issues at most ~0.4 of either per cycle "
+                                        "(tools/ubench/issue.hip); the measurements behind this are in DESIGN.md 3.3 and "
+                                        "profiles/README.md, not repeated in this line"}
     kernels = {k: {"ms": round(v[0], 3), "launches": int(v[1]), "busy_ms": round(busy.get(k, 0.0), 3),
                    "GBps": (round(v[2] / (busy[k] * 1e-3) / 1e9, 1) if busy.get(k, 0) > 0 and v[2] > 0 else None)}
                for k, v in agg.items()}
@@ -353,6 +413,7 @@ def main():
                        "mrf_solver": solver},
             "estep_ms": float(np.mean(t_e) * 1e3), "mstep_ms": float(np.mean(t_m) * 1e3),
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
+            "build": {"source_hash": source_hash()},
             "value_estep_only": n_global * a.steps / float(np.sum(t_e)),
             "setup_s": setup_s, "block_threads": runner.n_threads, "kernels": kernels, "roofline": roofline,
             "roofline_limiter": roofline_limiter,
@@ -375,31 +436,29 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def sq_profile(kernel):
-    """SQ counters of one kernel from the rocprofv3 --pmc pass committed under profiles/ (r2_sq_issue_by_kernel.json),
-    as ratios of the wave's cycles; None when not on file."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_sq_issue_by_kernel.json")))[kernel]
-        out = {k.replace("SQ_", "").replace("/WAVE_CYCLES", "_per_wave_cycle").lower(): v for k, v in d.items() if "/" in k}
-        if "SQ_INSTS_VALU" in d and "SQ_WAVE_CYCLES" in d:
-            out["valu_issue_share_of_simd_at_3_waves"] = round(3.0 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 3)
-            out["instructions_per_wave_quad_cycle"] = round(d.get("SQ_ACTIVE_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"], 3)
-        return out
-    except Exception:
-        return None
-
-
-def pmc_traffic(workload, kernel_class):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; see profiles/README.md).
-    None when no measurement for this workload / kernel is on file."""
-    fn = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+def pmc_traffic(workload, kernel_names):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, corrected as
+    MI355X_MICROARCH.md prescribes) of the named kernels, from profiles/pmc_by_kernel.json -- but only if that file was
+    recorded with THIS build (its source_hash equals the hash of phylo_hmrf_amd/csrc now) on this workload; otherwise
+    None and the reason.  -> (bytes or None, provenance string)"""
+    fn = os.path.join(ROOT, "profiles", "pmc_by_kernel.json")
     try:
         d = json.load(open(fn))
-        rec = d[workload][kernel_class]
-        return int(rec["hbm_bytes_per_launch"])
     except Exception:
-        return None
+        return None, "no profiles/pmc_by_kernel.json"
+    if d.get("source_hash") != source_hash():
+        return None, "profiles/pmc_by_kernel.json was recorded with another build (source_hash %s, now %s)" % (
+            d.get("source_hash"), source_hash())
+    if d.get("workload") != workload:
+        return None, "profiles/pmc_by_kernel.json was recorded on workload %s" % d.get("workload")
+    tot_b, tot_l = 0.0, 0
+    for name, rec in d.get("kernels", {}).items():
+        if any(name.startswith(k) for k in kernel_names):
+            tot_b += rec["hbm_bytes"]
+            tot_l += rec["launches"]
+    if tot_l == 0:
+        return None, "kernels %s not in profiles/pmc_by_kernel.json" % (kernel_names,)
+    return int(tot_b / tot_l), "profiles/pmc_by_kernel.json: %s (git %s)" % (d.get("command"), d.get("git_rev"))
 
 
 def cpu_baseline(a, S, K, nn, n_blocks=1, n_total=0, n_max=0):

@@ -210,9 +210,11 @@ PHMRF_API int phmrf_kmeans_step(phmrf_block_t b, const double* centers /* [K,S] 
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
- * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip, 7 propose,
- * 8 coarse (coarse alpha-expansions: coarsen + strip kernels on the super-cell grid + apply). */
-#define PHMRF_NUM_KERNEL_CLASSES 9
+ * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip (the strip
+ * alpha-expansions: strip_cols_kernel, every listed label of a cut in one launch), 7 propose, 8 coarse (coarse
+ * alpha-expansions: coarsen + strip kernels on the super-cell grid + apply), 9 fusion (strip_kernel: the fusion passes and
+ * the single-label strip passes of the API). */
+#define PHMRF_NUM_KERNEL_CLASSES 10
 PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
 PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[9]*/, int64_t* launches /*[9]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
@@ -224,8 +226,9 @@ PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
  *   out[3] DP steps walked (one 64-state step = one cell of one unit)   out[4] strip launches
  *   strip_multi_kernel (all labels of a strip in one wave) counts a (strip, label) pair in out[0] and, instead of
  *   out[1]:  out[5] the strip cells it swept (once per strip visit, whatever the number of labels),
- *            out[6] cells x labels examined (one label's unary term per cell)                                        */
-PHMRF_API int phmrf_block_get_work(phmrf_block_t b, int64_t* out /*[7]*/);
+ *            out[6] cells x labels examined (one label's unary term per cell)
+ *   out[7] nodes whose fusion proposal was recomputed (the proposal kernels skip node tiles without a new change stamp)  */
+PHMRF_API int phmrf_block_get_work(phmrf_block_t b, int64_t* out /*[8]*/);
 /* The timed intervals of one kernel class on a time base common to all blocks of the calling thread's device
  * (phmrf_time_base_reset marks t = 0; call it before the timed region): out = [start_ms, end_ms] pairs, at most
  * `capacity` of them; *count = how many there are.  Blocks run on their own streams, so their intervals overlap:

@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PHMRF_LIB") or os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
-NUM_KERNEL_CLASSES = 9
-KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose", "coarse")
+NUM_KERNEL_CLASSES = 10
+KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose", "coarse", "fusion")
 
 
 class PhmrfError(RuntimeError):

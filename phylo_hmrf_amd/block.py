@@ -219,10 +219,10 @@ class Block(object):
 
     def work(self):
         """Device-counted work of the strip kernels since reset_timing."""
-        out = (ctypes.c_int64 * 7)()
+        out = (ctypes.c_int64 * 8)()
         check(self._L.phmrf_block_get_work(self._h, out))
         return dict(units=out[0], cells=out[1], staged_cells=out[2], dp_steps=out[3], launches=out[4], swept_cells=out[5],
-                    label_cells=out[6])
+                    label_cells=out[6], proposal_nodes=out[7])
 
     def intervals(self, kernel_class):
         """[start_ms, end_ms] of every timed interval of the class, on the device's common time base -> array [m,2]."""

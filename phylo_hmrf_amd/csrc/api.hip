@@ -757,7 +757,7 @@ static int work_fetch_async(phmrf_block_t b) {
   return PHMRF_OK;
 }
 static void work_fold(phmrf_block_t b) {
-  static const int SLOT_OF[WORK_SLOTS] = {0, 1, 2, 3, 5, 6};      // work[4] = launches (host-counted)
+  static const int SLOT_OF[WORK_SLOTS] = {0, 1, 2, 3, 5, 6, 7};   // work[4] = launches (host-counted)
   for (int k = 0; k < WORK_BANKS; ++k)
     for (int q = 0; q < WORK_SLOTS; ++q) b->work[SLOT_OF[q]] += (int64_t)b->work_host[k * WORK_SLOTS + q];
 }
@@ -859,7 +859,7 @@ static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift
   if (b->tick) ++b->tick;
   PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, geom));
   b->work[4] += 1;
-  if (timed) toc(b, KC_STRIP, 1);
+  if (timed) toc(b, KC_FUSION, 1);
   return PHMRF_OK;
 }
 
@@ -1261,7 +1261,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         static double seen[PHMRF_NUM_KERNEL_CLASSES] = {};
         resolve_timing(b);
         fprintf(stderr, "[phmrf solve]   ms:");
-        static const char* NM[PHMRF_NUM_KERNEL_CLASSES] = {"emis", "icm", "chain", "comp", "energy", "post", "strip", "prop", "coarse"};
+        static const char* NM[PHMRF_NUM_KERNEL_CLASSES] = {"emis", "icm", "chain", "comp", "energy", "post", "strip", "prop", "coarse", "fusion"};
         for (int kc = 0; kc < PHMRF_NUM_KERNEL_CLASSES; ++kc) {
           fprintf(stderr, " %s %.2f", NM[kc], b->ms[kc] - seen[kc]);
           seen[kc] = b->ms[kc];
@@ -1468,7 +1468,7 @@ int phmrf_time_base_reset(void) {
 
 int phmrf_block_get_work(phmrf_block_t b, int64_t* out) {
   PHMRF_CHECK(b && out, PHMRF_ERR_INVALID, "NULL argument");
-  for (int q = 0; q < 7; ++q) out[q] = b->work[q];
+  for (int q = 0; q < 8; ++q) out[q] = b->work[q];
   return PHMRF_OK;
 }
 

@@ -34,7 +34,7 @@ int fail(int status, const std::string& msg);
   } while (0)
 
 // ---- kernel classes for the built-in timers (phmrf.h) -------------------------------------------
-enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5, KC_STRIP = 6, KC_PROPOSE = 7, KC_COARSE = 8 };
+enum KernelClass { KC_EMISSION = 0, KC_ICM = 1, KC_CHAIN = 2, KC_COMPONENT = 3, KC_ENERGY = 4, KC_POSTERIOR = 5, KC_STRIP = 6, KC_PROPOSE = 7, KC_COARSE = 8, KC_FUSION = 9 };
 
 // A chain family (grid rows / columns / diagonals / anti-diagonals): `nodes` lists node ids chain after
 // chain in chain order.  Chains of one colour share no edge.  Every chain is cut into SEGMENTS of at most
@@ -139,7 +139,7 @@ struct phmrf_block {
 
 namespace phmrf {
 
-constexpr int WORK_SLOTS = 6;         // see phmrf_block_get_work
+constexpr int WORK_SLOTS = 7;         // see phmrf_block_get_work
 constexpr int WORK_BANKS = 256;       // work_acc[WORK_BANKS][WORK_SLOTS]: strips staged, their cells, staged cells (with rim), DP
                                       // steps of the strip kernels, one bank per workgroup id mod 256 (no hot address)
 constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every (K,S) the posterior / statistics kernel supports

@@ -1957,16 +1957,18 @@ __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                       const uint8_t* __restrict__ labels, float beta,
                                                       uint8_t* __restrict__ prop, const uint16_t* __restrict__ stamp,
-                                                      int since) {
+                                                      int since, unsigned long long* __restrict__ work) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   const int KV = K / VEC;
+  unsigned int done = 0u;                   // nodes whose proposal this workgroup recomputed (thread 0's count)
   for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
     const int64_t rem = n - base;
     const int rows = rem < TB ? (int)rem : TB;
     // since >= 0: the proposals of the previous launch are still in `prop`; a node's proposal depends on its own and
     // its neighbours' labels only, so a tile none of whose (dilated) stamps is newer than that launch is left alone
     if (since >= 0 && !__syncthreads_or((int)threadIdx.x < rows && (int)stamp[base + threadIdx.x] > since)) continue;
+    done += (unsigned int)rows;
     for (int q = threadIdx.x; q < rows * KV; q += TB) {
       const int r = q / KV;
       const int c = (q - r * KV) * VEC;
@@ -2003,6 +2005,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ 
     }
     __syncthreads();
   }
+  if (work && threadIdx.x == 0 && done) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + 6, (unsigned long long)done);
 }
 
 // The same proposals on a grid block, from the tables the strip moves use: the unary terms from the label-major planes
@@ -2013,13 +2016,15 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
                                                            int diagonal, const float4* __restrict__ fwd_w,
                                                            const uint8_t* __restrict__ labels, float beta,
                                                            uint8_t* __restrict__ prop, const uint16_t* __restrict__ stamp,
-                                                           int since) {
+                                                           int since, unsigned long long* __restrict__ work) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
+  unsigned int done = 0u;
   for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
     const int64_t rem = n - base;
     const int rows = rem < TB ? (int)rem : TB;
     if (since >= 0 && !__syncthreads_or((int)threadIdx.x < rows && (int)stamp[base + threadIdx.x] > since)) continue;
+    done += (unsigned int)rows;
     if ((int)threadIdx.x < rows) {
       const int64_t v = base + threadIdx.x;
       float* row = tile + threadIdx.x * Kp;
@@ -2051,6 +2056,7 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
       prop[v] = (uint8_t)bk;
     }
   }
+  if (work && threadIdx.x == 0 && done) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + 6, (unsigned long long)done);
 }
 
 inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
@@ -2065,14 +2071,14 @@ int launch_propose(phmrf_block* b, float beta) {
   const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
   if (b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->D == 8) {
     hipLaunchKernelGGL(propose_grid_kernel, dim3(grid), dim3(TB), lds, b->stream, b->uT, b->n, K, Kp, b->H, b->W, b->diagonal,
-                       b->fwd_w, b->labels, beta, b->labels_tmp, b->stamp, since);
+                       b->fwd_w, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc);
     PHMRF_HIP(hipGetLastError());
     b->prop_tick = b->tick ? b->tick : -1;
     return PHMRF_OK;
   }
 #define PHMRF_LAUNCH_PROP(VEC_)                                                                                     \
   hipLaunchKernelGGL((propose_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
-                     b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since)
+                     b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_PROP(4); break;
     case 2: PHMRF_LAUNCH_PROP(2); break;

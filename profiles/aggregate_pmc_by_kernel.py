@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs: the TCC counters of both do not fit one pass,
+MI355X_MICROARCH.md) -> profiles/pmc_by_kernel.json: HBM bytes per kernel NAME, tagged with the build and the command,
+which bench.py reports as roofline.traffic only while the tag matches the build it runs.
+
+usage: aggregate_pmc_by_kernel.py FETCH_DIR WRITE_DIR OUT.json WORKLOAD "COMMAND"
+
+Units and corrections (MI355X_MICROARCH.md, HBM): the counters are KiB.  On gfx950 FETCH_SIZE tallies a 128-byte
+request at 64 bytes: wide coalesced streams read exactly half their bytes, narrower access widths are uncalibrated.
+Both figures are kept: `fetch_bytes_raw` and `fetch_bytes_x2`; `hbm_bytes` = fetch x 2 + write, the guide's correction
+(an upper bound where the kernel's reads are narrow gathers)."""
+import csv, glob, hashlib, json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("phmrf::", "")
+    base = name.split("(")[0]
+    tmpl = ""
+    if "<" in base:
+        base, rest = base.split("<", 1)
+        tmpl = "<" + rest.split(">")[0] + ">"
+    base = base.split()[-1] if base.strip() else base
+    return base + tmpl
+
+
+def collect(d, counter):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                e = out.setdefault(short(row["Kernel_Name"]), [0.0, 0])
+                e[0] += float(row["Counter_Value"])
+                e[1] += 1
+    return out
+
+
+def source_hash():
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "phylo_hmrf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def main():
+    fdir, wdir, out, workload, command = sys.argv[1:6]
+    fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, fl = fetch.get(k, [0.0, 0])
+        w, wl = write.get(k, [0.0, 0])
+        n = max(fl, wl)
+        kernels[k] = {"launches": n, "fetch_bytes_raw": f * 1024.0, "fetch_bytes_x2": 2.0 * f * 1024.0,
+                      "write_bytes": w * 1024.0, "hbm_bytes": 2.0 * f * 1024.0 + w * 1024.0,
+                      "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / max(n, 1),
+                      "fetch_raw_per_launch": f * 1024.0 / max(n, 1), "write_per_launch": w * 1024.0 / max(n, 1)}
+    try:
+        rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        rev = os.environ.get("PHMRF_GIT_REV", "unknown")
+    json.dump({"source_hash": source_hash(), "git_rev": rev, "workload": workload, "command": command, "kernels": kernels,
+               "note": __doc__.split("Units and corrections")[1].strip()}, open(out, "w"), indent=1)
+    top = sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes"])[:8]
+    for k, v in top:
+        print("%-34s launches %6d  fetch raw %8.2f MB/launch  write %8.2f MB/launch" % (k, v["launches"], v["fetch_raw_per_launch"] / 1e6, v["write_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -36,12 +36,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 0 < r["busy_ms_per_step"] <= d["ms_per_step"]
     for k in d["kernels"].values():
         assert k["busy_ms"] <= k["ms"] + 1e-3 and k["busy_ms"] <= d["ms_per_step"] * d["steps"] + 1e-3
-    if r["kernel"] == "strip":
+    # every figure in the roofline object is measured in this run or says where it comes from
+    assert "traffic_source" in r and (r["traffic"] is None or r["traffic"] > 0)
+    assert r["isolated"] is not None and r["isolated"]["avg_launch_us"] > 0 and r["isolated"]["launches"] > 0
+    assert d["build"]["source_hash"]
+    if r["kernel"] in ("strip", "fusion"):
         lim = d["roofline_limiter"]
         # device-counted work: (strip, label) pairs, cells swept once per strip visit, one unary entry per cell and label
-        assert lim["bound"].startswith("latency") and 0 < lim["lds"]["frac"] < 1 and lim["units"] > 0 and lim["dp_steps"] > 0
+        assert lim["bound"].startswith("instruction issue") and 0 < lim["lds"]["frac"] < 1 and lim["units"] > 0 and lim["dp_steps"] > 0
         assert 0 < lim["swept_cells"] <= lim["label_cells"] <= 315 * lim["units"]
-        assert lim["single_proposal_cells"] > 0
+        assert lim["single_proposal_cells"] > 0 and lim["proposal_nodes"] > 0
+        assert set(lim) <= {"bound", "kernel", "lds", "units", "single_proposal_cells", "swept_cells", "label_cells", "dp_steps",
+                            "proposal_nodes", "note"}          # no figures from other builds or other workloads
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "vectorised", "all_cores_upper_bound"):
         assert key in c, key

@@ -61,6 +61,47 @@ def test_energy_below_the_reference_on_real_hic(ex, it, tol_ppb):
     np.testing.assert_allclose(res["energy"], e_mine, rtol=2e-5)     # the device's f32 logprob vs the f64 oracle
 
 
+@pytest.fixture(scope="module")
+def exfull():
+    """BASELINE config 1 at its real block size: the FULL chr22 synteny block of example_input (683 bins, 233,586 nodes),
+    the reference's own K=20 --miter 5 run (tests/golden/make_golden_chr22_full.py).  The edge list is rebuilt from X
+    with the builder that tests/golden/grid_edges.npz pins bit-exact on the reference's (the generator handed the
+    reference exactly these edges)."""
+    g = np.load(os.path.join(G, "example_chr22_full.npz"))
+    d = {k: g[k] for k in g.files}
+    d["X"] = np.float64(d["X"])
+    lv = d["len_vec"][0]
+    edges = R.grid_edges(d["X"], int(lv[3]), int(lv[4]), True, 8)
+    assert edges.shape[0] == int(d["n_edges"])
+    d["w"], d["eid"] = R.edge_weights_from_distance(edges, float(d["beta1"]))
+    return d
+
+
+@pytest.mark.parametrize("it", [0, 1, 2, 3, 4])
+def test_energy_below_the_reference_on_the_full_chr22_block(exfull, it):
+    """north_star's "final MRF energy <= the reference's" on real data at config 1's own block size, every EM iteration
+    of the reference's run, from the reference's own warm start, at the exact fixed point and at the fit's stopping
+    tolerance: strictly at or below the labelling gco's swap returned through pygco (scored by the same float64 function)."""
+    ex = exfull
+    beta = float(ex["beta"])
+    lp = R.log_multivariate_normal_density_full(ex["X"], ex["it_means"][it], ex["it_covars"][it])
+    e_init = R.mrf_energy(np.int64(ex["it_init"][it]), lp, ex["eid"], ex["w"], beta)[0]
+    e_ref_lab = R.mrf_energy(np.int64(ex["it_labels"][it]), lp, ex["eid"], ex["w"], beta)[0]
+    np.testing.assert_allclose([e_init, e_ref_lab], [ex["it_efloat_init"][it][0], ex["it_efloat"][it][0]], rtol=1e-9)
+    b = _block(ex)
+    b.emission(ex["it_means"][it], ex["it_covars"][it])
+    for tol_ppb in (0, 1000):
+        b.set_labels(ex["it_init"][it])
+        res = b.solve(beta, energy_tol_ppb=tol_ppb)
+        e_mine = R.mrf_energy(b.get_labels(), lp, ex["eid"], ex["w"], beta)[0]
+        print("full chr22 block, iteration %d tol %d ppb: E init %.2f  reference (gco swap via pygco) %.2f  GPU %.2f  rounds %d"
+              % (it, tol_ppb, e_init, e_ref_lab, e_mine, res["rounds"]))
+        assert res["converged"]
+        assert e_mine <= e_ref_lab                   # strictly: <= the reference's labelling
+        assert e_mine <= e_init                      # and never above the warm start (the reference's is, at iteration 1)
+    b.close()
+
+
 def test_live_gco_fine_quantisation_on_real_hic(ex):
     """The same inputs with gco at its finest safe quantisation (not what the reference runs): also strictly below."""
     from oracle import gco_ref

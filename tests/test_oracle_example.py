@@ -48,3 +48,25 @@ def test_reference_labelling_can_raise_the_float_energy_on_real_data(ex):
     lowers the INTEGER energy, can return labels whose float energy is above the warm start's."""
     d = ex["it_efloat"][:, 0] - ex["it_efloat_init"][:, 0]
     assert (d > 0).any() and (d < 0).any()
+
+
+def test_oracle_energy_on_the_full_chr22_block():
+    """The full 683-bin chr22 block (tests/golden/example_chr22_full.npz, BASELINE config 1's block size): the oracle's
+    edge builder gives the edge count the reference was handed, and the oracle's float64 energy of the reference's own
+    labels is what the generator recorded (two of the five iterations; each is a 233,586 x 20 density evaluation)."""
+    g = np.load(os.path.join(G, "example_chr22_full.npz"))
+    lv = g["len_vec"][0]
+    X = np.float64(g["X"])
+    n = X.shape[0]
+    assert lv[0] == n == 683 * 684 // 2 and lv[3] == lv[4] == 683 and lv[8] == 1 and lv[9] == 22
+    edges = R.grid_edges(X, 683, 683, True, 8)
+    assert edges.shape[0] == int(g["n_edges"])
+    w, eid = R.edge_weights_from_distance(edges, float(g["beta1"]))
+    for it in (1, 4):
+        lp = R.log_multivariate_normal_density_full(X, g["it_means"][it], g["it_covars"][it])
+        e = R.mrf_energy(np.int64(g["it_labels"][it]), lp, eid, w, float(g["beta"]))
+        np.testing.assert_allclose(e, g["it_efloat"][it], rtol=1e-10)
+        e0 = R.mrf_energy(np.int64(g["it_init"][it]), lp, eid, w, float(g["beta"]))
+        np.testing.assert_allclose(e0, g["it_efloat_init"][it], rtol=1e-10)
+    # the reference's labelling of iteration 1 has a HIGHER float energy than its warm start (pygco's quantisation)
+    assert g["it_efloat"][1][0] > g["it_efloat_init"][1][0]
