@@ -1475,10 +1475,12 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
 
 // The filter over the labels of `todo` on the wave's staged strip, lane <-> strip column.  Quiet labels get their memo
 // entry; flagged ones go to ubuf / abuf (at most NBUF, then the caller turns to the DP).  Returns the labels not looked at
-// yet; *nbuf_out (LDS) = how many are flagged.  Out of line: its ~80 registers of per-cell state and the DP's tables must
-// not share one register allocation (inlined, the compiler kept them alive across each other and spilled 100+ VGPRs).
+// yet; *nbuf_out (LDS) = how many are flagged.  Inlined into the kernel, with the DP out of line (dp_flagged): the two
+// register sets -- ~80 registers of per-cell state here, the DP's records and tables there -- then never share one
+// allocation (both inlined: 100+ VGPRs spilled), and an out-of-line filter would save and restore the 40 callee-saved
+// VGPRs it needs on every call (measured: ~100 MB of scratch writes per launch on the chr1 block).
 #ifndef PHMRF_FILTER_INLINE
-#define PHMRF_FILTER_INLINE __noinline__
+#define PHMRF_FILTER_INLINE __forceinline__
 #endif
 template <int ORIENT>
 __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsigned int lds, int lane, int rs0_, int ca_, int ncols_, int ncell_,
