@@ -552,15 +552,29 @@ int phmrf_block_set_grid(phmrf_block_t b, int H, int W, int diagonal, int num_ne
     ci[v] = i;
     cj[v] = j;
   }
-  for (int64_t v = 0; v < n; ++v)
+  int64_t present = 0, expected = 0;       // adjacency entries on file / entries of the complete stencil
+  for (int64_t v = 0; v < n; ++v) {
     for (int x = 0; x < D; ++x) {
       const int32_t u = nbr[(size_t)v * D + x];
       if (u < 0) continue;
       const int di = std::abs(ci[u] - ci[v]), dj = std::abs(cj[u] - cj[v]);
       PHMRF_CHECK(di <= 1 && dj <= 1 && (di + dj) > 0, PHMRF_ERR_INVALID, "edge list joins nodes that are not grid neighbours");
       PHMRF_CHECK(num_neighbor == 8 || (di + dj) == 1, PHMRF_ERR_INVALID, "diagonal edge in a 4-neighbour block");
+      ++present;
     }
-  return setup_grid_tables(b, g, num_neighbor);
+    for (int di = -1; di <= 1; ++di)
+      for (int dj = -1; dj <= 1; ++dj) {
+        if ((di == 0 && dj == 0) || (num_neighbor == 4 && di != 0 && dj != 0)) continue;
+        const int ni = ci[v] + di, nj = cj[v] + dj;
+        if (ni < 0 || ni >= H || nj < 0 || nj >= W || (diagonal && ni > nj)) continue;
+        ++expected;
+      }
+  }
+  PHMRF_TRY(setup_grid_tables(b, g, num_neighbor));
+  // kernels that find their neighbours by geometry and COUNT them (the posterior kernel: isolated nodes, estimate_type
+  // != 3) need every stencil edge to be on file; weights alone are indifferent to a missing edge (it weighs 0)
+  b->grid_complete = present == expected;
+  return PHMRF_OK;
 }
 
 int phmrf_block_build_grid_graph(phmrf_block_t b, int H, int W, int diagonal, int num_neighbor, double beta1) {
@@ -581,7 +595,9 @@ int phmrf_block_build_grid_graph(phmrf_block_t b, int H, int W, int diagonal, in
   if (!b->colour_nodes) PHMRF_TRY(dev_alloc(&b->colour_nodes, (size_t)b->n));
   b->has_graph = true;
   b->E = 0;
-  return setup_grid_tables(b, g, num_neighbor);
+  PHMRF_TRY(setup_grid_tables(b, g, num_neighbor));
+  b->grid_complete = true;                 // built from the stencil: every edge is there
+  return PHMRF_OK;
 }
 
 int phmrf_block_get_adjacency(phmrf_block_t b, int* D, int32_t* nbr_out, float* wgt_out) {

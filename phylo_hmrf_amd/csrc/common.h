@@ -86,6 +86,7 @@ struct phmrf_block {
 
   // grid geometry (optional) and chain families
   int H = 0, W = 0, diagonal = 0, num_neighbor = 0;
+  bool grid_complete = false;               // every edge of the stencil is in the edge list (always so for device-built graphs)
   std::vector<phmrf::ChainFamily> families;
 
   // component-move scratch

@@ -6,6 +6,8 @@
 // each lane works on its own node with plain dynamic LDS indexing (neighbour-label histogram,
 // argmin / softmax over k).  All of these kernels are HBM-bound (<= 20 flop/B); no MFMA.
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace phmrf {
@@ -385,12 +387,16 @@ __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restric
 // -------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int S, int VEC, bool WRITE_POST>
+// GRID: the block is the reference's 8-neighbour stencil on a grid: the neighbours are found by geometry and their
+// weights come from the forward-edge records (16 B per node, each edge stored once) instead of the explicit adjacency
+// rows (64 B per node) -- the same neighbours in the same order, so the two forms agree bit for bit.
+template <int S, int VEC, bool WRITE_POST, bool GRID>
 __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ X, const float* __restrict__ logprob,
                                                         int64_t n, int K, int Kp, int D,
                                                         const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                         const uint8_t* __restrict__ labels, float beta, int use_w,
-                                                        float* __restrict__ post_out, double* __restrict__ accum) {
+                                                        float* __restrict__ post_out, double* __restrict__ accum,
+                                                        int gH, int gW, int gdiag, const float4* __restrict__ fwd_w) {
   extern __shared__ float lds[];
   constexpr int M = 1 + S + S * S;
   constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
@@ -423,7 +429,27 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
       const float* wg = wgt + i * D;
       float diff = 0.f;
       int deg = 0;
-      if (D == 8) {                      // the reference's stencil: the whole row and the labels behind it side by side
+      if (GRID) {
+        int gi, gj;
+        grid_coords(i, gW, gdiag, &gi, &gj);
+        int64_t cc[8];
+        float ww[8];
+        grid_gather_neighbours(i, gi, gj, gH, gW, gdiag, fwd_w, cc, ww);      // (an absent neighbour is the node itself)
+        int ll[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ll[t] = labels[cc[t]];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (cc[t] != i) {
+            const float w = use_w ? ww[t] : 1.f;
+            const int l = ll[t];
+            row[l] += w;
+            wtot += w;
+            if (l != li) diff += w;
+            ++deg;
+          }
+        }
+      } else if (D == 8) {               // the reference's stencil: the whole row and the labels behind it side by side
         const int4 c0 = *reinterpret_cast<const int4*>(nb), c1 = *reinterpret_cast<const int4*>(nb + 4);
         const float4 w0 = *reinterpret_cast<const float4*>(wg), w1 = *reinterpret_cast<const float4*>(wg + 4);
         const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
@@ -479,6 +505,8 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     }
     __syncthreads();
     // phase 2: tile = logprob + beta*h   (coalesced row loads, K/VEC lanes per row)
+    // (measured: issuing these loads and the observation vector before phase 1 -- 24 more registers -- made the kernel 12 %
+    //  slower; smaller tiles for more workgroups per CU: 128 rows +13 %, 64 rows +33 %)
     rows_to_tile<VEC, true>(logprob, nullptr, base, rows, K, Kp, tile, 1.f, beta);
     __syncthreads();
     // phase 3: posteriors = softmax_k(tile_k - beta*wtot) in place; per-node features [1 | x | x x^T]
@@ -569,7 +597,8 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   constexpr int M = 1 + S + S * S;
   constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
   const int K = b->K, Kp = padded_k(K);
-  int TB = 256;
+  static const int tb_env = getenv("PHMRF_POST_TB") ? atoi(getenv("PHMRF_POST_TB")) : 0;     // development: tile rows
+  int TB = (tb_env == 64 || tb_env == 128 || tb_env == 256) ? tb_env : 256;
   const size_t acc_bytes = (size_t)K * M * sizeof(double);            // the workgroup's f64 statistics
   // (the tile prefers 64 KB, which leaves two workgroups per CU; K and S at their limits -- K = 64, S = 8: 72 KB at 64 rows --
   //  take a larger share of the CU's 160 KB instead of being refused)
@@ -577,14 +606,23 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   PHMRF_CHECK((size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes <= 158 * 1024, PHMRF_ERR_UNSUPPORTED,
               "posterior_stats: K and S too large for the LDS tile");
   const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes;
-  const int grid = grid_for(b->n, TB, 256 * 8);
+  static const int cap_env = getenv("PHMRF_POST_GRID") ? atoi(getenv("PHMRF_POST_GRID")) : 0;   // development: grid cap
+  // (grid cap swept on the 12.4 M-node block: 2048 -> 925 us, 1024 -> 1069, 768 = three resident workgroups per CU -> 885, 512 -> 1111)
+  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 50 * 1024 ? 256 * 3 : 256 * 8) * (256 / TB));
   const int use_w = estimate_type == 3 ? 1 : 0;
+  // the grid form needs the 8-neighbour stencil's forward-edge records (phmrf_block_set_grid / build_grid_graph)
+  const bool grid_form = b->has_grid && b->grid_complete && b->fwd_w && b->D == 8 && b->num_neighbor == 8;
+#define PHMRF_LAUNCH_POST_G(VEC_, WP_, G_)                                                                          \
+  {                                                                                                                 \
+    if (lds > 64 * 1024 - 256)                                                                                      \
+      PHMRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&posterior_kernel<S, VEC_, WP_, G_>),             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+    hipLaunchKernelGGL((posterior_kernel<S, VEC_, WP_, G_>), dim3(grid), dim3(TB), lds, b->stream, b->X, b->logprob, \
+                       b->n, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, use_w, b->posteriors, b->accum, b->H, b->W, \
+                       b->diagonal, b->fwd_w);                                                                      \
+  }
 #define PHMRF_LAUNCH_POST(VEC_, WP_)                                                                                \
-  if (lds > 64 * 1024 - 256)                                                                                        \
-    PHMRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&posterior_kernel<S, VEC_, WP_>),                   \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-  hipLaunchKernelGGL((posterior_kernel<S, VEC_, WP_>), dim3(grid), dim3(TB), lds, b->stream, b->X, b->logprob, b->n, \
-                     K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, use_w, b->posteriors, b->accum)
+  if (grid_form) PHMRF_LAUNCH_POST_G(VEC_, WP_, true) else PHMRF_LAUNCH_POST_G(VEC_, WP_, false)
   const int v = vec_of(K);
   if (write_post) {
     if (v == 4) { PHMRF_LAUNCH_POST(4, true); } else if (v == 2) { PHMRF_LAUNCH_POST(2, true); } else { PHMRF_LAUNCH_POST(1, true); }
@@ -592,6 +630,7 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
     if (v == 4) { PHMRF_LAUNCH_POST(4, false); } else if (v == 2) { PHMRF_LAUNCH_POST(2, false); } else { PHMRF_LAUNCH_POST(1, false); }
   }
 #undef PHMRF_LAUNCH_POST
+#undef PHMRF_LAUNCH_POST_G
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

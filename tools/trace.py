@@ -26,4 +26,6 @@ sys.stderr.write("---- warm\n")
 b.reset_timing()
 res = b.solve(1.0, energy_tol_ppb=tol, init_mode=0, use_expansion=expn)
 print("warm solve:", res)
+stats, costs, _ = b.posterior_stats(1.0, 3)
+print("costs/n:", (costs / n).round(5))
 print("work:", b.work())
