@@ -58,6 +58,11 @@ PHMRF_API int phmrf_set_device(int device);
  * (its LDS tile, 64 rows x (K + 1 + S + S*S) floats plus K (1 + S + S*S) doubles, is at most 72 KB of the CU's 160) and
  * returns PHMRF_ERR_UNSUPPORTED for S > 8; node degree <= 64 (phmrf_block_set_graph). */
 PHMRF_API int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out);
+/* Environment, read when a block is created: PHMRF_DETERMINISTIC=1 makes the label solver's reductions independent of
+ * the order in which atomics land (the component moves' per-component sums and the round-by-round energies are then
+ * accumulated as fixed-point integers; 8 instead of 4 bytes per node and label of scratch for the component table): two
+ * solves of the same inputs return identical labels.  Default: f32 / f64 atomics, labellings that can differ in a few
+ * nodes from run to run (the reference is not deterministic either: random restarts, k-means). */
 PHMRF_API int phmrf_block_destroy(phmrf_block_t b);
 /* Run this block's kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
  * block's own stream. */

@@ -310,6 +310,11 @@ int phmrf_set_device(int device) {
 }
 
 // ---- block lifetime -----------------------------------------------------------------------------
+static bool deterministic_env() {       // PHMRF_DETERMINISTIC=1: order-independent reductions (read at every block creation)
+  const char* e = getenv("PHMRF_DETERMINISTIC");
+  return e && e[0] == '1';
+}
+
 int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
   PHMRF_CHECK(out, PHMRF_ERR_INVALID, "out is NULL");
   *out = nullptr;
@@ -322,6 +327,7 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
   b->n = n;
   b->S = S;
   b->K = K;
+  b->deterministic = deterministic_env();
   int st = PHMRF_OK;
   auto guard = [&](int s) {
     if (s != PHMRF_OK && st == PHMRF_OK) st = s;
@@ -380,6 +386,7 @@ int phmrf_block_destroy(phmrf_block_t b) {
   for (auto& f : b->families) free_family(f);
   dev_free(b->comp);
   dev_free(b->comp_tab);
+  dev_free(b->comp_tab64);
   dev_free(b->comp_best);
   dev_free(b->comp_gain);
   dev_free(b->comp_move);
@@ -809,6 +816,13 @@ static int energy_now(phmrf_block_t b, double beta, double* eu, double* ep) {
   toc(b, KC_ENERGY, 1);
   PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   PHMRF_HIP(hipStreamSynchronize(b->stream));
+  if (b->deterministic) {             // 2^-20 fixed-point integers in the two slots (kernels.hip energy_flush)
+    long long q[2];
+    std::memcpy(q, b->accum_host + 4, sizeof(q));
+    *eu = (double)q[0] / 1048576.0;
+    *ep = beta * ((double)q[1] / 1048576.0);
+    return PHMRF_OK;
+  }
   *eu = b->accum_host[4];
   *ep = beta * b->accum_host[5];
   return PHMRF_OK;

@@ -92,6 +92,8 @@ struct phmrf_block {
   // component-move scratch
   int32_t* comp = nullptr;                  // device [n] component root per node
   float* comp_tab = nullptr;                // device [n, K] per-root sums
+  long long* comp_tab64 = nullptr;          // ... in deterministic mode: the same sums in 2^-16 fixed point (integer atomics)
+  bool deterministic = false;               // PHMRF_DETERMINISTIC=1 at block creation: order-independent reductions
   int32_t* comp_best = nullptr;             // device [n]
   float* comp_gain = nullptr;               // device [n]
   uint8_t* comp_move = nullptr;             // device [n]

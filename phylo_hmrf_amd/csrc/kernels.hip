@@ -18,6 +18,20 @@ constexpr int ACC_COST = 0;    // accum[0..3]  cost numerators
 constexpr int ACC_ENERGY = 4;  // accum[4..5]  unary, pair
 constexpr int ACC_STATS = 8;   // accum[8..]   post | obs | obs*obs.T
 
+// The two energy sums of a workgroup.  Deterministic mode (PHMRF_DETERMINISTIC=1): as 2^-20 fixed-point integers in the
+// same 8-byte slots -- integer atomics commute, so the round-by-round energies the solver decides on are the same in
+// every run (the host converts back, api.hip energy_now).
+constexpr double ENERGY_FIX = 1048576.0;
+__device__ __forceinline__ void energy_flush(double* accum, double tu, double tp, int det) {
+  if (det) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(accum + ACC_ENERGY), (unsigned long long)__double2ll_rn(tu * ENERGY_FIX));
+    atomicAdd(reinterpret_cast<unsigned long long*>(accum + ACC_ENERGY + 1), (unsigned long long)__double2ll_rn(tp * ENERGY_FIX));
+  } else {
+    atomicAdd(accum + ACC_ENERGY, tu);
+    atomicAdd(accum + ACC_ENERGY + 1, tp);
+  }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(256) void icm_kernel(const float* __restrict__ logp
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ logprob, int64_t n, int K, int D,
                                                      const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
-                                                     const uint8_t* __restrict__ labels, double* __restrict__ accum) {
+                                                     const uint8_t* __restrict__ labels, double* __restrict__ accum, int det) {
   __shared__ double red[8];
   double eu = 0.0, ep = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -297,10 +311,7 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ l
   }
   const double tu = block_sum(eu, red);
   const double tp = block_sum(ep, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(accum + ACC_ENERGY, tu);
-    atomicAdd(accum + ACC_ENERGY + 1, 0.5 * tp);
-  }
+  if (threadIdx.x == 0) energy_flush(accum, tu, 0.5 * tp, det);
 }
 
 // The same energy on a grid block, from the forward-edge records the strip kernels use (fwd_w: E, SW, S, SE -- every
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restrict__ logprob, const float* __restrict__ uT,
                                                           int64_t n, int K, int H, int W,
                                                           int diagonal, const float4* __restrict__ fwd_w,
-                                                          const uint8_t* __restrict__ labels, double* __restrict__ accum) {
+                                                          const uint8_t* __restrict__ labels, double* __restrict__ accum, int det) {
   __shared__ double red[8];
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   double eu = 0.0, ep = 0.0;
@@ -369,10 +380,7 @@ __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restric
   }
   const double tu = block_sum(eu, red);
   const double tp = block_sum(ep, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(accum + ACC_ENERGY, tu);
-    atomicAdd(accum + ACC_ENERGY + 1, tp);
-  }
+  if (threadIdx.x == 0) energy_flush(accum, tu, tp, det);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -686,13 +694,14 @@ int launch_energy(const phmrf_block* b, float beta) {
     const int cap = 2048 / gx + 1;          // ~2048 workgroups: each sums many rows before its two f64 atomics
     if (gy > cap) gy = cap;
     hipLaunchKernelGGL(energy_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->logprob,
-                       (b->uT && b->uT_valid) ? b->uT : nullptr, b->n, b->K, b->H, b->W, b->diagonal, b->fwd_w, b->labels, b->accum);
+                       (b->uT && b->uT_valid) ? b->uT : nullptr, b->n, b->K, b->H, b->W, b->diagonal, b->fwd_w, b->labels, b->accum,
+                       b->deterministic ? 1 : 0);
     PHMRF_HIP(hipGetLastError());
     return PHMRF_OK;
   }
   const int grid = grid_for(b->n, 256, 256 * 8);
   hipLaunchKernelGGL(energy_kernel, dim3(grid), dim3(256), 0, b->stream, b->logprob, b->n, b->K, b->D, b->nbr, b->wgt,
-                     b->labels, b->accum);
+                     b->labels, b->accum, b->deterministic ? 1 : 0);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

@@ -340,8 +340,17 @@ __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, co
 
 // flatten, and clear what the table / decide / block kernels accumulate into: only the ROOT rows of the move table are
 // ever used, so only those are zeroed (instead of a memset of n*K floats per pass)
+// Deterministic mode (PHMRF_DETERMINISTIC=1): the per-component sums are accumulated as 2^-16 fixed-point integers --
+// integer addition is associative, so the table, the moves it decides and hence the labelling no longer depend on the
+// order in which the atomics land.  (f32 atomics, the default: the labelling of two runs can differ in a few nodes.)
+constexpr float TAB_FIX = 65536.f;
+__device__ __forceinline__ void tab_add(float* tab, long long* tab64, int64_t idx, float acc) {
+  if (tab64) atomicAdd(reinterpret_cast<unsigned long long*>(tab64 + idx), (unsigned long long)__float2ll_rn(acc * TAB_FIX));
+  else atomicAdd(tab + idx, acc);
+}
+
 __global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n, float* __restrict__ tab, int K,
-                                  uint8_t* __restrict__ move) {
+                                  uint8_t* __restrict__ move, long long* __restrict__ tab64) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int c = comp[i];
     int p = comp[c];
@@ -352,8 +361,13 @@ __global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n, float* 
     comp[i] = c;
     move[i] = 0;
     if (c == (int)i) {
-      float* row = tab + i * K;
-      for (int k = 0; k < K; ++k) row[k] = 0.f;
+      if (tab64) {
+        long long* row = tab64 + i * K;
+        for (int k = 0; k < K; ++k) row[k] = 0ll;
+      } else {
+        float* row = tab + i * K;
+        for (int k = 0; k < K; ++k) row[k] = 0.f;
+      }
     }
   }
 }
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256) void comp_table_kernel(const float* __restrict
                                                          const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                          const uint8_t* __restrict__ labels,
                                                          const int32_t* __restrict__ comp, float beta,
-                                                         float* __restrict__ tab) {
+                                                         float* __restrict__ tab, long long* __restrict__ tab64) {
   extern __shared__ float lds[];
   const int TB = blockDim.x;
   float* tile = lds;                                          // [TB][Kp]
@@ -422,13 +436,13 @@ __global__ __launch_bounds__(256) void comp_table_kernel(const float* __restrict
         for (int r = r0; r < r1; ++r) {
           const int rr = roots[r];
           if (rr != root) {
-            atomicAdd(tab + (int64_t)root * K + k, acc);
+            tab_add(tab, tab64, (int64_t)root * K + k, acc);
             acc = 0.f;
             root = rr;
           }
           acc += tile[r * Kp + k];
         }
-        atomicAdd(tab + (int64_t)root * K + k, acc);
+        tab_add(tab, tab64, (int64_t)root * K + k, acc);
       }
     }
     __syncthreads();
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(256) void comp_table_grid_kernel(const float* __res
                                                               int W, int diagonal, const float4* __restrict__ fwd_w,
                                                               const uint8_t* __restrict__ labels,
                                                               const int32_t* __restrict__ comp, float beta,
-                                                              float* __restrict__ tab) {
+                                                              float* __restrict__ tab, long long* __restrict__ tab64) {
   extern __shared__ float lds[];
   const int TB = blockDim.x;
   float* tile = lds;                                          // [TB][Kp]
@@ -488,13 +502,13 @@ __global__ __launch_bounds__(256) void comp_table_grid_kernel(const float* __res
         for (int r = r0; r < r1; ++r) {
           const int rr = roots[r];
           if (rr != root) {
-            atomicAdd(tab + (int64_t)root * K + k, acc);
+            tab_add(tab, tab64, (int64_t)root * K + k, acc);
             acc = 0.f;
             root = rr;
           }
           acc += tile[r * Kp + k];
         }
-        atomicAdd(tab + (int64_t)root * K + k, acc);
+        tab_add(tab, tab64, (int64_t)root * K + k, acc);
       }
     }
     __syncthreads();
@@ -504,11 +518,22 @@ __global__ __launch_bounds__(256) void comp_table_grid_kernel(const float* __res
 // best strictly-improving label per component (computed at the root node); gain = dE < 0 or 0
 __global__ void comp_decide_kernel(const float* __restrict__ tab, int64_t n, int K, const uint8_t* __restrict__ labels,
                                    const int32_t* __restrict__ comp, int32_t* __restrict__ best,
-                                   float* __restrict__ gain) {
+                                   float* __restrict__ gain, const long long* __restrict__ tab64) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float g = 0.f;
     int bk = -1;
-    if (comp[i] == (int32_t)i) {
+    if (comp[i] == (int32_t)i && tab64) {            // deterministic mode: fixed-point sums
+      const long long* row = tab64 + i * K;
+      const int cur = labels[i];
+      const float tc = (float)row[cur] * (1.f / TAB_FIX);
+      float bv = tc;
+      for (int k = 0; k < K; ++k) {
+        const float v = (float)row[k] * (1.f / TAB_FIX);
+        if (v < bv) { bv = v; bk = k; }
+      }
+      const float margin = 1e-5f * fabsf(tc) + 1e-6f;
+      if (bk >= 0 && bv < tc - margin) g = bv - tc; else bk = -1;
+    } else if (comp[i] == (int32_t)i) {
       const float* row = tab + i * K;
       const int cur = labels[i];
       const float tc = row[cur];
@@ -653,7 +678,9 @@ int launch_component_pass(phmrf_block* b, float beta) {
   const int64_t n = b->n;
   const int K = b->K, Kp = padded_k(K), D = b->D;
   PHMRF_TRY(ensure(&b->comp, (size_t)n));
-  PHMRF_TRY(ensure(&b->comp_tab, (size_t)n * K));
+  if (b->deterministic) PHMRF_TRY(ensure(&b->comp_tab64, (size_t)n * K));
+  else PHMRF_TRY(ensure(&b->comp_tab, (size_t)n * K));
+  long long* const tab64 = b->deterministic ? b->comp_tab64 : nullptr;
   PHMRF_TRY(ensure(&b->comp_best, (size_t)n));
   PHMRF_TRY(ensure(&b->comp_gain, (size_t)n));
   PHMRF_TRY(ensure(&b->comp_move, (size_t)n));
@@ -661,20 +688,20 @@ int launch_component_pass(phmrf_block* b, float beta) {
   const int g = grid1d(n);
   hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels);
   hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0);
-  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move);
+  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move, tab64);
   const bool grid_tables = b->has_grid && b->num_neighbor == 8 && D == 8 && b->fwd_w && b->uT && b->uT_valid;
   if (grid_tables) {
     const int TB = tile_threads(K);
     const size_t lds = (size_t)TB * Kp * sizeof(float) + (size_t)TB * sizeof(int32_t);
     hipLaunchKernelGGL(comp_table_grid_kernel, dim3(grid1d(n, TB)), dim3(TB), lds, st, b->uT, n, K, Kp, b->H, b->W, b->diagonal,
-                       b->fwd_w, b->labels, b->comp, beta, b->comp_tab);
+                       b->fwd_w, b->labels, b->comp, beta, b->comp_tab, tab64);
   } else {
     const int TB = tile_threads(K);
     const size_t lds = (size_t)TB * Kp * sizeof(float) + (size_t)TB * sizeof(int32_t);
     const int grid = grid1d(n, TB);
 #define PHMRF_LAUNCH_TAB(VEC_)                                                                                       \
   hipLaunchKernelGGL((comp_table_kernel<VEC_>), dim3(grid), dim3(TB), lds, st, b->logprob, n, K, Kp, D, b->nbr, b->wgt, \
-                     b->labels, b->comp, beta, b->comp_tab)
+                     b->labels, b->comp, beta, b->comp_tab, tab64)
     switch (vec_of(K)) {
       case 4: PHMRF_LAUNCH_TAB(4); break;
       case 2: PHMRF_LAUNCH_TAB(2); break;
@@ -683,7 +710,7 @@ int launch_component_pass(phmrf_block* b, float beta) {
 #undef PHMRF_LAUNCH_TAB
   }
   hipLaunchKernelGGL(comp_decide_kernel, dim3(g), dim3(256), 0, st, b->comp_tab, n, K, b->labels, b->comp, b->comp_best,
-                     b->comp_gain);
+                     b->comp_gain, tab64);
   hipLaunchKernelGGL(comp_block_kernel, dim3(g), dim3(256), 0, st, n, D, b->nbr, b->comp, b->comp_gain, b->comp_move);
   hipLaunchKernelGGL(comp_apply_kernel, dim3(g), dim3(256), 0, st, n, b->comp, b->comp_best, b->comp_move, b->labels,
                      b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick, b->nbr, D);
