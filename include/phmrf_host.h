@@ -48,6 +48,18 @@ PHMRF_HOST_API int phmrf_ou_objective(const phmrf_tree_tables* tree, const doubl
                                       const double* oo, double n_samples, double reg, double min_covar, double* f_out,
                                       double* grad, double* V_out, double* mu_out);
 
+/* One state's SLSQP run over the objective above (phylo_hmrf.py:1383-1384: scipy.optimize.minimize(method='SLSQP',
+ * bounds lower <= p <= upper)), driven natively: `slsqp_entry` is the address of SciPy's own Fortran SLSQP core, taken by
+ * the caller from the f2py object (scipy.optimize._slsqp.slsqp._cpointer; SciPy 1.15 calling sequence, 32-bit INTEGERs).
+ * Same routine and calling sequence as scipy's `_minimize_slsqp`, hence the same iterates; x_out = the final point,
+ * *mode_out = SLSQP's exit mode (0 = converged), *n_eval_out = objective evaluations.  Returns
+ * PHMRF_HOST_ILL_CONDITIONED as soon as an evaluation meets an ill-conditioned V: the caller repeats the state with its
+ * Python loop, which takes the reference's pseudo-inverse path there.                                            */
+PHMRF_HOST_API int phmrf_ou_slsqp(const phmrf_tree_tables* tree, void* slsqp_entry, double post, const double* obs,
+                                  const double* oo, double n_samples, double reg, double min_covar, const double* x0,
+                                  double lower, double upper, double acc, int maxiter, double* x_out, int* mode_out,
+                                  int* n_eval_out);
+
 /* Pre-processing: the reference's median fill of empty contact-map cells, `near_interpolation1`
  * (symmetric != 0: square matrix, upper triangle scanned, value mirrored; utility.py:603-631) and
  * `near_interpolation1a` (symmetric == 0: general matrix; utility.py:633-660).  mtx: C-order float64 [n1,n2], updated

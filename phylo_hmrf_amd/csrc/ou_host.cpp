@@ -233,3 +233,78 @@ extern "C" int phmrf_ou_objective(const phmrf_tree_tables* t, const double* p, d
   for (int i = 0; i < N; ++i) grad[1 + 2 * B + i] = gtheta[i] + 2.0 * reg * p[1 + 2 * B + i];
   return PHMRF_HOST_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// One state's SLSQP run, natively: the loop of scipy 1.15 `_minimize_slsqp` (bounds only, no constraints) around
+// SciPy's own Fortran core -- whose entry point the caller takes from the f2py object
+// (scipy.optimize._slsqp.slsqp._cpointer) -- with the objective above evaluated in place.  Same routine, same calling
+// sequence, same iterates as the Python loop (phylo_hmrf_amd/mstep.py `_slsqp_lean`); what goes away is ~20 us of
+// interpreter and f2py argument handling per objective evaluation (~300 evaluations per state and EM iteration).
+typedef void (*slsqp_fn)(int* m, int* meq, int* la, int* n, double* x, double* xl, double* xu, double* f, double* c,
+                         double* g, double* a, double* acc, int* iter, int* mode, double* w, int* l_w, int* jw, int* l_jw,
+                         double* alpha, double* f0, double* gs, double* h1, double* h2, double* h3, double* h4, double* t,
+                         double* t0, double* tol, int* iexact, int* incons, int* ireset, int* itermx, int* line, int* n1,
+                         int* n2, int* n3);
+
+extern "C" int phmrf_ou_slsqp(const phmrf_tree_tables* tree, void* slsqp_entry, double post, const double* obs,
+                              const double* oo, double n_samples, double reg, double min_covar, const double* x0,
+                              double lower, double upper, double acc, int maxiter, double* x_out, int* mode_out,
+                              int* n_eval_out) {
+  if (!tree || !slsqp_entry || !obs || !oo || !x0 || !x_out || !mode_out) return PHMRF_HOST_ERR_INVALID;
+  const int N = tree->N;
+  if (N < 2 || N > 4 * MAXS) return PHMRF_HOST_ERR_INVALID;
+  int n = 3 * (N - 1) + 2;
+  constexpr int MAXN = 3 * (4 * MAXS) + 2;
+  const int n1 = n + 1;
+  int m = 0, meq = 0, la = 1;
+  const int mineq = m - meq + n1 + n1;
+  int l_w = (3 * n1 + m) * (n1 + 1) + (n1 - meq + 1) * (mineq + 2) + 2 * mineq + (n1 + mineq) * (n1 - meq) + 2 * meq + n1 +
+            ((n + 1) * n) / 2 + 2 * m + 3 * n + 3 * n1 + 1;
+  int l_jw = mineq;
+  std::vector<double> w((size_t)l_w, 0.0);
+  std::vector<int> jw((size_t)l_jw, 0);
+  double x[MAXN], xl[MAXN], xu[MAXN], xc[MAXN], g[MAXN + 1], gr[MAXN], a[MAXN + 1], c[1] = {0.0};
+  for (int i = 0; i < n; ++i) {
+    xl[i] = lower;
+    xu[i] = upper;
+    x[i] = x0[i] < lower ? lower : (x0[i] > upper ? upper : x0[i]);
+  }
+  for (int i = 0; i <= n; ++i) a[i] = 0.0;
+  int mode = 0, iter = maxiter;
+  double accv = acc;
+  double sf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // alpha f0 gs h1 h2 h3 h4 t t0 tol
+  int si[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // iexact incons ireset itermx line n1 n2 n3
+  int n_eval = 0;
+  auto evaluate = [&](bool want_grad, double* f_out) -> int {     // (gh11403: SLSQP may leave the box by an ulp or two)
+    for (int i = 0; i < n; ++i) xc[i] = x[i] < lower ? lower : (x[i] > upper ? upper : x[i]);
+    ++n_eval;
+    return phmrf_ou_objective(tree, xc, post, obs, oo, n_samples, reg, min_covar, f_out, want_grad ? gr : nullptr, nullptr, nullptr);
+  };
+  double fx = 0.0;
+  int st = evaluate(true, &fx);
+  if (st != PHMRF_HOST_OK) return st;
+  for (int i = 0; i < n; ++i) g[i] = gr[i];
+  g[n] = 0.0;
+  slsqp_fn core = reinterpret_cast<slsqp_fn>(slsqp_entry);
+  for (;;) {
+    core(&m, &meq, &la, &n, x, xl, xu, &fx, c, g, a, &accv, &iter, &mode, w.data(), &l_w, jw.data(), &l_jw, &sf[0], &sf[1],
+         &sf[2], &sf[3], &sf[4], &sf[5], &sf[6], &sf[7], &sf[8], &sf[9], &si[0], &si[1], &si[2], &si[3], &si[4], &si[5],
+         &si[6], &si[7]);
+    if (mode == 1) {                       // function evaluation
+      st = evaluate(false, &fx);
+      if (st != PHMRF_HOST_OK) return st;
+    } else if (mode == -1) {               // gradient evaluation
+      double dummy;
+      st = evaluate(true, &dummy);
+      if (st != PHMRF_HOST_OK) return st;
+      for (int i = 0; i < n; ++i) g[i] = gr[i];
+      g[n] = 0.0;
+    }
+    if (mode != 1 && mode != -1) break;
+  }
+  for (int i = 0; i < n; ++i) x_out[i] = x[i];
+  *mode_out = mode;
+  if (n_eval_out) *n_eval_out = n_eval;
+  return PHMRF_HOST_OK;
+}

@@ -51,8 +51,40 @@ def host_lib():
                                          ctypes.c_double, ctypes.c_double, dp, dp, dp, dp]
         L.phmrf_ou_objective.restype = ctypes.c_int
         L.phmrf_host_version.restype = ctypes.c_int
+        ipt = ctypes.POINTER(ctypes.c_int)
+        L.phmrf_ou_slsqp.argtypes = [ctypes.POINTER(_TreeTables), ctypes.c_void_p, ctypes.c_double, dp, dp, ctypes.c_double,
+                                     ctypes.c_double, ctypes.c_double, dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int, dp, ipt, ipt]
+        L.phmrf_ou_slsqp.restype = ctypes.c_int
         _HOST_LIB = L
     return _HOST_LIB
+
+
+_SLSQP_ENTRY = [None, False]        # [address of SciPy's Fortran SLSQP core, looked up already]
+
+
+def slsqp_entry():
+    """The address of SciPy's own SLSQP routine (the Fortran core behind scipy.optimize.minimize(method='SLSQP')), from
+    the f2py object's `_cpointer` capsule; None if this SciPy does not expose it (the callers then keep the Python loop).
+    Tied to the calling sequence of SciPy 1.12 - 1.15 (checked against the f2py signature string)."""
+    if not _SLSQP_ENTRY[1]:
+        _SLSQP_ENTRY[1] = True
+        try:
+            from scipy.optimize._slsqp import slsqp
+            sig = (slsqp.__doc__ or "").split("\n")[0].replace(" ", "")
+            want = ("slsqp(m,meq,x,xl,xu,f,c,g,a,acc,iter,mode,w,jw,alpha,f0,gs,h1,h2,h3,h4,t,t0,tol,iexact,incons,ireset,"
+                    "itermx,line,n1,n2,n3,[la,n,l_w,l_jw])")
+            if sig == want:
+                api = ctypes.pythonapi
+                api.PyCapsule_GetName.restype = ctypes.c_char_p
+                api.PyCapsule_GetName.argtypes = [ctypes.py_object]
+                api.PyCapsule_GetPointer.restype = ctypes.c_void_p
+                api.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+                cap = slsqp._cpointer
+                _SLSQP_ENTRY[0] = api.PyCapsule_GetPointer(cap, api.PyCapsule_GetName(cap))
+        except Exception:
+            _SLSQP_ENTRY[0] = None
+    return _SLSQP_ENTRY[0]
 
 
 class NativeTree(object):
@@ -267,7 +299,30 @@ def _slsqp_lean(fun_and_grad, x0, lower, upper, acc=1e-6, maxiter=200):
     return x, int(mode)
 
 
+def _slsqp_native(obj, x0, lower, upper, acc=1e-6, maxiter=200):
+    """The same SLSQP run with the loop in libphmrf_host.so (phmrf_ou_slsqp): SciPy's Fortran core called through its
+    address, the objective evaluated in place -- identical iterates, no interpreter in the loop.  -> (x, exit_mode), or
+    None when the entry point is unavailable, the objective is not the native one, or an evaluation met an
+    ill-conditioned covariance (the Python loop then repeats the state and takes the pseudo-inverse path)."""
+    entry = slsqp_entry()
+    if entry is None or obj.native is None:
+        return None
+    dp = ctypes.POINTER(ctypes.c_double)
+    n = obj.t.n_params
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    obs, oo = np.ascontiguousarray(obj.obs), np.ascontiguousarray(obj.oo)
+    x = np.zeros(n)
+    mode, n_eval = ctypes.c_int(0), ctypes.c_int(0)
+    st = host_lib().phmrf_ou_slsqp(ctypes.byref(obj.native.tables), entry, obj.post, obs.ctypes.data_as(dp),
+                                   oo.ctypes.data_as(dp), obj.n, obj.reg, obj.min_covar, x0.ctypes.data_as(dp), lower, upper,
+                                   acc, int(maxiter), x.ctypes.data_as(dp), ctypes.byref(mode), ctypes.byref(n_eval))
+    if st != 0:
+        return None
+    return x, int(mode.value)
+
+
 _LEAN_OK = [True]      # cleared (per process) the first time the private SLSQP core rejects our call
+NATIVE_LOOP = [os.environ.get("PHMRF_MSTEP_NATIVE_LOOP", "1") != "0"]      # the SLSQP loop in libphmrf_host.so (default)
 
 
 def _solve_state(args):
@@ -280,8 +335,8 @@ def _solve_state(args):
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore", RuntimeWarning)
-                lean = None
-                if _LEAN_OK[0]:
+                lean = _slsqp_native(obj, x0, LOWER, UPPER, acc=1e-6, maxiter=200) if NATIVE_LOOP[0] else None
+                if lean is None and _LEAN_OK[0]:
                     try:
                         lean = _slsqp_lean(obj.value_and_grad, x0, LOWER, UPPER, acc=1e-6, maxiter=200)
                     except (TypeError, ValueError, AttributeError, SystemError) as err:

@@ -144,3 +144,32 @@ def test_lean_slsqp_driver_equals_scipy_minimize():
                            tol=1e-6, options={"maxiter": 200})
         assert lean[1] == res.status
         np.testing.assert_allclose(lean[0], res.x, rtol=1e-12, atol=1e-14)
+
+
+def test_native_slsqp_loop_reproduces_the_python_loop():
+    """phmrf_ou_slsqp (libphmrf_host.so: SciPy's Fortran SLSQP core called through its address, the objective evaluated in
+    place) against the Python loop around the same core: identical iterates, hence identical results and exit modes."""
+    from phylo_hmrf_amd import synthetic
+    from phylo_hmrf_amd.mstep import LOWER, UPPER, OUObjective, _slsqp_lean, _slsqp_native, slsqp_entry
+    from phylo_hmrf_amd.tree import PhyloTree
+    if slsqp_entry() is None:
+        pytest.skip("this SciPy does not expose the SLSQP core's address")
+    for S, K in ((4, 6), (8, 4)):
+        tree = PhyloTree(synthetic.tree_for(S))
+        rng = np.random.default_rng(S)
+        P = synthetic.sample_ou_params(rng, tree, K)
+        mu, cv = tree.mean_cov(P)
+        cv = cv + 1e-3 * np.eye(S)
+        n = 20000
+        lab = rng.integers(0, K, n)
+        L = np.linalg.cholesky(cv)
+        X = np.maximum(mu[lab] + np.einsum("nij,nj->ni", L[lab], rng.standard_normal((n, S))), 0)
+        for c in range(K):
+            Xc = X[lab == c]
+            obj = OUObjective(tree, float(Xc.shape[0]), Xc.sum(0), Xc.T @ Xc, n, 1.0)
+            x0 = 0.4 * P[c] + 0.6 * rng.random(tree.n_params)
+            a = _slsqp_native(obj, x0, LOWER, UPPER)
+            b = _slsqp_lean(obj.value_and_grad, np.clip(x0, LOWER, UPPER), LOWER, UPPER, acc=1e-6, maxiter=200)
+            assert a is not None and b is not None
+            assert a[1] == b[1]
+            assert np.array_equal(a[0], b[0]), float(np.abs(a[0] - b[0]).max())
