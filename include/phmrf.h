@@ -213,6 +213,14 @@ PHMRF_API int phmrf_posterior_stats_dev(phmrf_block_t b, double beta, int estima
 PHMRF_API int phmrf_kmeans_step(phmrf_block_t b, const double* centers /* [K,S] */, int write_labels,
                                 double* out /* [K*S + K + 1] */);
 
+/* The same step with the per-cluster second moments behind the other outputs (S <= 8):
+ *   out[K*S+K+1 .. +K*S*S)  sum over the cluster's nodes of x x^T.
+ * With the sums and the counts that is everything the reference's initialisation takes from the observations after
+ * clustering: the per-cluster OU fit works on a cluster's mean and X^T X / n (phylo_hmrf.py:1246-1325, :1427-1498) and
+ * the first covariance is the global one (:258) -- so no host pass over the observations is left.                   */
+PHMRF_API int phmrf_kmeans_moments(phmrf_block_t b, const double* centers /* [K,S] */, int write_labels,
+                                   double* out /* [K*S + K + 1 + K*S*S] */);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
  * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip (the strip

@@ -70,8 +70,10 @@ def parse_args(argv=None):
                                                         "write it in the reference's cache format")
     parser.add_option("--seed", default="", help="random seed (default: non-deterministic like the reference)")
     parser.add_option("--quiet", default="0", help="1: suppress the per-iteration prints")
-    parser.add_option("--init", default="sklearn", help="initial clustering: 'sklearn' = MiniBatchKMeans on the host as in "
-                      "the reference (phylo_hmrf.py:234-238); 'device' = k-means on the GPU (whole-genome inputs)")
+    parser.add_option("--init", default="minibatch", help="initial clustering: 'minibatch' = the reference's MiniBatchKMeans "
+                      "(phylo_hmrf.py:234-238) for the centres, the assignment of all nodes and the per-cluster "
+                      "statistics on the GPU; 'sklearn' = the reference's initialisation verbatim on the host; "
+                      "'device' = Lloyd k-means on the GPU")
     parser.add_option("-h", "--help", action="help")
     opts, _ = parser.parse_args(argv)
     return opts
@@ -127,7 +129,7 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
         initial_mode, initial_weight, initial_weight1, initial_magnitude, position1, position2, filter_sigma, beta,
         beta1, num_neighbor, filter_mode, conv_threshold, estimate_type, simu_version, annotation, reload_mode,
         diagonal_type, m_iter, resolution, quantile, ref_species, output_path, synthetic="0", seed="", quiet="0",
-        init_method="sklearn"):
+        init_method="minibatch"):
     run_id = int(run_id1)
     n_components1 = int(num_states)
     cons_param = float(cons_param)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "phmrf_posterior_stats": [_vp, _d, _i, _dp, _dp, _dp],
     "phmrf_posterior_stats_dev": [_vp, _d, _i, _vp],
     "phmrf_kmeans_step": [_vp, _dp, _i, _dp],
+    "phmrf_kmeans_moments": [_vp, _dp, _i, _dp],
     "phmrf_block_enable_timing": [_vp, _i],
     "phmrf_block_get_timing": [_vp, _dp, _lp],
     "phmrf_block_reset_timing": [_vp],

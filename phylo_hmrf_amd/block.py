@@ -204,6 +204,16 @@ class Block(object):
         KS = self.K * self.S
         return out[:KS].reshape(self.K, self.S), out[KS:KS + self.K], float(out[KS + self.K])
 
+    def kmeans_moments(self, centers, write_labels=False):
+        """The Lloyd step with the per-cluster second moments: -> (sums[K,S], counts[K], inertia, outer[K,S,S])."""
+        c = as_f64(centers)
+        assert c.shape == (self.K, self.S)
+        K, S = self.K, self.S
+        out = np.zeros(K * S + K + 1 + K * S * S)
+        check(self._L.phmrf_kmeans_moments(self._h, ptr_d(c), int(bool(write_labels)), ptr_d(out)))
+        KS = K * S
+        return (out[:KS].reshape(K, S), out[KS:KS + K], float(out[KS + K]), out[KS + K + 1:].reshape(K, S, S))
+
     # -- timing -----------------------------------------------------------------------------------
     def enable_timing(self, on=True):
         check(self._L.phmrf_block_enable_timing(self._h, int(on)))

@@ -1455,6 +1455,27 @@ int phmrf_kmeans_step(phmrf_block_t b, const double* centers, int write_labels, 
   return PHMRF_OK;
 }
 
+int phmrf_kmeans_moments(phmrf_block_t b, const double* centers, int write_labels, double* out) {
+  PHMRF_CHECK(b && centers && out, PHMRF_ERR_INVALID, "NULL argument");
+  PHMRF_CHECK(b->has_X, PHMRF_ERR_STATE, "observations not set");
+  const int K = b->K, S = b->S, NP = K * S + K + 1 + K * S * S;
+  PHMRF_CHECK(S <= 8, PHMRF_ERR_UNSUPPORTED, "second moments: S must be in [1,8]");
+  PHMRF_CHECK(8 + NP <= ACCUM_DOUBLES, PHMRF_ERR_UNSUPPORTED, "K*S*S too large");
+  std::vector<float> c((size_t)K * S);
+  for (int i = 0; i < K * S; ++i) {
+    PHMRF_CHECK(std::isfinite(centers[i]), PHMRF_ERR_INVALID, "centres must be finite");
+    c[i] = (float)centers[i];
+  }
+  PHMRF_TRY(upload(b->emis_params, c.data(), c.size() * sizeof(float), b->stream));
+  PHMRF_TRY(zero_accum(b, 8, NP));
+  PHMRF_TRY(launch_kmeans_step(b, b->emis_params, write_labels != 0, b->accum + 8, true));
+  PHMRF_HIP(hipMemcpyAsync(b->accum_host + 8, b->accum + 8, NP * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  std::memcpy(out, b->accum_host + 8, NP * sizeof(double));
+  if (write_labels) b->has_labels = true;
+  return PHMRF_OK;
+}
+
 // ---- measurement --------------------------------------------------------------------------------
 int phmrf_block_enable_timing(phmrf_block_t b, int enable) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");

@@ -169,7 +169,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
                       int geom = -1);   // geom 0..2: one of the three fixed cuts (enables the memo of quiet strips)
 int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, unsigned long long label_mask,
                        int geom = -1);   // all listed alpha-expansions of the cut, one wave per strip
-int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev);
+int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev, bool outer = false);
 int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
 int64_t coarse_nodes(const phmrf_block* b, int s, int off);                        // nodes of the coarse grid (s, off)
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta);

@@ -13,12 +13,15 @@
 namespace phmrf {
 namespace {
 
-template <int S>
+// OUTER: also the per-cluster second moments sum_i x_i x_i^T (K*S*S values behind the others): with the sums and the
+// counts they are all the per-cluster OU fit of the initialisation (phylo_hmrf.py:1246-1325 works on a cluster's mean
+// and X^T X / n only) and the global covariance (:258) need -- no host pass over the observations.
+template <int S, bool OUTER>
 __global__ __launch_bounds__(256) void kmeans_step_kernel(const float* __restrict__ X, int64_t n, int K,
                                                           const float* __restrict__ centers, uint8_t* __restrict__ labels,
-                                                          double* __restrict__ acc /* [K*S sums | K counts | inertia] */) {
-  extern __shared__ float part[];                 // [K*S sums | K counts | 1 inertia]
-  const int NP = K * S + K + 1;
+                                                          double* __restrict__ acc /* [K*S sums | K counts | inertia | K*S*S] */) {
+  extern __shared__ float part[];                 // [K*S sums | K counts | 1 inertia | K*S*S second moments]
+  const int NP = K * S + K + 1 + (OUTER ? K * S * S : 0);
   for (int q = threadIdx.x; q < NP; q += blockDim.x) part[q] = 0.f;
   __syncthreads();
   for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
@@ -52,6 +55,13 @@ __global__ __launch_bounds__(256) void kmeans_step_kernel(const float* __restric
       for (int s = 0; s < S; ++s) atomicAdd(part + bk * S + s, x[s]);     // LDS float atomics
       atomicAdd(part + K * S + bk, 1.f);
       atomicAdd(part + K * S + K, best);
+      if (OUTER) {
+        float* oo = part + K * S + K + 1 + bk * S * S;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+          for (int t = 0; t < S; ++t) atomicAdd(oo + s * S + t, x[s] * x[t]);
+      }
     }
     __syncthreads();
     // flush the tile's partial sums (f32 over at most 256 nodes) into the f64 accumulators
@@ -66,16 +76,21 @@ __global__ __launch_bounds__(256) void kmeans_step_kernel(const float* __restric
 
 }  // namespace
 
-int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev) {
+int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool write_labels, double* acc_dev, bool outer) {
   const int K = b->K;
-  const size_t lds = (size_t)(K * b->S + K + 1) * sizeof(float);
+  if (outer && b->S > 8) return fail(PHMRF_ERR_UNSUPPORTED, "second moments: S must be in [1,8]");
+  const size_t lds = (size_t)(K * b->S + K + 1 + (outer ? K * b->S * b->S : 0)) * sizeof(float);
   int64_t g64 = (b->n + 255) / 256;
   const int grid = (int)(g64 > 2048 ? 2048 : g64);
   switch (b->S) {
 #define PHMRF_CASE(S_)                                                                                               \
   case S_:                                                                                                           \
-    hipLaunchKernelGGL((kmeans_step_kernel<S_>), dim3(grid), dim3(256), lds, b->stream, b->X, b->n, K, centers_dev,  \
-                       write_labels ? b->labels : nullptr, acc_dev);                                                 \
+    if (outer && S_ <= 8)                                                                                            \
+      hipLaunchKernelGGL((kmeans_step_kernel<(S_ <= 8 ? S_ : 1), true>), dim3(grid), dim3(256), lds, b->stream, b->X, b->n, \
+                         K, centers_dev, write_labels ? b->labels : nullptr, acc_dev);                               \
+    else                                                                                                             \
+      hipLaunchKernelGGL((kmeans_step_kernel<S_, false>), dim3(grid), dim3(256), lds, b->stream, b->X, b->n, K,      \
+                         centers_dev, write_labels ? b->labels : nullptr, acc_dev);                                  \
     break;
     PHMRF_CASE(1) PHMRF_CASE(2) PHMRF_CASE(3) PHMRF_CASE(4) PHMRF_CASE(5) PHMRF_CASE(6) PHMRF_CASE(7) PHMRF_CASE(8)
     PHMRF_CASE(9) PHMRF_CASE(10) PHMRF_CASE(11) PHMRF_CASE(12) PHMRF_CASE(13) PHMRF_CASE(14) PHMRF_CASE(15) PHMRF_CASE(16)

@@ -33,7 +33,7 @@ class phyloHMRF(_BaseGraph):
                  random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
                  learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
                  solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=12,
-                 init_method="sklearn"):
+                 init_method="minibatch"):
         _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
                             startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
                             random_state=random_state, n_iter=n_iter, tol=tol, params=params, verbose=verbose,
@@ -86,8 +86,10 @@ class phyloHMRF(_BaseGraph):
                                 energy_tol_ppb=1000)
         if solver_opts:
             self.solver_opts.update(solver_opts)
-        if init_method not in ("sklearn", "device"):
-            raise ValueError("init_method must be 'sklearn' (the reference's MiniBatchKMeans) or 'device'")
+        if init_method not in ("minibatch", "sklearn", "device"):
+            raise ValueError("init_method must be 'minibatch' (the reference's MiniBatchKMeans for the centres, every pass "
+                             "over all nodes on the device), 'sklearn' (the reference's initialisation verbatim, on the "
+                             "host) or 'device' (Lloyd iterations on the device)")
         self.init_method = init_method
 
         # species tree tables (phylo_hmrf.py:103-143)
@@ -195,16 +197,30 @@ class phyloHMRF(_BaseGraph):
         X = np.asarray(X)
         n_samples, n_features = X.shape
         seed = None if self.random_state is None else int(self.random_state)
-        if self.init_method == "device":
-            # k-means on the GPU where X already lives (kmeans.py); every rank draws the same host sample for seeding
-            from .kmeans import device_kmeans
-            srng = np.random.default_rng(seed)
-            rows = srng.choice(n_samples, size=min(n_samples, 50000), replace=False)
-            centers, _ = device_kmeans([self.blocks[r] for r in self.my_regions], X[np.sort(rows)], self.n_components,
-                                       srng, reducer=self.reducer if self.world > 1 else None)
+        my_blocks = [self.blocks[r] for r in self.my_regions]
+        red = self.reducer if self.world > 1 else None
+        if self.init_method in ("minibatch", "device"):
+            from .kmeans import device_kmeans, device_moments, minibatch_centers
+            if self.init_method == "minibatch":
+                # the reference's estimator and settings for the centres (:234-236); every rank computes the same ones
+                centers = minibatch_centers(X, self.n_components, seed)
+            else:
+                # Lloyd iterations on the GPU (kmeans.py); every rank draws the same host sample for seeding
+                srng = np.random.default_rng(seed)
+                rows = srng.choice(n_samples, size=min(n_samples, 50000), replace=False)
+                centers, _ = device_kmeans(my_blocks, X[np.sort(rows)], self.n_components, srng, reducer=red)
+            # what the reference does next with passes over all rows -- labels_ (:239), the per-cluster OU fit on a cluster's
+            # mean and X^T X / n (:246 -> :1246-1325), the global covariance (:258) -- from ONE device pass over X
+            counts, sums, outer, _ = device_moments(my_blocks, centers, reducer=red, write_labels=True)
             self.means_ = centers
             self._snapshot_labels(SLOT_LOCAL)
             init_label = np.int64(self._gather_labels(SLOT_LOCAL))
+            self._log("initialize parameters...")
+            self.init_ou_params = _mstep.init_ou_params_moments(self.tree, counts, sums, outer, self.means_, self.params_vec1,
+                                                                self.initial_w2, self.rng, workers=self.mstep_workers)
+            n_tot = float(counts.sum())
+            mean_all = sums.sum(axis=0) / n_tot
+            cv = (outer.sum(axis=0) - n_tot * np.outer(mean_all, mean_all)) / (n_tot - 1.0) + self.min_covar * np.eye(n_features)
         else:
             from sklearn import cluster
             kmeans = cluster.MiniBatchKMeans(n_clusters=self.n_components, random_state=seed, batch_size=2000,
@@ -212,15 +228,15 @@ class phyloHMRF(_BaseGraph):
             kmeans.fit(X)
             self.means_ = kmeans.cluster_centers_
             init_label = kmeans.labels_
-        self._log("initialize parameters...")
-        self.init_ou_params = _mstep.init_ou_params(self.tree, X, init_label, self.means_, self.params_vec1,
-                                                    self.initial_w2, self.rng, workers=self.mstep_workers)   # :246
+            self._log("initialize parameters...")
+            self.init_ou_params = _mstep.init_ou_params(self.tree, X, init_label, self.means_, self.params_vec1,
+                                                        self.initial_w2, self.rng, workers=self.mstep_workers)   # :246
+            cv = np.cov(X.T) + self.min_covar * np.eye(n_features)              # :258
         self.params_vec1 = self.init_ou_params.copy()
         self.init_label = np.int64(init_label)
         self.labels = self.init_label.copy()
         self.labels_local = self.init_label.copy()
         self._upload_labels(self.init_label)
-        cv = np.cov(X.T) + self.min_covar * np.eye(n_features)                  # :258
         self._covars_ = np.tile(np.atleast_2d(cv), (self.n_components, 1, 1))   # :261-262
         self._log("return from initializing parameters...")
 

@@ -6,6 +6,13 @@ labels and means.  Here the assignment + accumulation step runs on the GPU where
 per-iteration reduction of K(S+1)+1 doubles over blocks (and ranks), a few restarts, best inertia wins.
 It is an alternative initialiser, not a restatement of MiniBatchKMeans (whose result depends on sklearn's version and
 RNG stream): parity of the EM path does not depend on it.
+
+`minibatch_centers` + `device_moments` are the default initialiser (init_method "minibatch"): the reference's own
+estimator with the reference's settings finds the centres -- on all rows when there are at most `sample_cap` of them (then
+these are exactly the reference's centres), else on a uniform host sample of that many rows (mini-batch k-means only ever
+touches random batches of 2000 rows) -- and everything that is a pass over ALL nodes runs on the device: the assignment
+of every node to its nearest centre, the per-cluster sums and second moments for the per-cluster OU fit, the global
+covariance.
 """
 import numpy as np
 
@@ -63,3 +70,34 @@ def device_kmeans(blocks, sample, K, rng, reducer=None, n_init=3, max_iter=100, 
     centers = best[0]
     _, _, inertia = _step(blocks, centers, reducer, write_labels=True)
     return centers, inertia
+
+
+def minibatch_centers(X, K, seed, sample_cap=2000000):
+    """The reference's clustering call (phylo_hmrf.py:234-238: MiniBatchKMeans, batch 2000, max_iter 1000, n_init 10) on
+    the rows of X, or on a uniform sample of `sample_cap` rows when there are more.  -> centres [K,S]."""
+    from sklearn import cluster
+    X = np.asarray(X)
+    n = X.shape[0]
+    if n > sample_cap:
+        rows = np.sort(np.random.default_rng(seed).choice(n, size=sample_cap, replace=False))
+        X = X[rows]
+    km = cluster.MiniBatchKMeans(n_clusters=K, random_state=seed, batch_size=2000, max_iter=1000, n_init=10)
+    km.fit(X)
+    return np.asarray(km.cluster_centers_, dtype=np.float64)
+
+
+def device_moments(blocks, centers, reducer=None, write_labels=True):
+    """Every node to its nearest centre (the assignment becomes the blocks' labels) and the per-cluster statistics of the
+    assignment, on the device: -> (counts[K], sums[K,S], outer[K,S,S], inertia), summed over blocks and ranks."""
+    K, S = centers.shape
+    acc = np.zeros(K * S + K + 1 + K * S * S)
+    for b in blocks:
+        sums, counts, inertia, outer = b.kmeans_moments(centers, write_labels)
+        acc[:K * S] += sums.ravel()
+        acc[K * S:K * S + K] += counts
+        acc[K * S + K] += inertia
+        acc[K * S + K + 1:] += outer.ravel()
+    if reducer is not None:
+        acc = reducer.allreduce(acc)
+    return (acc[K * S:K * S + K], acc[:K * S].reshape(K, S), acc[K * S + K + 1:].reshape(K, S, S), float(acc[K * S + K]))
+

@@ -252,6 +252,15 @@ class OUObjectiveSingle(OUObjective):
         n = X.shape[0]
         OUObjective.__init__(self, tree, 1.0, X.mean(axis=0), X.T @ X / n, 1.0, 0.0, min_covar)
 
+    @classmethod
+    def from_moments(cls, tree, mean, second_moment, min_covar=1e-3):
+        """The same objective from the cluster's sample mean and X^T X / n -- all `_ou_lik_varied_single` takes from the
+        observations (:1290-1293) -- e.g. as accumulated on the device (phmrf_kmeans_moments)."""
+        obj = cls.__new__(cls)
+        OUObjective.__init__(obj, tree, 1.0, np.asarray(mean, dtype=np.float64), np.asarray(second_moment, dtype=np.float64),
+                             1.0, 0.0, min_covar)
+        return obj
+
 
 def _slsqp_lean(fun_and_grad, x0, lower, upper, acc=1e-6, maxiter=200):
     """SciPy's SLSQP core (scipy.optimize._slsqp.slsqp, the routine `minimize(method="SLSQP")` drives) for a problem
@@ -461,7 +470,8 @@ def ou_init_guess(tree, mean_values, w2, rng):
 
 def _init_state(args):
     tree, X, guesses = args
-    obj = OUObjectiveSingle(tree, X)
+    # (X: the cluster's rows, or the pair (mean, X^T X / n) of its sample moments)
+    obj = OUObjectiveSingle.from_moments(tree, X[0], X[1]) if isinstance(X, tuple) else OUObjectiveSingle(tree, X)
     bounds = [(LOWER, UPPER)] * tree.n_params
     params1, flag = guesses[-1], -1
     for guess in guesses[:-1]:
@@ -502,3 +512,27 @@ def init_ou_params(tree, X, init_label, means, params_default, w2, rng, workers=
     for c, (p, _) in zip(idx, res):
         out[c] = p
     return out
+
+
+def init_ou_params_moments(tree, counts, sums, outer, means, params_default, w2, rng, workers=None):
+    """`_init_ou_param` (phylo_hmrf.py:184-203) from per-cluster sufficient statistics instead of the clusters' rows:
+    counts[K], sums[K,S] = sum of x, outer[K,S,S] = sum of x x^T (phmrf_kmeans_moments, summed over blocks and ranks).
+    The objective of the per-cluster fit (:1246-1325) only ever uses the cluster's mean and X^T X / n, so this is the same
+    fit on ALL of a cluster's nodes without a host pass over them (init_ou_params subsamples clusters above 200,000 rows)."""
+    K = params_default.shape[0]
+    out = params_default.copy()
+    tasks, idx = [], []
+    for c in range(K):
+        if not counts[c] > 0:
+            continue                                                                  # "empty cluster!" (:191-192)
+        guesses = [ou_init_guess(tree, means[c], w2, rng) for _ in range(4)]
+        tasks.append((tree, (sums[c] / counts[c], outer[c] / counts[c]), guesses))
+        idx.append(c)
+    if workers is None:
+        workers = min(max(len(tasks), 1), os.cpu_count() or 1)
+    pool = _pool(workers)
+    res = pool.map(_init_state, tasks) if pool is not None else [_init_state(t) for t in tasks]
+    for c, (p, _) in zip(idx, res):
+        out[c] = p
+    return out
+

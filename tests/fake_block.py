@@ -42,6 +42,15 @@ class FakeBlock(object):
             self.labels = lab.astype(np.int64)
         return sums, counts, inertia
 
+    def kmeans_moments(self, centers, write_labels=False):
+        from oracle import ref_numpy as R
+        sums, counts, inertia = self.kmeans_step(centers, write_labels)
+        lab, _, _, _ = R.kmeans_step(self.X, centers)
+        K, S = centers.shape
+        outer = np.zeros((K, S, S))
+        np.add.at(outer, lab, self.X[:, :, None] * self.X[:, None, :])
+        return sums, counts, inertia, outer
+
     def get_labels(self):
         return self.labels.astype(np.int32)
 

@@ -96,7 +96,9 @@ def test_blocks_in_flight_give_the_sequential_result():
                       len_vec=lens, type_id=1, branch_list=[1.0] * 7, edge_list_1=edges, cons_param=1.0, beta=1.0,
                       beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0,
                       learning_rate=0.001, estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, random_state=5,
-                      quiet=True, mstep_workers=1, block_threads=threads)
+                      quiet=True, mstep_workers=1, block_threads=threads, init_method="sklearn")
+        # (the host initialiser: what is compared is the E-step with 1 and with 3 blocks in flight, from bit-identical
+        #  starting parameters; the default initialiser's device-side moments carry f64 atomics of their own)
         res = m.fit_accumulate_test(X, lens, 1e-3, "t", 4)
         m.close()
         return res

@@ -119,3 +119,88 @@ def test_device_initialisation_reaches_no_worse_a_cost_than_the_reference_initia
         m.close()
     print("seed %d: best cost1  reference initialiser %.4f   device initialiser %.4f" % (seed, best["sklearn"], best["device"]))
     assert best["device"] <= best["sklearn"] + 0.05 * abs(best["sklearn"])      # measured: -4.1 %, +1.6 %, -0.7 %
+
+
+@pytest.mark.gpu
+def test_default_initialiser_is_the_reference_s_on_the_full_chr22_block():
+    """SURVEY 8f3 / phylo_hmrf.py:205-264 at BASELINE config 1's block size (the real chr22 block, 233,586 nodes, K = 20).
+    The default initialiser ("minibatch") = the reference's own clustering call for the centres + ONE device pass for
+    everything the reference does with passes over all rows.  Against the reference's initialisation run verbatim on the
+    host ("sklearn": the same estimator, settings and seed on the same rows):
+      centres            identical (the same call; the sample cap is above this block's size)
+      labels             kmeans.labels_ up to f32 distance ties
+      per-cluster stats  the device's sums / second moments = the host's over the same labels
+      global covariance  np.cov(X.T) to 1e-6
+      per-cluster OU fit from the moments = from the rows (same objective: value and gradient agree to 1e-9)"""
+    import os
+    from sklearn import cluster
+    from phylo_hmrf_amd import Block, kmeans, mstep, synthetic
+    from phylo_hmrf_amd.tree import PhyloTree
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_chr22_full.npz"))
+    X = np.float64(g["X"])
+    n, S, K, seed = X.shape[0], 4, 20, 22
+    centers = kmeans.minibatch_centers(X, K, seed)
+    km = cluster.MiniBatchKMeans(n_clusters=K, random_state=seed, batch_size=2000, max_iter=1000, n_init=10).fit(X)
+    assert np.array_equal(centers, km.cluster_centers_)
+    b = Block(n, S, K)
+    b.set_observations(X)
+    counts, sums, outer, inertia = kmeans.device_moments([b], centers, write_labels=True)
+    lab = b.get_labels()
+    b.close()
+    ref = km.labels_
+    diff = np.flatnonzero(lab != ref)
+    d2 = ((X[diff, None, :] - centers[None, :, :]) ** 2).sum(axis=2)
+    assert diff.size <= n // 5000                                     # measured: a handful of f32 ties
+    assert np.all(np.abs(d2[np.arange(diff.size), lab[diff]] - d2[np.arange(diff.size), ref[diff]]) <= 1e-5 * (1 + d2.min(axis=1)))
+    assert counts.sum() == n
+    host_counts = np.bincount(lab, minlength=K)
+    assert np.array_equal(counts, host_counts)
+    host_sums = np.zeros((K, S))
+    np.add.at(host_sums, lab, X)
+    host_outer = np.zeros((K, S, S))
+    np.add.at(host_outer, lab, X[:, :, None] * X[:, None, :])
+    np.testing.assert_allclose(sums, host_sums, rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(outer, host_outer, rtol=2e-6, atol=1e-5)
+    n_tot = float(n)
+    mean_all = sums.sum(axis=0) / n_tot
+    cv = (outer.sum(axis=0) - n_tot * np.outer(mean_all, mean_all)) / (n_tot - 1.0)
+    np.testing.assert_allclose(cv, np.cov(X.T), rtol=1e-6, atol=1e-9)
+    # the per-cluster OU objective from the device's moments vs from the cluster's rows
+    tree = PhyloTree(synthetic.tree_for(S))
+    rng = np.random.default_rng(0)
+    for c in (0, 7, 19):
+        rows = X[lab == c]
+        o1 = mstep.OUObjectiveSingle(tree, rows)
+        o2 = mstep.OUObjectiveSingle.from_moments(tree, sums[c] / counts[c], outer[c] / counts[c])
+        p = np.clip(synthetic.sample_ou_params(rng, tree, 1)[0], 1e-3, 50)
+        f1, g1 = o1.value_and_grad(p)
+        f2, g2 = o2.value_and_grad(p)
+        np.testing.assert_allclose(f2, f1, rtol=1e-6)
+        np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fits_from_the_default_and_the_verbatim_initialiser_agree(seed):
+    """The whole fit from the default initialiser against the fit from the reference's initialisation verbatim (same
+    seed, data, K, --miter): the same centres and (up to ties) labels, the per-cluster OU fits from moments instead of
+    rows -- the runs end at best cost1 values within 3 % of each other."""
+    import phylo_hmrf as cli
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    K = 5
+    X, len_vec, edge_list_vec, tree = cli.synthetic_cache(90, 4, K, 8, seed)
+    n = X.shape[0]
+    best, init = {}, {}
+    for method in ("sklearn", "minibatch"):
+        m = phyloHMRF(n_components=K, run_id=0, n_samples=n, n_features=4, observation=X, edge_list=tree, len_vec=len_vec,
+                      type_id=1, branch_list=[1.0] * 7, edge_list_1=edge_list_vec, cons_param=1.0, beta=1.0, beta1=0.5,
+                      initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, learning_rate=0.001,
+                      estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, random_state=seed, quiet=True,
+                      mstep_workers=1, init_method=method)
+        res = m.fit_accumulate_test(X, len_vec, 1e-3, "t", 8)
+        best[method] = float(res[5][:, 3].min())
+        init[method] = m.init_label.copy()
+        m.close()
+    assert (init["sklearn"] != init["minibatch"]).mean() < 1e-3
+    print("seed %d: best cost1  verbatim %.4f   default %.4f" % (seed, best["sklearn"], best["minibatch"]))
+    assert abs(best["minibatch"] - best["sklearn"]) <= 0.03 * abs(best["sklearn"])
