@@ -379,6 +379,7 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->logprob);
   dev_free(b->labels);
   dev_free(b->labels_tmp);
+  dev_free(b->sgain);
   for (int s = 0; s < 4; ++s) dev_free(b->saved[s]);
   dev_free(b->nbr);
   dev_free(b->wgt);

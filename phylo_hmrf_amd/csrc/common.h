@@ -71,6 +71,7 @@ struct phmrf_block {
   float* logprob = nullptr;
   uint8_t* labels = nullptr;
   uint8_t* labels_tmp = nullptr;
+  float* sgain = nullptr;                   // device [n]: cost of switching a node alone to its fusion proposal (launch_propose)
   uint8_t* saved[4] = {nullptr, nullptr, nullptr, nullptr};
   bool has_X = false, has_logprob = false, has_labels = false, has_graph = false, has_grid = false;
 

@@ -1169,6 +1169,12 @@ struct ColsLds {
   unsigned char slabl[SLABL];                // ... and label bytes of the staged rectangle
 };
 
+// ... and of fusion_cols_kernel: the same, plus the proposal byte of every staged cell
+struct FusLds {
+  ColsLds c;
+  unsigned char slabp[SLABL];
+};
+
 template <int P, int C, int... TT>
 __device__ __forceinline__ void dp_chunk_steps(float& m, unsigned long long& took, int lane, const char* tabc,
                                                std::integer_sequence<int, TT...>) {
@@ -1249,11 +1255,77 @@ __device__ __forceinline__ void dp_pass_chunked(float& m, unsigned long long& to
   dp_chunk<P, 3, RECORD>(m, took, lane, tabch, c0, c1, wu, wlu, wl, wld, bits, t_lo, t_end, dlo, dhi, live, dp_wk, dp_t0);
 }
 
+// ---- the exact filter on one strip, lane <-> strip column (shared by strip_cols_kernel and fusion_cols_kernel) -------
+// cap_r (the discount sum over the in-strip neighbours that are still in U) lives in a register per row; a pass tests
+// every row against its cap and SUBTRACTS the contributions of the cells it deletes from the caps of the rows around them
+// (three selects and at most eight multiply-adds per row that lost a cell; a row that lost none costs nothing, and the pass
+// that confirms the fixed point is twenty instructions).  Rows from the outside in (0, 4, 1, 3, 2): a strip's edge rows have
+// the fewest in-strip neighbours, the peeling runs from them towards the middle row and gets there within one pass.  Any
+// order and any stale (too large) cap is sound: U only ever loses cells that cannot be in a switching set.
+//
+// peel_drop<R>: the cells of row R in `del` leave U: their discounts come off the caps of the rows R - 1, R, R + 1
+// (a cell of row r' is the d = 5 / 6 / 7 neighbour of row r' - 1, the d = 3 / 4 neighbour of row r', the d = 0 / 1 / 2
+//  neighbour of row r' + 1; (dr, dc) of d: 0 (-1,-1) 1 (-1,0) 2 (-1,+1) 3 (0,-1) 4 (0,+1) 5 (+1,-1) 6 (+1,0) 7 (+1,+1))
+template <int R>
+__device__ __forceinline__ void peel_drop(float (&cap)[SH], const float (&v8)[SH][8], unsigned long long del) {
+  if (del == 0ull) return;
+  const float gl = __builtin_amdgcn_inverse_ballot_w64(del << 1) ? -1.f : 0.f;   // column c - 1 leaves
+  const float gc = __builtin_amdgcn_inverse_ballot_w64(del) ? -1.f : 0.f;
+  const float gr = __builtin_amdgcn_inverse_ballot_w64(del >> 1) ? -1.f : 0.f;   // column c + 1 leaves
+  if (R > 0) {
+    constexpr int A = R > 0 ? R - 1 : 0;
+    cap[A] = __builtin_fmaf(gl, v8[A][5], cap[A]);
+    cap[A] = __builtin_fmaf(gc, v8[A][6], cap[A]);
+    cap[A] = __builtin_fmaf(gr, v8[A][7], cap[A]);
+  }
+  cap[R] = __builtin_fmaf(gl, v8[R][3], cap[R]);
+  cap[R] = __builtin_fmaf(gr, v8[R][4], cap[R]);
+  if (R < SH - 1) {
+    constexpr int B = R < SH - 1 ? R + 1 : 0;
+    cap[B] = __builtin_fmaf(gl, v8[B][0], cap[B]);
+    cap[B] = __builtin_fmaf(gc, v8[B][1], cap[B]);
+    cap[B] = __builtin_fmaf(gr, v8[B][2], cap[B]);
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void peel_row(const float (&sc)[SH], const float (&v8)[SH][8], float (&cap)[SH],
+                                         unsigned long long (&U)[SH], unsigned long long& seeds, unsigned long long& gone) {
+  // (a hair of slack for the f32 sums: the caps are carried by subtraction, so the slack has an absolute part that covers
+  //  eight roundings at the largest cap a strip can have)
+  const float capx = __builtin_fmaf(cap[R], 1.0001f, 2e-5f);
+  const unsigned long long keep = __ballot(sc[R] <= capx);
+  const unsigned long long sd = __ballot(sc[R] < 0.5f * capx);
+  const unsigned long long del = U[R] & ~keep;
+  U[R] &= keep;
+  seeds |= U[R] & sd;
+  gone |= del;
+  peel_drop<R>(cap, v8, del);
+}
+
+// -> true: no seed is left (no improving switching set exists on this strip); false: the DP has to decide, on U
+__device__ __forceinline__ bool peel_strip(const float (&sc)[SH], const float (&v8)[SH][8], float (&cap)[SH],
+                                           unsigned long long (&U)[SH], int peel_max) {
+  for (int it = 0; it < peel_max; ++it) {
+    unsigned long long seeds = 0ull, gone = 0ull;
+    peel_row<0>(sc, v8, cap, U, seeds, gone);
+    peel_row<4>(sc, v8, cap, U, seeds, gone);
+    peel_row<1>(sc, v8, cap, U, seeds, gone);
+    peel_row<3>(sc, v8, cap, U, seeds, gone);
+    peel_row<2>(sc, v8, cap, U, seeds, gone);
+    if (!seeds) return true;
+    if (!gone) break;
+  }
+  return false;
+}
+
 // cell record of the DP for cell t of the strip, straight from the staged slab (strip_kernel's step B with a constant
 // proposal alpha and the cells outside U pinned)
-template <int ORIENT>
-__device__ __forceinline__ void slab_record(const float* slabw, const unsigned char* slabl, int t, int ncols, int ncell, int alpha, bool in_u, float u0,
-                                            float u1, bool have, float& c0, float& c1, float (&w4)[4], int& bits) {
+// FUSION: every cell has a proposal of its own (slabp) instead of the constant alpha.
+template <int ORIENT, bool FUSION>
+__device__ __forceinline__ void slab_record(const float* slabw, const unsigned char* slabl, const unsigned char* slabp, int t, int ncols,
+                                            int ncell, int alpha, bool in_u, float u0, float u1, bool have, float& c0, float& c1,
+                                            float (&w4)[4], int& bits) {
   c0 = 0.f;
   c1 = BIG;
   w4[0] = w4[1] = w4[2] = w4[3] = 0.f;
@@ -1262,6 +1334,7 @@ __device__ __forceinline__ void slab_record(const float* slabw, const unsigned c
   const int cc = t / SH, rr = t - cc * SH;
   const int e0 = (cc + 1) * EH + (rr + 1), w0 = (cc + 1) * SWC + (rr + 1) * 4;
   const int l = slabl[e0];
+  const int pl = FUSION ? (int)slabp[e0] : alpha;
   float a0 = 0.f, a1 = 0.f;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
@@ -1281,15 +1354,16 @@ __device__ __forceinline__ void slab_record(const float* slabw, const unsigned c
     constexpr int QOF[8] = {1, 0, -1, 2, -1, 3, -1, -1};
     if (QOF[d] >= 0 && inside) {
       w4[QOF[d] >= 0 ? QOF[d] : 0] = w;
-      const int nib = (l != lj ? 1 : 0) | (l != alpha ? 2 : 0) | (alpha != lj ? 4 : 0);
+      const int pj = FUSION ? (int)slabp[en] : alpha;
+      const int nib = (l != lj ? 1 : 0) | (l != pj ? 2 : 0) | (pl != lj ? 4 : 0) | (pl != pj ? 8 : 0);
       bits |= nib << (4 * (QOF[d] >= 0 ? QOF[d] : 0));
     }
     if (!inside) {
       if (l != lj) a0 += w;
-      if (alpha != lj) a1 += w;
+      if (pl != lj) a1 += w;
     }
   }
-  const bool can = in_u && l != alpha && u1 < 1.0e29f;
+  const bool can = in_u && l != pl && u1 < 1.0e29f;
   c0 = u0 + a0;
   c1 = can ? u1 + a1 : BIG;
 }
@@ -1299,20 +1373,20 @@ __device__ __forceinline__ void slab_record(const float* slabw, const unsigned c
 #ifndef PHMRF_DP_INLINE
 #define PHMRF_DP_INLINE __noinline__
 #endif
-template <int ORIENT>
+template <int ORIENT, bool FUSION>
 __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds, int kb, int lane,
                                                    int rs0, int ca, int ncols, int ncell, int alpha, int tick_a, int64_t n, int D,
                                                    const int32_t* nbr_, const float* uT_, uint8_t* labels_, uint16_t* stamp_,
-                                                   uint16_t* mrow_, unsigned long long* changed_) {
+                                                   uint16_t* mslot_, unsigned long long* changed_slot) {
     const global_ptr<const int32_t> nbr = as_global(nbr_);
     const global_ptr<const float> uT = as_global(uT_);
     const global_ptr<uint8_t> labels = as_global(labels_);
     const global_ptr<uint16_t> stamp = as_global(stamp_);
-    const global_ptr<uint16_t> mrow = as_global(mrow_);
-    unsigned long long* __restrict__ changed = changed_;
+    const global_ptr<uint16_t> mslot = as_global(mslot_);       // this move's memo entry (label alpha's, or the fusion pass's)
     ColsLds* L = lds_object<ColsLds>(lds);
     const float* slabw = L->slabw;
     const unsigned char* slabl = L->slabl;
+    const unsigned char* slabp = FUSION ? lds_object<FusLds>(lds)->slabp : L->slabl;
     float* tabch = L->tabch;
     const unsigned long long* ub = L->ubuf[kb];
     unsigned int* wk = L->wk;
@@ -1340,7 +1414,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
       }
     }
     if (t_hi < 0) {
-      if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+      if (mslot && lane == 0) *mslot = (uint16_t)tick_a;
       return 0u;
     }
     int t_end = t_hi + SH + 1;
@@ -1358,9 +1432,9 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
 #endif
 #ifdef PHMRF_DP_COUNT
     if (lane == 0) {                     // development build: solver-trace counters (PHMRF_SOLVE_TRACE)
-      atomicAdd(changed - 8 + 100, 1ull);
-      atomicAdd(changed - 8 + 102, 1ull);
-      atomicAdd(changed - 8 + 103, (unsigned long long)(t_end - t_lo + 1));
+      atomicAdd(changed_slot - (FUSION ? 0 : alpha) - 8 + 100, 1ull);
+      atomicAdd(changed_slot - (FUSION ? 0 : alpha) - 8 + 102, 1ull);
+      atomicAdd(changed_slot - (FUSION ? 0 : alpha) - 8 + 103, (unsigned long long)(t_end - t_lo + 1));
     }
 #endif
     // which table chunks hold, or directly follow, a cell of U (see dp_chunk)
@@ -1390,7 +1464,8 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
       const int e0 = (cc + 1) * EH + (rr + 1);
       const int l = nd >= 0 ? (int)slabl[e0] : 0;
       ru0[p] = uT[(int64_t)l * n + (nd >= 0 ? nd : 0)];
-      ru1[p] = (uT + (int64_t)alpha * n)[nd >= 0 ? nd : 0];
+      const int pl = FUSION ? (nd >= 0 ? (int)slabp[e0] : 0) : alpha;
+      ru1[p] = uT[(int64_t)pl * n + (nd >= 0 ? nd : 0)];
       havem |= (nd >= 0 ? 1u : 0u) << p;
       havem |= (inu[p] ? 1u : 0u) << (8 + p);
     }
@@ -1401,7 +1476,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
     asm volatile("" : "+v"(t));                                                                                        \
     float w4[4], c0, c1;                                                                                               \
     int bits;                                                                                                          \
-    slab_record<ORIENT>(slabw, slabl, t, ncols, ncell, alpha, (havem >> (8 + P_)) & 1u, ru0[P_], ru1[P_], (havem >> P_) & 1u,   \
+    slab_record<ORIENT, FUSION>(slabw, slabl, slabp, t, ncols, ncell, alpha, (havem >> (8 + P_)) & 1u, ru0[P_], ru1[P_], (havem >> P_) & 1u,   \
                         c0, c1, w4, bits);                                                                             \
     DPH(2)                                                                                                             \
     dp_pass_chunked<P_, REC_>(m, took, lane, tabch, c0, c1, w4[0], w4[1], w4[2], w4[3], bits, t_lo, t_end, dlo[P_],     \
@@ -1416,11 +1491,11 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
     PHMRF_DP_PASS(0, false) PHMRF_DP_PASS(1, false) PHMRF_DP_PASS(2, false) PHMRF_DP_PASS(3, false) PHMRF_DP_PASS(4, false)
     const float mmin = wave_min_f32(m);
     if (!(took & 1ull) && PHMRF_RL(m, 0) == mmin) {
-      if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
+      if (mslot && lane == 0) *mslot = (uint16_t)tick_a;
       return 0u;
     }
 #ifdef PHMRF_DP_COUNT
-    if (lane == 0) atomicAdd(changed - 8 + 104, 1ull);
+    if (lane == 0) atomicAdd(changed_slot - (FUSION ? 0 : alpha) - 8 + 104, 1ull);
 #endif
     DPH(4)
     // a move exists: walk again, this time recording the decision ballots
@@ -1452,7 +1527,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
         const int cc = t / SH, rr = t - cc * SH;
         const int node = strip_node(g, rs0 + rr, ca + cc);
         if (node >= 0) {
-          labels[node] = (uint8_t)alpha;
+          labels[node] = FUSION ? slabp[(cc + 1) * EH + (rr + 1)] : (uint8_t)alpha;
           if (stamp) {
             stamp[node] = (uint16_t)tick_a;
             const global_ptr<const int32_t> nb2 = nbr + (int64_t)node * D;
@@ -1466,8 +1541,8 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) my_changed += __shfl_xor(my_changed, off, 64);
     if (lane == 0) {
-      if (my_changed) atomicAdd(changed + alpha, (unsigned long long)my_changed);
-      if (mrow) mrow[alpha] = my_changed ? (uint16_t)0 : (uint16_t)tick_a;
+      if (my_changed) atomicAdd(changed_slot, (unsigned long long)my_changed);
+      if (mslot) *mslot = my_changed ? (uint16_t)0 : (uint16_t)tick_a;
     }
     DPH(5)
     return my_changed;
@@ -1639,72 +1714,20 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
 #pragma unroll
         for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
       }
-      // ---- the filter, incrementally: cap_r (the discount sum over the in-strip neighbours that are still in U) lives in
-      //      a register per row; a pass tests every row against its cap and SUBTRACTS the contributions of the cells it
-      //      deletes from the caps of the rows around them (three selects and at most eight multiply-adds per row that
-      //      lost a cell; a row that lost none costs nothing, and the pass that confirms the fixed point is twenty
-      //      instructions).  Rows from the outside in (0, 4, 1, 3, 2): a strip's edge rows have the fewest in-strip
-      //      neighbours, the peeling runs from them towards the middle row and gets there within one pass.  Any order and
-      //      any stale (too large) cap is sound: U only ever loses cells that cannot be in a switching set.
-      //      The caps start from the label-independent sum over ALL in-strip neighbours, minus -- for a label that
-      //      occurs in the rectangle -- the cells that carry it.
-      bool quiet = false;
+      // ---- the filter (peel_strip): the caps start from the label-independent sum over ALL in-strip neighbours, minus --
+      //      for a label that occurs in the rectangle -- the cells that carry it
       FPH(3)
       float cap[SH];
 #pragma unroll
       for (int r = 0; r < SH; ++r) cap[r] = capf[r];
-      // the cells of row R_ in the mask DEL_ leave U: their discounts come off the caps of the rows R_ - 1, R_, R_ + 1
-      // (a cell of row r' is the d = 5 / 6 / 7 neighbour of row r' - 1, the d = 3 / 4 neighbour of row r', the d = 0 / 1 / 2
-      //  neighbour of row r' + 1; (dr, dc) of d: 0 (-1,-1) 1 (-1,0) 2 (-1,+1) 3 (0,-1) 4 (0,+1) 5 (+1,-1) 6 (+1,0) 7 (+1,+1))
-#define PHMRF_DROP(R_, DEL_)                                                                                      \
-  if ((DEL_) != 0ull) {                                                                                           \
-    const float gl = __builtin_amdgcn_inverse_ballot_w64((DEL_) << 1) ? -1.f : 0.f;   /* column c - 1 leaves */   \
-    const float gc = __builtin_amdgcn_inverse_ballot_w64(DEL_) ? -1.f : 0.f;                                      \
-    const float gr = __builtin_amdgcn_inverse_ballot_w64((DEL_) >> 1) ? -1.f : 0.f;   /* column c + 1 leaves */   \
-    if (R_ > 0) {                                                                                                 \
-      cap[R_ > 0 ? R_ - 1 : 0] = __builtin_fmaf(gl, v8[R_ > 0 ? R_ - 1 : 0][5], cap[R_ > 0 ? R_ - 1 : 0]);       \
-      cap[R_ > 0 ? R_ - 1 : 0] = __builtin_fmaf(gc, v8[R_ > 0 ? R_ - 1 : 0][6], cap[R_ > 0 ? R_ - 1 : 0]);       \
-      cap[R_ > 0 ? R_ - 1 : 0] = __builtin_fmaf(gr, v8[R_ > 0 ? R_ - 1 : 0][7], cap[R_ > 0 ? R_ - 1 : 0]);       \
-    }                                                                                                             \
-    cap[R_] = __builtin_fmaf(gl, v8[R_][3], cap[R_]);                                                             \
-    cap[R_] = __builtin_fmaf(gr, v8[R_][4], cap[R_]);                                                             \
-    if (R_ < SH - 1) {                                                                                            \
-      cap[R_ < SH - 1 ? R_ + 1 : 0] = __builtin_fmaf(gl, v8[R_ < SH - 1 ? R_ + 1 : 0][0], cap[R_ < SH - 1 ? R_ + 1 : 0]); \
-      cap[R_ < SH - 1 ? R_ + 1 : 0] = __builtin_fmaf(gc, v8[R_ < SH - 1 ? R_ + 1 : 0][1], cap[R_ < SH - 1 ? R_ + 1 : 0]); \
-      cap[R_ < SH - 1 ? R_ + 1 : 0] = __builtin_fmaf(gr, v8[R_ < SH - 1 ? R_ + 1 : 0][2], cap[R_ < SH - 1 ? R_ + 1 : 0]); \
-    }                                                                                                             \
-  }
       if (present) {
-        PHMRF_DROP(0, valid[0] & ~U[0]) PHMRF_DROP(1, valid[1] & ~U[1]) PHMRF_DROP(2, valid[2] & ~U[2])
-        PHMRF_DROP(3, valid[3] & ~U[3]) PHMRF_DROP(4, valid[4] & ~U[4])
+        peel_drop<0>(cap, v8, valid[0] & ~U[0]);
+        peel_drop<1>(cap, v8, valid[1] & ~U[1]);
+        peel_drop<2>(cap, v8, valid[2] & ~U[2]);
+        peel_drop<3>(cap, v8, valid[3] & ~U[3]);
+        peel_drop<4>(cap, v8, valid[4] & ~U[4]);
       }
-      for (int it = 0; it < peel_max; ++it) {
-#ifdef PHMRF_PHASE_CLOCK
-        if (lane == 0) atomicAdd(&wk[0], 1u << 12);     // passes, in units of 4096 next to the pair count
-#endif
-        unsigned long long seeds = 0ull, gone = 0ull;
-        // (a hair of slack for the f32 sums: the caps are carried by subtraction, so the slack has an absolute part that
-        //  covers eight roundings at the largest cap a strip can have)
-#define PHMRF_ROW(R_)                                                                                   \
-  {                                                                                                     \
-    const float capx = __builtin_fmaf(cap[R_], 1.0001f, 2e-5f);                                         \
-    const unsigned long long keep = __ballot(sc[R_] <= capx);                                           \
-    const unsigned long long sd = __ballot(sc[R_] < 0.5f * capx);                                       \
-    const unsigned long long del = U[R_] & ~keep;                                                       \
-    U[R_] &= keep;                                                                                      \
-    seeds |= U[R_] & sd;                                                                                \
-    gone |= del;                                                                                        \
-    PHMRF_DROP(R_, del)                                                                                 \
-  }
-        PHMRF_ROW(0) PHMRF_ROW(4) PHMRF_ROW(1) PHMRF_ROW(3) PHMRF_ROW(2)
-#undef PHMRF_ROW
-        if (!seeds) {
-          quiet = true;
-          break;
-        }
-        if (!gone) break;
-      }
-#undef PHMRF_DROP
+      const bool quiet = peel_strip(sc, v8, cap, U, peel_max);
       FPH(2)
       if (quiet) {
         quiet_mask |= 1ull << alpha;
@@ -1903,8 +1926,8 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 #endif
       for (int kb = 0; kb < nbuf; ++kb) {
         const int alpha = __builtin_amdgcn_readfirstlane(abuf[kb]);
-        const unsigned int my_changed = dp_flagged<ORIENT>(g, lds, kb, lane, rs0, ca, ncols, ncell, alpha, tick0 + alpha, n, D, nbr, uT,
-                                                           labels, stamp, mrow, changed);
+        const unsigned int my_changed = dp_flagged<ORIENT, false>(g, lds, kb, lane, rs0, ca, ncols, ncell, alpha, tick0 + alpha, n, D, nbr,
+                                                                  uT, labels, stamp, mrow ? mrow + alpha : nullptr, changed + alpha);
         PH(4)
         if (my_changed) {
           // the labels of this strip have changed: everything later is filtered again on the new labelling
@@ -1927,6 +1950,219 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 #endif
 #endif
 #undef PH
+  __syncthreads();
+  if (work && threadIdx.x < WORK_SLOTS) {
+    const unsigned int v = wk[threadIdx.x];
+    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + threadIdx.x, (unsigned long long)v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fusion_cols_kernel (round 3): the FUSION pass -- every cell keeps its label or takes its proposal (its best alternative
+// label, launch_propose) -- with the exact filter of the expansions in front of the DP.
+//
+// A cell's single-site cost s_i (switch i alone to p_i) and, per in-strip edge, what the pair saves against the sum of the
+// two single-site costs when both ends switch,  disc_ij = w ([p_i != l_j] + [l_i != p_j] - [l_i != l_j] - [p_i != p_j]),
+// play the parts they play in strip_cols_kernel.  disc_ij can be negative here (the pair table of a fusion move need not
+// be submodular); the filter uses max(0, disc_ij): every bound it relies on -- a member of an optimal switching set cannot
+// leave at a profit, an improving set has a seed -- only gets weaker with a larger discount, so the deletion stays sound
+// and the DP (exact for any 2 x 2 tables) decides what is left.  At the warm start of an EM iteration the proposals are
+// near-ICM-optimal alternatives, s_i >= 0 almost everywhere, and most strips are settled by the filter: the pass no longer
+// walks 315 DP steps per strip to find nothing.
+#ifndef PHMRF_FUSION_WPE
+#define PHMRF_FUSION_WPE 4
+#endif
+template <int ORIENT>
+__global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(StripGeom g, int64_t n, int K, int D,
+                                                                          const int32_t* __restrict__ nbr,
+                                                                          const float4* __restrict__ fwd_w,
+                                                                          const float* __restrict__ uT, uint8_t* __restrict__ labels,
+                                                                          const uint8_t* __restrict__ prop,
+                                                                          const float* __restrict__ sgain, float beta,
+                                                                          unsigned long long* __restrict__ changed,
+                                                                          uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
+                                                                          int tick, unsigned long long* __restrict__ work, int peel_max) {
+  __shared__ FusLds lds_pool;
+  float* slabw = lds_pool.c.slabw;
+  unsigned char* slabl = lds_pool.c.slabl;
+  unsigned char* slabp = lds_pool.slabp;
+  unsigned int* wk = lds_pool.c.wk;
+  const unsigned int lds = lds_address_of(&lds_pool);
+  const int lane = threadIdx.x & 63;
+  const int nstrips = g.nbands * g.nsegs;
+  if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
+  __syncthreads();
+
+  for (int strip_v = blockIdx.x; strip_v < nstrips; strip_v += gridDim.x) {
+    const int strip = __builtin_amdgcn_readfirstlane(strip_v);
+    const int bnd = strip / g.nsegs;
+    const int seg = strip - bnd * g.nsegs;
+    const int rs0 = bnd * (SH + 1) - g.shift_r;
+    const int cs0 = seg * 64 - g.shift_c;
+    const int ca = cs0 > 0 ? cs0 : 0;
+    const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
+    const int ncols = cb > ca ? cb - ca : 0;
+    const int ncell = ncols * SH;
+    if (ncell <= 0) continue;
+
+    // ---- column layout, memo test (slot K of the strip's memo row: the fusion pass)
+    unsigned long long valid[SH];
+    int ndx[SH];
+    uint16_t* mslot = memo ? memo + (int64_t)strip * (K + 1) + K : nullptr;
+#pragma unroll
+    for (int r = 0; r < SH; ++r) ndx[r] = lane < ncols ? strip_node(g, rs0 + r, ca + lane) : -1;
+    if (mslot) {
+      const int last_quiet = *mslot;
+      if (last_quiet) {
+        int nw = 0;
+#pragma unroll
+        for (int r = 0; r < SH; ++r) {
+          const int st = stamp[ndx[r] >= 0 ? ndx[r] : 0];
+          nw = (ndx[r] >= 0 && st > nw) ? st : nw;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const int o2 = __shfl_xor(nw, off, 64);
+          nw = o2 > nw ? o2 : nw;
+        }
+        if (nw < last_quiet) continue;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < SH; ++r) valid[r] = __ballot(ndx[r] >= 0);
+
+    // ---- staging: labels, proposals and forward weights of the strip's rectangle and rim -> LDS
+    {
+      constexpr int NEP = (ECELLS + 63) / 64;
+      int enode[NEP], eidx[NEP];
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {
+        int er, ec;
+        if (ORIENT == 0) {
+          int l2 = lane;
+          asm volatile("" : "+v"(l2));
+          er = q < EH ? q : l2;
+          ec = q < EH ? l2 : 64;
+          if (q >= EH && l2 >= EH) ec = 1 << 20;
+        } else {
+          int e = q * 64 + lane;
+          asm volatile("" : "+v"(e));
+          ec = e / EH;
+          er = e - ec * EH;
+        }
+        const bool have = ec < ncols + 2;
+        eidx[q] = have ? ec * EH + er : -1;
+        enode[q] = have ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
+      }
+      int elab[NEP], epl[NEP];
+      float4 ef[NEP];
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {
+        const int node = enode[q];
+        elab[q] = 0;
+        epl[q] = 0;
+        ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node >= 0) {
+          elab[q] = labels[node];
+          epl[q] = prop[node];
+          ef[q] = fwd_w[node];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {
+        const int e = eidx[q];
+        if (e >= 0) {
+          const int ec = e / EH, er = e - ec * EH;
+          float* wr = slabw + ec * SWC + er * 4;
+          if (er < EH - 1) {
+            wr[0] = ef[q].x * beta;
+            wr[1] = ef[q].y * beta;
+            wr[2] = ef[q].z * beta;
+            wr[3] = ef[q].w * beta;
+          } else {
+            wr[0] = ef[q].y * beta;          // (the bottom rim row's one needed weight: see strip_cols_kernel)
+          }
+          slabl[e] = (unsigned char)(enode[q] >= 0 ? elab[q] : 0);
+          slabp[e] = (unsigned char)(enode[q] >= 0 ? epl[q] : 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      atomicAdd(&wk[0], 1u);
+      atomicAdd(&wk[1], (unsigned int)ncell);                  // nodes this unit re-decides
+      atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));     // the staged rectangle
+    }
+
+    // ---- extraction, lane <-> column: single-site costs, clipped pair discounts, the cells that have a proposal
+    float v8[SH][8], sc[SH], cap[SH];
+    unsigned long long U[SH];
+    {
+      const bool act = lane < ncols;
+      float sg[SH];
+      int pl_[SH], l_[SH];
+#pragma unroll
+      for (int r = 0; r < SH; ++r) {
+        const int e0 = (lane + 1) * EH + (r + 1);
+        const bool have = (valid[r] >> lane) & 1ull;
+        l_[r] = have ? (int)slabl[act ? e0 : 0] : 0;
+        pl_[r] = have ? (int)slabp[act ? e0 : 0] : 0;
+        // the single-site cost of the proposal, as the proposal kernel found it (five row loads, contiguous in orientation
+        // 0; no gathers into the unary planes -- those are left to the rare DP)
+        sg[r] = sgain[have ? ndx[r] : 0];
+      }
+#pragma unroll
+      for (int r = 0; r < SH; ++r) {
+        const bool have = (valid[r] >> lane) & 1ull;
+        float cf = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) v8[r][d] = 0.f;
+        if (have && pl_[r] != l_[r]) {
+          const int e0 = (lane + 1) * EH + (r + 1), w0 = (lane + 1) * SWC + (r + 1) * 4;
+          const int l = l_[r], pl = pl_[r];
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+            constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+            const int dr = DR[d], dc = DC[d];
+            if (r + dr < 0 || r + dr >= SH) continue;              // a rim neighbour is never in U
+            const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;
+            const bool fwd = di > 0 || (di == 0 && dj > 0);
+            const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
+            const int en = e0 + dc * EH + dr, wn = w0 + dc * SWC + dr * 4;
+            const float w = fwd ? slabw[w0 + comp] : slabw[wn + comp];
+            const int lj = slabl[en], pj = slabp[en];
+            const bool inside = (lane + dc >= 0) && (lane + dc < ncols);
+            // what the pair saves when both ends switch, clipped at 0 (an absent or proposal-less neighbour is never in U)
+            const float disc = w * ((pl != lj ? 1.f : 0.f) + (l != pj ? 1.f : 0.f) - (l != lj ? 1.f : 0.f) - (pl != pj ? 1.f : 0.f));
+            const float dp = (inside && pj != lj) ? fmaxf(disc, 0.f) : 0.f;
+            v8[r][d] = dp;
+            cf += dp;
+          }
+        }
+        sc[r] = sg[r];
+        cap[r] = cf;
+        U[r] = valid[r] & __ballot(have && pl_[r] != l_[r] && sg[r] < 1.0e29f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // (cap holds the discounts of all in-strip neighbours that have a proposal = exactly the neighbours in the first U)
+    const bool quiet = !(U[0] | U[1] | U[2] | U[3] | U[4]) || peel_strip(sc, v8, cap, U, peel_max);
+    if (quiet) {
+      if (mslot && lane == 0) *mslot = (uint16_t)tick;
+      continue;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < SH; ++r) lds_pool.c.ubuf[0][r] = U[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    dp_flagged<ORIENT, true>(g, lds, 0, lane, rs0, ca, ncols, ncell, -1, tick, n, D, nbr, uT, labels, stamp, mslot, changed);
+    __builtin_amdgcn_wave_barrier();
+  }
   __syncthreads();
   if (work && threadIdx.x < WORK_SLOTS) {
     const unsigned int v = wk[threadIdx.x];
@@ -1959,7 +2195,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                       const uint8_t* __restrict__ labels, float beta,
                                                       uint8_t* __restrict__ prop, const uint16_t* __restrict__ stamp,
-                                                      int since, unsigned long long* __restrict__ work) {
+                                                      int since, unsigned long long* __restrict__ work, float* __restrict__ sgain) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   const int KV = K / VEC;
@@ -2004,6 +2240,8 @@ __global__ __launch_bounds__(256) void propose_kernel(const float* __restrict__ 
         if (k != cur && v < best) { best = v; bk = k; }
       }
       prop[i] = (uint8_t)bk;
+      // what switching the node alone to its proposal costs (>= 0 at an ICM fixed point): the fusion pass's filter reads it
+      if (sgain) sgain[i] = bk != cur ? best - row[cur] : 1.0e30f;
     }
     __syncthreads();
   }
@@ -2018,7 +2256,7 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
                                                            int diagonal, const float4* __restrict__ fwd_w,
                                                            const uint8_t* __restrict__ labels, float beta,
                                                            uint8_t* __restrict__ prop, const uint16_t* __restrict__ stamp,
-                                                           int since, unsigned long long* __restrict__ work) {
+                                                           int since, unsigned long long* __restrict__ work, float* __restrict__ sgain) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   unsigned int done = 0u;
@@ -2056,6 +2294,7 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
         if (k != cur && x < best) { best = x; bk = k; }
       }
       prop[v] = (uint8_t)bk;
+      if (sgain) sgain[v] = bk != cur ? best - row[cur] : 1.0e30f;
     }
   }
   if (work && threadIdx.x == 0 && done) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + 6, (unsigned long long)done);
@@ -2067,20 +2306,21 @@ inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 int launch_propose(phmrf_block* b, float beta) {
   const int since = b->tick ? b->prop_tick : -1;
+  if (!b->sgain) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->sgain), (size_t)b->n * sizeof(float)));
   const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
   const size_t lds = (size_t)TB * Kp * sizeof(float);
   int64_t g64 = (b->n + TB - 1) / TB;
   const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
   if (b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->D == 8) {
     hipLaunchKernelGGL(propose_grid_kernel, dim3(grid), dim3(TB), lds, b->stream, b->uT, b->n, K, Kp, b->H, b->W, b->diagonal,
-                       b->fwd_w, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc);
+                       b->fwd_w, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc, b->sgain);
     PHMRF_HIP(hipGetLastError());
     b->prop_tick = b->tick ? b->tick : -1;
     return PHMRF_OK;
   }
 #define PHMRF_LAUNCH_PROP(VEC_)                                                                                     \
   hipLaunchKernelGGL((propose_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
-                     b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc)
+                     b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc, b->sgain)
   switch (vec_of(K)) {
     case 4: PHMRF_LAUNCH_PROP(4); break;
     case 2: PHMRF_LAUNCH_PROP(2); break;
@@ -2159,6 +2399,22 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   int grid = (nstrips + WPB - 1) / WPB;
   if (grid > (1 << 22)) grid = 1 << 22;          // one workgroup per strip (see launch_strip_multi)
   const bool use_memo = b->tick && geom >= 0 && b->memo && (int64_t)nstrips <= b->memo_strips;
+  // the fusion pass of a solve (proposals in labels_tmp) runs behind the exact filter (fusion_cols_kernel); the
+  // single-label passes of the API and the coarse child problems keep strip_kernel.  PHMRF_FUSION_V=1: strip_kernel always.
+  static const int fusion_v = getenv("PHMRF_FUSION_V") ? atoi(getenv("PHMRF_FUSION_V")) : 2;
+  if (alpha < 0 && fusion_v != 1) {
+#define PHMRF_LAUNCH_FUSION(O_)                                                                                       \
+  hipLaunchKernelGGL((fusion_cols_kernel<O_>), dim3(grid), dim3(64), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,  \
+                     b->uT, b->labels, b->labels_tmp, b->sgain, beta, b->counters + b->counter_slot,                   \
+                     b->tick ? b->stamp : nullptr,                                                                    \
+                     use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr, b->tick, \
+                     b->work_acc, peel_sweeps())
+    if (orient) PHMRF_LAUNCH_FUSION(1);
+    else PHMRF_LAUNCH_FUSION(0);
+#undef PHMRF_LAUNCH_FUSION
+    PHMRF_HIP(hipGetLastError());
+    return PHMRF_OK;
+  }
 #define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
   hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
                      b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters + b->counter_slot,       \
