@@ -2263,9 +2263,12 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
   for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
     const int64_t rem = n - base;
     const int rows = rem < TB ? (int)rem : TB;
-    if (since >= 0 && !__syncthreads_or((int)threadIdx.x < rows && (int)stamp[base + threadIdx.x] > since)) continue;
-    done += (unsigned int)rows;
-    if ((int)threadIdx.x < rows) {
+    // (every thread works in its own LDS row: the "nothing changed here" test is per WAVE -- 64 consecutive nodes -- which
+    //  leaves far fewer nodes to recompute after a round of scattered changes than a test per 256-node tile)
+    const bool mine = (int)threadIdx.x < rows;
+    if (since >= 0 && !__any(mine && (int)stamp[base + threadIdx.x] > since)) continue;
+    if (mine) ++done;
+    if (mine) {
       const int64_t v = base + threadIdx.x;
       float* row = tile + threadIdx.x * Kp;
       // (loads first, uses after: a loop of load -> LDS store per label is one memory round trip per label and thread)
@@ -2297,7 +2300,12 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
       if (sgain) sgain[v] = bk != cur ? best - row[cur] : 1.0e30f;
     }
   }
-  if (work && threadIdx.x == 0 && done) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + 6, (unsigned long long)done);
+  {   // nodes recomputed by this workgroup (per-thread counts -> one add per wave)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off, 64);
+    if (work && (threadIdx.x & 63) == 0 && done)
+      atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + 6, (unsigned long long)done);
+  }
 }
 
 inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
