@@ -223,19 +223,29 @@ def main():
     runner = BlockRunner(a.block_threads, local_rank)
     order = sorted(range(len(blocks)), key=lambda i: -blocks[i].n)
 
+    block_trace = [] if os.environ.get("PHMRF_BLOCK_TRACE") else None      # development: (step start, block, n, t0, t1)
+
     def estep_block(i):
         b = blocks[i]
+        tb0 = time.time()
         b.restore_labels(SLOT_LOCAL)                           # init_labels = labels_local (phylo_hmrf.py:479)
         b.emission(state["means"], state["covars"])
         b.solve_fast(a.beta, **solver)
         b.posterior_stats_dev(a.beta, 3, stats_dev[i].data_ptr())
         b.sync()
+        if block_trace is not None:
+            block_trace.append((i, b.n, tb0, time.time()))
 
     cost1_log = []                                             # cost1 of every EM iteration (warm-up included)
 
     def em_step():
         t0 = time.time()
+        if block_trace is not None:
+            del block_trace[:]
         runner.map(estep_block, order)
+        if block_trace is not None and rank == 0:
+            sys.stderr.write("[block trace] E-step %.2f ms: " % ((time.time() - t0) * 1e3) + " ".join(
+                "%d:%.1fM[%.1f-%.1f]" % (i, n / 1e6, (s0 - t0) * 1e3, (s1 - t0) * 1e3) for i, n, s0, s1 in sorted(block_trace, key=lambda r: r[2])) + "\n")
         tot = stats_dev.sum(dim=0).to(coll_dev)
         if use_dist:
             dist.all_reduce(tot)                               # RCCL: K(1+S+S^2)+4 doubles

@@ -8,6 +8,7 @@ from phylo_hmrf_amd.tree import PhyloTree
 K, S, N = int(sys.argv[1]), 4, int(sys.argv[2])
 tol = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 expn = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+comp = int(sys.argv[5]) if len(sys.argv) > 5 else 1          # component moves in the WARM solve
 tree = PhyloTree(synthetic.tree_for(S)); rng = np.random.default_rng(0)
 P = synthetic.sample_ou_params(rng, tree, K); mu, cv = tree.mean_cov(P); cv = cv + 1e-3 * np.eye(S)
 P2 = np.clip(P * (1 + 0.15 * rng.standard_normal(P.shape)), 1e-3, 50); mu2, cv2 = tree.mean_cov(P2); cv2 = cv2 + 1e-3 * np.eye(S)
@@ -24,7 +25,7 @@ P3 = np.clip(P2 * (1 + float(os.environ.get("PHMRF_TRACE_PERT", "0.02")) * rng.s
 b.emission(mu3, cv3)
 sys.stderr.write("---- warm\n")
 b.reset_timing()
-res = b.solve(1.0, energy_tol_ppb=tol, init_mode=0, use_expansion=expn)
+res = b.solve(1.0, energy_tol_ppb=tol, init_mode=0, use_expansion=expn, use_components=bool(comp))
 print("warm solve:", res)
 stats, costs, _ = b.posterior_stats(1.0, 3)
 print("costs/n:", (costs / n).round(5))
