@@ -338,6 +338,49 @@ __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, co
   }
 }
 
+// The same two kernels on a grid block whose adjacency is the complete 8-neighbour stencil: the neighbours by geometry
+// (one byte of label each, rows of the label image the wave shares) instead of a 32-byte adjacency row per node.  Same
+// hooks as above, hence the same forest up to the order of the atomics and the same roots (a root is the smallest id).
+__global__ __launch_bounds__(256) void cc_init_grid_kernel(int32_t* __restrict__ comp, int64_t n, int W, int diagonal,
+                                                           const uint8_t* __restrict__ labels) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = base + lane;
+    bool linked = false;
+    if (v < n && v > 0) {
+      int i, j;
+      grid_coords(v, W, diagonal, &i, &j);
+      linked = j - 1 >= (diagonal ? i : 0) && labels[v - 1] == labels[v];
+    }
+    const unsigned long long starts = ~__ballot(linked);
+    const unsigned long long below = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int head = 63 - __clzll((long long)below);
+    if (v < n) comp[v] = head >= 0 ? (int)(base + head) : (lane == 0 ? (int)(v - 1) : (int)base);
+  }
+}
+
+__global__ void cc_union_grid_kernel(int32_t* __restrict__ comp, int64_t n, int W, int diagonal,
+                                     const uint8_t* __restrict__ labels) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    int i, j;
+    grid_coords(v, W, diagonal, &i, &j);
+    if (i == 0) continue;                                   // no row above: the runs of init are the components so far
+    const int64_t up = grid_row_base(i - 1, W, diagonal);
+    const bool has_w = j - 1 >= (diagonal ? i : 0), has_nw = j - 1 >= 0, has_ne = j + 1 < W;
+    const int l = labels[v];
+    const int lw = labels[has_w ? v - 1 : v], lnw = labels[has_nw ? up + j - 1 : v], ln = labels[up + j];
+    const int lne = labels[has_ne ? up + j + 1 : v];
+    int ri = -1;
+    if (has_w && lw == l) {       // linked left: only where an upper run STARTS at my up-right cell (see cc_union_kernel)
+      if (has_ne && ln != l && lne == l) cc_hook(comp, ri, (int)v, (int)(up + j + 1));
+      continue;
+    }
+    if (has_nw && lnw == l) cc_hook(comp, ri, (int)v, (int)(up + j - 1));
+    if (ln == l) cc_hook(comp, ri, (int)v, (int)(up + j));
+    if (has_ne && lne == l) cc_hook(comp, ri, (int)v, (int)(up + j + 1));
+  }
+}
+
 // flatten, and clear what the table / decide / block kernels accumulate into: only the ROOT rows of the move table are
 // ever used, so only those are zeroed (instead of a memset of n*K floats per pass)
 // Deterministic mode (PHMRF_DETERMINISTIC=1): the per-component sums are accumulated as 2^-16 fixed-point integers --
@@ -554,8 +597,10 @@ __global__ void comp_decide_kernel(const float* __restrict__ tab, int64_t n, int
       const float margin = 1e-5f * fabsf(tc) + 1e-6f;
       if (bk >= 0 && bv < tc - margin) g = bv - tc; else bk = -1;
     }
-    best[i] = bk;
-    gain[i] = g;
+    if (comp[i] == (int32_t)i) {        // (best / gain are read at roots only: comp_block, comp_apply)
+      best[i] = bk;
+      gain[i] = g;
+    }
   }
 }
 
@@ -596,11 +641,24 @@ __global__ void comp_apply_kernel(int64_t n, const int32_t* __restrict__ comp, c
                                   unsigned long long* __restrict__ changed, uint16_t* __restrict__ stamp, int tick,
                                   const int32_t* __restrict__ nbr, int D) {
   unsigned int mine = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = comp[i];
-    const int bk = best[ci];
-    if (bk >= 0 && !blocked[ci]) {
-      labels[i] = (uint8_t)bk;
+  // four nodes per thread and trip, their three dependent reads (root, its decision, its block flag) side by side: the
+  // kernel is three memory round trips per node and nothing else
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
+    int ci[U], bk[U];
+    bool go[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ci[u] = i0 + u * stride < n ? comp[i0 + u * stride] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) bk[u] = ci[u] >= 0 ? best[ci[u]] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) go[u] = bk[u] >= 0 && !blocked[ci[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!go[u]) continue;
+      const int64_t i = i0 + u * stride;
+      labels[i] = (uint8_t)bk[u];
       if (stamp) {
         stamp[i] = (uint16_t)tick;
         if (D <= 8) {
@@ -686,8 +744,14 @@ int launch_component_pass(phmrf_block* b, float beta) {
   PHMRF_TRY(ensure(&b->comp_move, (size_t)n));
   hipStream_t st = b->stream;
   const int g = grid1d(n);
-  hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels);
-  hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0);
+  static const bool cc_rows = getenv("PHMRF_CC_ROWS") != nullptr;       // development: the adjacency-row form on grid blocks
+  if (b->has_grid && b->grid_complete && b->num_neighbor == 8 && D == 8 && !cc_rows) {
+    hipLaunchKernelGGL(cc_init_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels);
+    hipLaunchKernelGGL(cc_union_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels);
+  } else {
+    hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels);
+    hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0);
+  }
   hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move, tab64);
   const bool grid_tables = b->has_grid && b->num_neighbor == 8 && D == 8 && b->fwd_w && b->uT && b->uT_valid;
   if (grid_tables) {
