@@ -69,6 +69,14 @@ PHMRF_HOST_API int phmrf_ou_slsqp(const phmrf_tree_tables* tree, void* slsqp_ent
 PHMRF_HOST_API int phmrf_median_fill(double* mtx, int64_t n1, int64_t n2, int symmetric, double threshold,
                                      int64_t* n_low, int64_t* n_filled);
 
+/* Pre-processing, filter_mode 1: the reference's `denoise_bilateral(img, sigma_color, sigma_spatial, multichannel=False)`
+ * of one channel (utility.py:1575-1582; scikit-image's `_denoise_cy._denoise_bilateral`, restated from the published
+ * algorithm -- scikit-image is not available here: PARITY UNPINNED).  img, out: C-order float64 [rows, cols], distinct
+ * buffers; win_size <= 0: max(5, 2 ceil(3 sigma_spatial) + 1); bins <= 0: 10000; mode 'constant' with cval 0.  A
+ * negative pixel (skimage raises ValueError) or a non-positive sigma returns PHMRF_HOST_ERR_INVALID.              */
+PHMRF_HOST_API int phmrf_bilateral(const double* img, int64_t rows, int64_t cols, double sigma_color,
+                                   double sigma_spatial, int win_size, int bins, double* out);
+
 PHMRF_HOST_API int phmrf_host_version(void);
 
 #ifdef __cplusplus

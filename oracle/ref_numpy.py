@@ -361,3 +361,41 @@ def kmeans_step(X, centers):
     sums = np.zeros_like(centers)
     np.add.at(sums, lab, X)
     return lab, sums, np.bincount(lab, minlength=K).astype(np.float64), float(d2[np.arange(X.shape[0]), lab].sum())
+
+
+# --------------------------------------------------------------------------------------
+# filter_mode 1 (utility.py:1575-1582): skimage.restoration.denoise_bilateral(img, sigma_color, sigma_spatial,
+# multichannel=False).  scikit-image is a third-party dependency that is neither installed here nor vendored under
+# /root/reference (the reference's README pins no version; its Python-2 era means 0.13 / 0.14): PARITY UNPINNED.  This
+# restates the published algorithm of `skimage/restoration/_denoise_cy.pyx::_denoise_bilateral` for one channel, loop by
+# loop over the window offsets (vectorised over the pixels): zero padding (mode 'constant', cval 0), spatial table
+# exp(-0.5 (d / sigma_spatial)^2), colour table of `bins` entries exp(-0.5 (b max / bins / sigma_color)^2) indexed by
+# min(int(|centre - value| * bins / max), bins - 1).
+# --------------------------------------------------------------------------------------
+def denoise_bilateral(img, sigma_color=None, sigma_spatial=1, win_size=None, bins=10000):
+    image = np.asarray(img, dtype=np.float64)
+    if win_size is None:
+        win_size = max(5, 2 * int(np.ceil(3 * sigma_spatial)) + 1)
+    sigma_color = sigma_color or image.std()
+    mn, mx = image.min(), image.max()
+    if mn == mx:
+        return image.copy()
+    if mn < 0.0:
+        raise ValueError("Image must contain only positive values")
+    ext = (win_size - 1) // 2
+    color_lut = np.exp(-0.5 * (np.arange(bins) * mx / bins / sigma_color) ** 2)
+    dist_scale = bins / mx
+    rows, cols = image.shape
+    padded = np.zeros((rows + 2 * ext, cols + 2 * ext))
+    padded[ext:ext + rows, ext:ext + cols] = image
+    total = np.zeros_like(image)
+    weight = np.zeros_like(image)
+    for wr in range(-ext, ext + 1):
+        for wc in range(-ext, ext + 1):
+            value = padded[ext + wr:ext + wr + rows, ext + wc:ext + wc + cols]
+            range_w = np.exp(-0.5 * (np.sqrt(float(wr * wr + wc * wc)) / sigma_spatial) ** 2)
+            b = np.minimum((np.abs(image - value) * dist_scale).astype(np.int64), bins - 1)
+            w = range_w * color_lut[b]
+            total += value * w
+            weight += w
+    return total / weight

@@ -12,7 +12,8 @@ Raw input (edge.1.txt, branch_length.1.txt, species_name.1.txt, path_list.txt, <
 the species' chr<c>.<res>K.txt contact files under --root_path, README.md:53-75) is pre-processed on the host by
 phylo_hmrf_amd/preprocess.py, a restatement of utility.load_data_chromosome2 pinned on the reference's own loader
 (tests/test_preprocess.py); --filter_mode 0 uses the build's Perona-Malik restatement of medpy's filter (medpy is not
-installed: parity unpinned for that one function), --filter_mode 1 (skimage bilateral) is not provided.
+installed: parity unpinned for that one function), --filter_mode 1 its restatement of skimage's bilateral filter
+(scikit-image is not installed either: parity unpinned likewise).
 --synthetic N instead generates a seeded multi-species block in the same cache format.
 """
 from __future__ import print_function

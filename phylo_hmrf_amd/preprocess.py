@@ -19,8 +19,10 @@ Python-2 semantics kept where they matter (the reference is Python 2): `N = ceil
 Filters: filter_mode 0 is medpy's `anisotropic_diffusion(img, niter=5, kappa=50, gamma=0.1, option=1)` (:412, :1573).
 medpy is not in this image and not under /root/reference, so `anisotropic_diffusion` below restates its published
 algorithm (Perona-Malik, exponential conductance, float32 working array) -- PARITY UNPINNED for that one function; the
-rest of the pipeline is pinned on fixtures recorded from the reference's own loader (tests/golden/).  filter_mode 1
-(skimage bilateral) is not provided; any other value with sigma > 0 is scipy's Gaussian filter, as in the reference.
+rest of the pipeline is pinned on fixtures recorded from the reference's own loader (tests/golden/).  filter_mode 1 is
+skimage's `denoise_bilateral(img, sigma_color=0.5, sigma_spatial=5)` (:1575-1582): scikit-image is absent as well, so
+`denoise_bilateral` below restates its published algorithm (native, libphmrf_host.so) -- PARITY UNPINNED likewise.  Any
+other value with sigma > 0 is scipy's Gaussian filter, as in the reference.
 """
 from __future__ import print_function
 
@@ -41,6 +43,9 @@ def _host():
         L.phmrf_median_fill.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_double, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.phmrf_median_fill.restype = ctypes.c_int
+        L.phmrf_bilateral.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.phmrf_bilateral.restype = ctypes.c_int
         L._pre_ready = True
     return L
 
@@ -82,6 +87,27 @@ def anisotropic_diffusion(img, niter=1, kappa=50, gamma=0.1, option=1):
     return out
 
 
+def denoise_bilateral(img, sigma_color=None, sigma_spatial=1, win_size=None, bins=10000):
+    """skimage.restoration.denoise_bilateral(img, sigma_color, sigma_spatial, multichannel=False) of a 2-D float image,
+    as the reference calls it for filter_mode 1 (utility.py:1575-1582): restated from the published algorithm of
+    scikit-image 0.13 / 0.14 (`_denoise_cy._denoise_bilateral`, mode 'constant', cval 0) -- scikit-image is absent here,
+    PARITY UNPINNED.  Native (libphmrf_host.so `phmrf_bilateral`); oracle/ref_numpy.py holds the NumPy restatement the
+    tests compare it with."""
+    a = np.ascontiguousarray(img, dtype=np.float64)
+    if a.ndim != 2:
+        raise ValueError("denoise_bilateral: a 2-D image (one channel) is expected")
+    if sigma_color is None:
+        sigma_color = float(a.std())                              # skimage: `sigma_color or image.std()`
+    out = np.empty_like(a)
+    dp = ctypes.POINTER(ctypes.c_double)
+    st = _host().phmrf_bilateral(a.ctypes.data_as(dp), a.shape[0], a.shape[1], float(sigma_color), float(sigma_spatial),
+                                 0 if win_size is None else int(win_size), int(bins), out.ctypes.data_as(dp))
+    if st != 0:
+        raise ValueError("denoise_bilateral: image must contain only positive values, sigmas must be positive, the "
+                         "window odd")
+    return out
+
+
 def _apply_filter(mtx1, filter_mode, filter_param1, filter_param2, sigma):
     """utility.py:1566-1588 / :1752-1774, channel by channel, in place."""
     dim1 = mtx1.shape[-1]
@@ -93,8 +119,11 @@ def _apply_filter(mtx1, filter_mode, filter_param1, filter_param2, sigma):
                 mtx1[:, :, i] = anisotropic_diffusion(mtx1[:, :, i], niter=filter_param1, kappa=filter_param2, gamma=0.1,
                                                       option=1)
     elif filter_mode == 1:
-        raise NotImplementedError("filter_mode 1 (skimage.restoration.denoise_bilateral) is not part of this build; use "
-                                  "filter_mode 0 (anisotropic diffusion) or 2 (Gaussian / none)")
+        for i in range(dim1):
+            if filter_param1 < 0:
+                mtx1[:, :, i] = denoise_bilateral(mtx1[:, :, i], sigma_color=0.5, sigma_spatial=5)
+            else:
+                mtx1[:, :, i] = denoise_bilateral(mtx1[:, :, i], sigma_color=filter_param1, sigma_spatial=filter_param2)
     elif sigma > 0:
         import scipy.ndimage
         for i in range(dim1):

@@ -152,8 +152,32 @@ def test_loader_errors(tmp_path, loader_golden):
         preprocess.quantile_contact_vec([21], RES, sizes, flist, SPECIES)          # no chr21 files
     with pytest.raises(ValueError):
         preprocess.quantile_contact_vec([7], RES, sizes, flist, SPECIES)           # chr7 not in the sizes file
-    with pytest.raises(NotImplementedError):
-        preprocess.load_data_chromosome2([22], 100.0, 0, RES, 8, 1, 0.25, 0, sizes, flist, SPECIES, d)
+
+
+def test_loader_filter_mode_1_runs_the_bilateral_filter(tmp_path, loader_golden):
+    """--filter_mode 1 (utility.py:1575-1582): same nodes, lengths and edge structure as the other modes, the features
+    smoothed by denoise_bilateral(sigma_color=0.5, sigma_spatial=5) -- checked against the loader's unfiltered image run
+    through the oracle's restatement of the filter."""
+    g = loader_golden
+    d, flist = _write_dir(tmp_path, g, "22", int(g["first_bin"]), 40, 0, g["a_synteny"])
+    sizes = os.path.join(d, "hg38.chrom.sizes")
+    mv = preprocess.quantile_contact_vec([22], RES, sizes, flist, SPECIES)
+    x_max = float(np.median(mv[:, 6]))                                        # phylo_hmrf.py:1662-1663
+    s1, lv1, e1 = preprocess.load_data_chromosome2([22], x_max, 0, RES, 8, 1, 0.25, 0, sizes, flist, SPECIES, d)
+    s2, lv2, e2 = preprocess.load_data_chromosome2([22], x_max, 0, RES, 8, 2, 0.0, 0, sizes, flist, SPECIES, d)   # no filter
+    assert s1.shape == s2.shape and [list(a) for a in lv1] == [list(a) for a in lv2]
+    assert all(np.array_equal(a[:, :2], b[:, :2]) for a, b in zip(e1, e2))
+    assert np.all(np.isfinite(s1)) and not np.allclose(s1, s2)
+    # the first block is diagonal: rebuild its image from the unfiltered nodes, filter it with the oracle, compare
+    n, _, _, H, W = [int(v) for v in lv2[0][:5]]
+    assert H == W and n == H * (H + 1) // 2
+    iu = np.triu_indices(H)
+    for c in range(s2.shape[1]):
+        img = np.zeros((H, W))
+        img[iu] = s2[:n, c]
+        img = img + img.T - np.diag(np.diag(img))
+        ref = R.denoise_bilateral(img, sigma_color=0.5, sigma_spatial=5)
+        np.testing.assert_allclose(s1[:n, c], ref[iu], rtol=1e-12, atol=1e-12)
 
 
 def _perona_malik_by_the_book(img, niter, kappa, gamma):
@@ -211,3 +235,53 @@ def test_anisotropic_diffusion_properties():
     step = np.zeros((1, 20)); step[0, 10:] = 1000.0           # an edge far above kappa survives
     o2 = preprocess.anisotropic_diffusion(step, niter=5, kappa=50, gamma=0.1)
     assert abs(o2[0, 9]) < 1e-3 and abs(o2[0, 10] - 1000.0) < 1e-3
+
+
+# ---- filter_mode 1: bilateral filter (scikit-image absent: parity unpinned; native vs the oracle's restatement) ----------
+@pytest.mark.parametrize("shape,sc,ss", [((23, 31), 0.5, 5), ((40, 40), 0.5, 5), ((7, 5), 0.2, 1), ((16, 9), None, 2)])
+def test_bilateral_native_matches_the_oracle(shape, sc, ss):
+    rng = np.random.default_rng(5)
+    img = np.abs(rng.standard_normal(shape)) * 2.0 + (np.arange(shape[1]) > shape[1] // 2) * 3.0     # an edge + noise
+    got = preprocess.denoise_bilateral(img, sigma_color=sc, sigma_spatial=ss)
+    ref = R.denoise_bilateral(img, sigma_color=sc, sigma_spatial=ss)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+    assert got.shape == img.shape and np.all(got >= 0) and got.max() <= img.max() + 1e-12
+
+
+def test_bilateral_by_the_book_pixel_loop():
+    """The published per-pixel loop (window, zero padding, two look-up tables), written out for single pixels,
+    independently of the vectorised oracle and of the native code."""
+    rng = np.random.default_rng(8)
+    img = rng.random((12, 14)) * 4.0
+    sc, ss, bins = 0.5, 1.5, 10000
+    win = max(5, 2 * int(np.ceil(3 * ss)) + 1)
+    ext = (win - 1) // 2
+    mx = img.max()
+    got = preprocess.denoise_bilateral(img, sigma_color=sc, sigma_spatial=ss)
+    for r, c in [(0, 0), (5, 7), (11, 13), (3, 0), (0, 9)]:
+        tot = wsum = 0.0
+        for wr in range(-ext, ext + 1):
+            for wc in range(-ext, ext + 1):
+                rr, cc = r + wr, c + wc
+                v = img[rr, cc] if (0 <= rr < 12 and 0 <= cc < 14) else 0.0
+                b = min(int(abs(img[r, c] - v) * (bins / mx)), bins - 1)
+                w = np.exp(-0.5 * (np.hypot(wr, wc) / ss) ** 2) * np.exp(-0.5 * (b * mx / bins / sc) ** 2)
+                tot += v * w
+                wsum += w
+        assert abs(got[r, c] - tot / wsum) < 1e-12
+
+
+def test_bilateral_properties_and_errors():
+    flat = np.full((9, 9), 2.5)
+    assert np.array_equal(preprocess.denoise_bilateral(flat, 0.5, 5), flat)             # min == max: returned unchanged
+    rng = np.random.default_rng(2)
+    # an interior far from the zero padding: a step edge survives, the noise on either side shrinks
+    img = np.where(np.arange(80)[None, :] < 40, 1.0, 6.0) + 0.05 * rng.random((80, 80))
+    out = preprocess.denoise_bilateral(img, sigma_color=0.5, sigma_spatial=2)
+    core = (slice(20, 60), slice(20, 60))
+    assert out[core][:, :18].std() < 0.5 * img[core][:, :18].std()
+    assert out[30, 45] - out[30, 34] > 4.9                                               # the edge is not blurred away
+    with pytest.raises(ValueError):
+        preprocess.denoise_bilateral(np.array([[1.0, -0.5], [0.2, 0.3]]), 0.5, 1)        # skimage: ValueError
+    with pytest.raises(ValueError):
+        preprocess.denoise_bilateral(np.ones((4, 4, 2)), 0.5, 1)
