@@ -514,7 +514,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     __syncthreads();
     // phase 2: tile = logprob + beta*h   (coalesced row loads, K/VEC lanes per row)
     // (measured: issuing these loads and the observation vector before phase 1 -- 24 more registers -- made the kernel 12 %
-    //  slower; smaller tiles for more workgroups per CU: 128 rows +13 %, 64 rows +33 %)
+    //  slower; smaller tiles for more workgroups per CU: 128 rows +13 %, 64 rows +33 %; a form of this kernel that reads
+    //  the node's K terms from the label-major planes into registers -- no LDS transposition, both soft-maxes unrolled
+    //  on registers, two barriers per tile: half the vector instructions, 142 registers, 1.11 instead of 0.89 ms on the
+    //  12.4 M-node block -- the kernel issues at ~0.19 vector instructions per cycle and SIMD as it is, and three waves
+    //  per SIMD do not hide a longer chain of loads per tile)
     rows_to_tile<VEC, true>(logprob, nullptr, base, rows, K, Kp, tile, 1.f, beta);
     __syncthreads();
     // phase 3: posteriors = softmax_k(tile_k - beta*wtot) in place; per-node features [1 | x | x x^T]

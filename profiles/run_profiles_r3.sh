@@ -14,6 +14,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 mkdir -p $O
+# the counters first: bench.py fills roofline.traffic from profiles/pmc_by_kernel.json when its source_hash is this build's
+bash profiles/run_pmc_by_kernel.sh $REV > $O/r3_pmc.out 2>&1
+[ -s $O/pmc_by_kernel.json ] && cp $O/pmc_by_kernel.json profiles/pmc_by_kernel.json
 python3 bench.py > $O/r3_bench.json 2> $O/r3_bench.err
 python3 bench.py --steps 20 --warmup 5 > $O/r3_bench_steps20_warmup5.json 2>> $O/r3_bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3_stats -- python3 bench.py --no-cpu-baseline > $O/r3_bench_under_rocprof.json 2> $O/r3_rocprof.err
@@ -22,7 +25,6 @@ rm -rf $O/r3_stats
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3_stats -- python3 bench.py --no-cpu-baseline --block-threads 1 --mstep-workers 1 > $O/r3_bench_under_rocprof_serial.json 2>> $O/r3_rocprof.err
 find $O/r3_stats -name "*kernel_stats.csv" -exec cp {} $O/r3_kernel_stats_serial.csv \;
 rm -rf $O/r3_stats
-bash profiles/run_pmc_by_kernel.sh $REV > $O/r3_pmc.out 2>&1
 bash profiles/warm_solve_profile.sh r3 > $O/r3_warm.out 2>&1
 python3 - <<'PY'
 import json, csv
