@@ -419,7 +419,7 @@ def main():
                        "blocks_per_rank": [int(sum(1 for o in owner if o == r)) for r in range(world)],
                        "nodes_per_rank": nodes_per_rank,
                        "S": S, "K": K, "num_neighbor": nn, "beta": a.beta, "beta1": a.beta1,
-                       "step": "full EM iteration: GPU E-step of every block + stats reduction + host M-step (SLSQP, %d workers)" % workers,
+                       "step": "full EM iteration: GPU E-step of every block + stats reduction + host M-step (SLSQP, %d host threads)" % workers,
                        "mrf_solver": solver},
             "estep_ms": float(np.mean(t_e) * 1e3), "mstep_ms": float(np.mean(t_m) * 1e3),
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)

@@ -60,6 +60,21 @@ PHMRF_HOST_API int phmrf_ou_slsqp(const phmrf_tree_tables* tree, void* slsqp_ent
                                   double lower, double upper, double acc, int maxiter, double* x_out, int* mode_out,
                                   int* n_eval_out);
 
+/* The M-step of one EM iteration, `_do_mstep` (phylo_hmrf.py:1500-1528): K independent `_ou_optimize2` runs
+ * (:1327-1403) on `n_threads` host threads (the states share nothing: the result does not depend on the thread count).
+ * Per state c: phmrf_ou_slsqp from guesses[c, r, :] for r = 0 .. n_guesses-1 until the result passes `_check_params`
+ * (:1405-1425: beta, lambda in [0, 100], theta in [-100, 100]); if none does, the state keeps init_params[c, :]
+ * (:1346-1349); params_out[c, :] = the chosen point, lik_out[c] = the objective there, mean_out[c, :] / V_out[c, :, :] =
+ * its OU leaf means and covariance (without the EM-time + min_covar I of :1524).  status_out[c] = PHMRF_HOST_OK, or
+ * PHMRF_HOST_ILL_CONDITIONED when an evaluation of that state met an ill-conditioned covariance: the caller then repeats
+ * THAT state with its Python loop (pseudo-inverse path); its outputs are undefined.
+ * Arrays are C-order float64: post[K], obs[K,S], oo[K,S,S], guesses[K,n_guesses,3B+2], init_params[K,3B+2].           */
+PHMRF_HOST_API int phmrf_ou_mstep(const phmrf_tree_tables* tree, void* slsqp_entry, int K, const double* post,
+                                  const double* obs, const double* oo, double n_samples, double reg, double min_covar,
+                                  const double* guesses, int n_guesses, const double* init_params, double lower,
+                                  double upper, double acc, int maxiter, int n_threads, double* params_out,
+                                  double* lik_out, double* mean_out, double* V_out, int* status_out);
+
 /* Pre-processing: the reference's median fill of empty contact-map cells, `near_interpolation1`
  * (symmetric != 0: square matrix, upper triangle scanned, value mirrored; utility.py:603-631) and
  * `near_interpolation1a` (symmetric == 0: general matrix; utility.py:633-660).  mtx: C-order float64 [n1,n2], updated

@@ -308,3 +308,76 @@ extern "C" int phmrf_ou_slsqp(const phmrf_tree_tables* tree, void* slsqp_entry, 
   if (n_eval_out) *n_eval_out = n_eval;
   return PHMRF_HOST_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole M-step of one EM iteration: `_do_mstep` (phylo_hmrf.py:1500-1528) = K independent `_ou_optimize2` runs
+// (:1327-1403), one host thread per state.  Per state, exactly what phylo_hmrf_amd/mstep.py `_solve_state` does around
+// phmrf_ou_slsqp: the start points in order (the first is used, the others are the reference's retries, :1332-1342), the
+// box test of the result (`_check_params`, :1405-1425), the fall-back to the state's initial parameters (:1346-1349), and
+// the objective at the chosen point with its mean and covariance.  A state that meets an ill-conditioned covariance
+// anywhere is reported with status PHMRF_HOST_ILL_CONDITIONED and left to the caller (its Python loop takes the
+// reference's pseudo-inverse path).  The states share nothing, so the result does not depend on the number of threads.
+#include <thread>
+
+namespace {
+
+// `_check_params`: 1 inside the box, <= -1 outside (beta, lambda in [0, 100], theta in [-100, 100]; NaN counts as outside)
+int check_box(const double* p, int N) {
+  const int B = N - 1;
+  for (int i = 0; i < 2 * B; ++i)
+    if (!(p[1 + i] >= 0.0 && p[1 + i] <= 100.0)) return -1;
+  for (int i = 0; i < N; ++i)
+    if (!(p[1 + 2 * B + i] >= -100.0 && p[1 + 2 * B + i] <= 100.0)) return -1;
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int phmrf_ou_mstep(const phmrf_tree_tables* tree, void* slsqp_entry, int K, const double* post, const double* obs,
+                              const double* oo, double n_samples, double reg, double min_covar, const double* guesses,
+                              int n_guesses, const double* init_params, double lower, double upper, double acc, int maxiter,
+                              int n_threads, double* params_out, double* lik_out, double* mean_out, double* V_out,
+                              int* status_out) {
+  if (!tree || !slsqp_entry || K <= 0 || !post || !obs || !oo || !guesses || n_guesses <= 0 || !init_params || !params_out ||
+      !lik_out || !mean_out || !V_out || !status_out)
+    return PHMRF_HOST_ERR_INVALID;
+  const int N = tree->N, S = tree->S;
+  if (N < 2 || N > 4 * MAXS || S < 1 || S > MAXS) return PHMRF_HOST_ERR_INVALID;
+  const int P = 3 * (N - 1) + 2;
+  auto one_state = [&](int c) {
+    const double* ob = obs + (size_t)c * S;
+    const double* o2 = oo + (size_t)c * S * S;
+    double* x = params_out + (size_t)c * P;
+    bool ok = false;
+    status_out[c] = PHMRF_HOST_OK;
+    for (int r = 0; r < n_guesses && !ok; ++r) {
+      int mode = 0, n_eval = 0;
+      const int st = phmrf_ou_slsqp(tree, slsqp_entry, post[c], ob, o2, n_samples, reg, min_covar,
+                                    guesses + ((size_t)c * n_guesses + r) * P, lower, upper, acc, maxiter, x, &mode, &n_eval);
+      if (st != PHMRF_HOST_OK) {
+        status_out[c] = st;
+        return;
+      }
+      ok = check_box(x, N) > 0;
+    }
+    if (!ok)
+      for (int i = 0; i < P; ++i) x[i] = init_params[(size_t)c * P + i];
+    const int st = phmrf_ou_objective(tree, x, post[c], ob, o2, n_samples, reg, min_covar, lik_out + c, nullptr,
+                                      V_out + (size_t)c * S * S, mean_out + (size_t)c * S);
+    if (st != PHMRF_HOST_OK) status_out[c] = st;
+  };
+  int nt = n_threads < 1 ? 1 : (n_threads > K ? K : n_threads);
+  if (nt == 1) {
+    for (int c = 0; c < K; ++c) one_state(c);
+    return PHMRF_HOST_OK;
+  }
+  std::vector<std::thread> th;
+  th.reserve((size_t)nt);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t]() {
+      for (int c = t; c < K; c += nt) one_state(c);
+    });
+  for (auto& t : th) t.join();
+  return PHMRF_HOST_OK;
+}

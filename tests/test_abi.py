@@ -87,7 +87,8 @@ HOST_LIB = os.path.join(ROOT, "phylo_hmrf_amd", "libphmrf_host.so")
 @pytest.mark.skipif(not os.path.exists(HOST_LIB), reason="libphmrf_host.so not built (run __graft_entry__.build())")
 def test_host_library_exports_every_declared_symbol():
     syms = sorted(set(re.findall(r"PHMRF_HOST_API\s+[\w\s\*]+?\b(phmrf_\w+)\s*\(", open(HOST_HEADER).read())))
-    assert syms == ["phmrf_bilateral", "phmrf_host_version", "phmrf_median_fill", "phmrf_ou_objective", "phmrf_ou_slsqp"]
+    assert syms == ["phmrf_bilateral", "phmrf_host_version", "phmrf_median_fill", "phmrf_ou_mstep", "phmrf_ou_objective",
+                    "phmrf_ou_slsqp"]
     L = ctypes.CDLL(HOST_LIB)
     assert not [s for s in syms if not hasattr(L, s)]
     L.phmrf_host_version.restype = ctypes.c_int

@@ -83,10 +83,22 @@ def test_do_mstep_improves_the_objective_and_respects_the_box():
         obj.value(params[c])
         np.testing.assert_allclose(covars[c], obj.last_V + 1e-3 * np.eye(4))
         np.testing.assert_allclose(means[c], obj.last_mean)
-    # pool path gives a valid result too
-    p2, _, _, lik2 = mstep.do_mstep(t, stats, cur, cur, 5000, 1.0, 1, 0.3, 0.1, 1.0, np.random.default_rng(1), workers=2)
-    assert np.all(np.isfinite(lik2)) and p2.shape == cur.shape
-    mstep.close_pool()
+    # workers > 1: all states in one library call on host threads (phmrf_ou_mstep) -- the same numbers as the in-process
+    # Python loop over the states, to the last bit, whatever the thread count
+    ref = mstep.do_mstep(t, stats, cur, cur, 5000, 1.0, 1, 0.3, 0.1, 1.0, np.random.default_rng(1), workers=1)
+    for w in (2, 3, 16):
+        got = mstep.do_mstep(t, stats, cur, cur, 5000, 1.0, 1, 0.3, 0.1, 1.0, np.random.default_rng(1), workers=w)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
+    # ... and the fork pool behind it (PHMRF_MSTEP_NATIVE=0; used when SciPy's SLSQP entry point is not available)
+    mstep.NATIVE_MSTEP[0] = False
+    try:
+        got = mstep.do_mstep(t, stats, cur, cur, 5000, 1.0, 1, 0.3, 0.1, 1.0, np.random.default_rng(1), workers=2)
+    finally:
+        mstep.NATIVE_MSTEP[0] = True
+        mstep.close_pool()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("tag", ["t4", "t8"])
@@ -173,3 +185,45 @@ def test_native_slsqp_loop_reproduces_the_python_loop():
             assert a is not None and b is not None
             assert a[1] == b[1]
             assert np.array_equal(a[0], b[0]), float(np.abs(a[0] - b[0]).max())
+
+
+def test_native_mstep_flags_an_ill_conditioned_state_and_leaves_the_others_alone():
+    """phmrf_ou_mstep: a state whose covariance is ill-conditioned (every variance 0 with min_covar = 0) comes back with
+    status 2 for the caller's Python loop; the other state of the same call is fitted as usual."""
+    import ctypes
+    g1 = np.load(os.path.join(G, "tree_tables.npz"))
+    g = np.load(os.path.join(G, "mstep_objective.npz"))
+    t = PhyloTree(g1["t4_edge_list"])
+    entry = mstep.slsqp_entry()
+    if entry is None:
+        pytest.skip("this SciPy does not expose the SLSQP entry point")
+    nt = mstep.NativeTree(t)
+    K, P, S = 2, t.n_params, t.n_features
+    post = np.ascontiguousarray(g["t4_post"][:2], dtype=np.float64)
+    obs = np.ascontiguousarray(g["t4_obs"][:2], dtype=np.float64)
+    oo = np.ascontiguousarray(g["t4_obsobsT"][:2], dtype=np.float64)
+    cur = np.clip(g["t4_params"][:2], mstep.LOWER, mstep.UPPER)
+    guesses = np.ascontiguousarray(np.stack([cur[0:1], np.full((1, P), 1e-16)]))          # [K, 1, P]
+    params, lik, mean, V = np.zeros((K, P)), np.zeros(K), np.zeros((K, S)), np.zeros((K, S, S))
+    status = np.full(K, -1, dtype=np.int32)
+    dp = ctypes.POINTER(ctypes.c_double)
+    L = mstep.host_lib()
+    L.phmrf_ou_mstep.restype = ctypes.c_int
+    L.phmrf_ou_mstep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, dp, dp, dp, ctypes.c_double, ctypes.c_double,
+                                 ctypes.c_double, dp, ctypes.c_int, dp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                 ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, ctypes.POINTER(ctypes.c_int)]
+    st = L.phmrf_ou_mstep(ctypes.cast(ctypes.byref(nt.tables), ctypes.c_void_p), entry, K, post.ctypes.data_as(dp),
+                          obs.ctypes.data_as(dp), oo.ctypes.data_as(dp), 5000.0, 1.0 / np.sqrt(5000.0), 0.0,
+                          guesses.ctypes.data_as(dp), 1, cur.ctypes.data_as(dp), mstep.LOWER, mstep.UPPER, 1e-6, 200, 2,
+                          params.ctypes.data_as(dp), lik.ctypes.data_as(dp), mean.ctypes.data_as(dp), V.ctypes.data_as(dp),
+                          status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    assert st == 0 and status[1] == 2
+    if status[0] == 0:                                   # (min_covar = 0 may make state 0 ill-conditioned on the way, too)
+        obj = mstep.OUObjective(t, post[0], obs[0], oo[0], 5000, 1.0, min_covar=0.0)
+        assert lik[0] == obj.value(params[0]) and np.array_equal(mean[0], obj.last_mean) and np.array_equal(V[0], obj.last_V)
+        assert lik[0] <= obj.value(cur[0]) + 1e-9
+    # bad arguments are refused
+    assert L.phmrf_ou_mstep(None, entry, K, post.ctypes.data_as(dp), obs.ctypes.data_as(dp), oo.ctypes.data_as(dp), 5000.0,
+                            0.01, 0.0, guesses.ctypes.data_as(dp), 1, cur.ctypes.data_as(dp), mstep.LOWER, mstep.UPPER, 1e-6,
+                            200, 2, params.ctypes.data_as(dp), lik.ctypes.data_as(dp), mean.ctypes.data_as(dp),
+                            V.ctypes.data_as(dp), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 1
