@@ -167,7 +167,8 @@ def test_fit_warns_when_a_region_is_not_a_grid_block():
                   initial_magnitude=1.0)
 
 
-def test_cli_runs_from_raw_hic_text(tmp_path):
+@pytest.mark.parametrize("filter_mode", ["0", "1"])
+def test_cli_runs_from_raw_hic_text(tmp_path, filter_mode):
     """Row f4: `python phylo_hmrf.py -n 6 --chromvec 22 -p <dir>` on example_input-style raw files (a 120-bin window of
     the example's chr22 rows, tests/golden/example_loader.npz) -> cache files + the .mat.  (The diffusion filter on this
     path is the build's own Perona-Malik restatement, medpy being absent; tests/test_preprocess.py checks it against the
@@ -189,7 +190,7 @@ def test_cli_runs_from_raw_hic_text(tmp_path):
     os.chdir(d)                                   # chrom_quantile_test.txt goes to the working directory (:1659-1661)
     try:
         o = cli.parse_args(["-n", "6", "-r", "1", "--miter", "4", "--chromvec", "22", "-p", d, "--output", out, "-g", "3",
-                            "--seed", "4", "--quiet", "1", "--filter_mode", "0"])
+                            "--seed", "4", "--quiet", "1", "--filter_mode", filter_mode])
         mat = cli.run(o.num_states, o.chromvec, o.root_path, o.multiple, o.species_name, o.sort_states, o.run_id,
                       o.cons_param, o.method_mode, o.initial_mode, o.initial_weight, o.initial_weight1,
                       o.initial_magnitude, o.position1, o.position2, o.filter_sigma, o.beta, o.beta1, o.num_neighbor,
@@ -198,7 +199,13 @@ def test_cli_runs_from_raw_hic_text(tmp_path):
     finally:
         os.chdir(cwd)
     samples, len_vec, edge_list_vec = cli.load_cache(out, 50000, 1)
-    assert np.array_equal(samples, g["a_diffusion_samples"]) and np.array_equal(len_vec, g["a_diffusion_lenvec"])
+    if filter_mode == "0":
+        assert np.array_equal(samples, g["a_diffusion_samples"]) and np.array_equal(len_vec, g["a_diffusion_lenvec"])
+    else:
+        # --filter_mode 1: the bilateral filter (utility.py:1575-1582; restated, scikit-image being absent): same nodes, other
+        # features than the unfiltered loader run of the reference
+        assert np.array_equal(len_vec, g["a_none_lenvec"]) and samples.shape == g["a_none_samples"].shape
+        assert np.all(np.isfinite(samples)) and not np.allclose(samples, g["a_none_samples"])
     assert os.path.exists(os.path.join(d, "chrom_quantile_test.txt"))
     dm = scipy.io.loadmat(mat)
     assert dm["state_vec"].size == samples.shape[0] and np.all(np.isfinite(dm["cost_vec"]))
