@@ -379,6 +379,7 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->logprob);
   dev_free(b->labels);
   dev_free(b->labels_tmp);
+  dev_free(b->labels_eval);
   dev_free(b->sgain);
   for (int s = 0; s < 4; ++s) dev_free(b->saved[s]);
   dev_free(b->nbr);
@@ -829,6 +830,66 @@ static int energy_now(phmrf_block_t b, double beta, double* eu, double* ep) {
   return PHMRF_OK;
 }
 
+// The energy after a round of a solve.  The first evaluation of a solve is the full pass; later ones on a large grid block
+// add the change since the previous evaluation, taken from the nodes the round's moves have stamped (energy_delta_grid_
+// kernel) -- a mop-up round touches a few per cent of the block.  Each evaluation leaves a snapshot of the labels and
+// its tick behind for the next.  (PHMRF_ENERGY_FULL=1: always the full pass; PHMRF_ENERGY_CHECK=1: both, compared.)
+static int energy_after_round(phmrf_block_t b, double beta, double* eu, double* ep, double* eu_raw_prev, double* ep_raw_prev) {
+  static const bool always_full = getenv("PHMRF_ENERGY_FULL") != nullptr;
+  static const bool check = getenv("PHMRF_ENERGY_CHECK") != nullptr;
+  const bool grid = b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->stamp && b->tick > 0 && b->n >= (1 << 18);
+  if (!grid || always_full) return energy_now(b, beta, eu, ep);
+  bool incremental = energy_delta_available(b);
+  if (incremental) {
+    PHMRF_TRY(zero_accum(b, 4, 2));
+    tic(b);
+    PHMRF_TRY(launch_energy_delta(b));
+    toc(b, KC_ENERGY, 1);
+    PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  }
+  if (!b->labels_eval) PHMRF_TRY(dev_alloc(&b->labels_eval, (size_t)b->n));
+  if (!incremental) {
+    PHMRF_TRY(energy_now(b, beta, eu, ep));          // synchronises
+    *eu_raw_prev = *eu;
+    if (b->deterministic) {
+      long long q1;
+      std::memcpy(&q1, b->accum_host + 5, sizeof(q1));
+      *ep_raw_prev = (double)q1 / 1048576.0;
+    } else {
+      *ep_raw_prev = b->accum_host[5];
+    }
+  }
+  // the snapshot for the next evaluation: every launch from here on carries a later tick
+  PHMRF_HIP(hipMemcpyAsync(b->labels_eval, b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
+  b->eval_tick = b->tick;
+  ++b->tick;
+  if (!incremental) return PHMRF_OK;
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  double du, dp;
+  if (b->deterministic) {
+    long long q[2];
+    std::memcpy(q, b->accum_host + 4, sizeof(q));
+    du = (double)q[0] / 1048576.0;
+    dp = (double)q[1] / 1048576.0;
+  } else {
+    du = b->accum_host[4];
+    dp = b->accum_host[5];
+  }
+  *eu_raw_prev += du;
+  *ep_raw_prev += dp;
+  *eu = *eu_raw_prev;
+  *ep = beta * *ep_raw_prev;
+  if (check) {
+    double fu, fp;
+    PHMRF_TRY(energy_now(b, beta, &fu, &fp));
+    const double tol = 1e-9 * std::fabs(fu + fp) + 1e-3;
+    if (std::fabs(fu - *eu) > tol || std::fabs(fp - *ep) > tol)
+      fprintf(stderr, "[phmrf energy check] incremental %.6f + %.6f, full %.6f + %.6f (diff %.3e, %.3e)\n", *eu, *ep, fu, fp,
+              *eu - fu, *ep - fp);
+  }
+  return PHMRF_OK;
+}
+
 int phmrf_mrf_energy(phmrf_block_t b, double beta, double* e_total, double* e_unary, double* e_pair) {
   PHMRF_TRY(check_solvable(b));
   double eu, ep;
@@ -1088,6 +1149,8 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
   if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
   PHMRF_HIP(hipMemsetAsync(b->stamp, 0, (size_t)b->n * sizeof(uint16_t), b->stream));
   b->tick = 1;
+  b->eval_tick = -1;                   // (no energy evaluation in this solve yet: the first one is a full pass)
+  double eu_carry = 0.0, ep_carry = 0.0;
   b->prop_tick = -1;
   if (chains) {                       // segment memos of all families: one buffer, one memset
     size_t total = 0;
@@ -1126,6 +1189,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     phmrf_block* blk;
     ~SolveScope() {
       blk->tick = 0;
+      blk->eval_tick = -1;
       blk->counter_slot = 0;
       blk->prop_tick = -1;
     }
@@ -1261,7 +1325,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                              b->stream));
     double eu = 0, ep = 0;
-    PHMRF_TRY(energy_now(b, beta, &eu, &ep));       // synchronises the stream
+    PHMRF_TRY(energy_after_round(b, beta, &eu, &ep, &eu_carry, &ep_carry));       // synchronises the stream
     const double e_now = eu + ep;
     int64_t ch = 0;
     for (int sl : slots) {

@@ -71,6 +71,8 @@ struct phmrf_block {
   float* logprob = nullptr;
   uint8_t* labels = nullptr;
   uint8_t* labels_tmp = nullptr;
+  uint8_t* labels_eval = nullptr;           // device [n]: the labels at a solve's last energy evaluation (launch_energy_delta)
+  int eval_tick = -1;                       //   ... and the launch tick then (-1: no evaluation in this solve yet)
   float* sgain = nullptr;                   // device [n]: cost of switching a node alone to its fusion proposal (launch_propose)
   uint8_t* saved[4] = {nullptr, nullptr, nullptr, nullptr};
   bool has_X = false, has_logprob = false, has_labels = false, has_graph = false, has_grid = false;
@@ -161,6 +163,8 @@ int launch_emission(const float* X, int64_t n, int S, int K, const float* packed
 int launch_argmax_labels(const phmrf_block* b);
 int launch_icm_colour(const phmrf_block* b, float beta, int colour);
 int launch_energy(const phmrf_block* b, float beta);  // -> accum[0]=unary, accum[1]=pair (caller zeroes)
+bool energy_delta_available(const phmrf_block* b);
+int launch_energy_delta(const phmrf_block* b);        // -> accum[..] += the change since labels_eval / eval_tick
 int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors);
 int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase);
 int launch_component_pass(phmrf_block* b, float beta);

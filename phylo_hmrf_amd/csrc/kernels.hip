@@ -383,6 +383,84 @@ __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restric
   if (threadIdx.x == 0) energy_flush(accum, tu, tp, det);
 }
 
+// The CHANGE of that energy since the last evaluation, from the nodes the moves have touched since: a node whose change
+// stamp is newer than `since` has changed its label or is the neighbour of one that has (the stamps are dilated by one
+// ring), and an edge's term can only differ where an end has changed -- so the touched nodes' unary terms and forward
+// edges, new labelling minus the snapshot `prev` taken at the last evaluation, are the whole difference, term by term exact
+// in f32 and summed in f64.  Waves whose nodes are all untouched read two bytes per node; a mop-up round of a warm solve
+// touches a few per cent of the block.  Same thread layout as energy_grid_kernel.
+__global__ __launch_bounds__(256) void energy_delta_grid_kernel(const float* __restrict__ uT, int64_t n, int H, int W, int diagonal,
+                                                                const float4* __restrict__ fwd_w,
+                                                                const uint8_t* __restrict__ labels,
+                                                                const uint8_t* __restrict__ prev,
+                                                                const uint16_t* __restrict__ stamp, int since,
+                                                                double* __restrict__ accum, int det) {
+  __shared__ double red[8];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  double eu = 0.0, ep = 0.0;
+  constexpr int UR = 4;
+  const int stride = gridDim.y * 4;
+  for (int i0 = blockIdx.y * 4 + (threadIdx.x >> 6); i0 < H; i0 += stride * UR) {
+    int64_t node[UR];
+    bool on[UR];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int i = i0 + u * stride;
+      const bool in = i < H && j < W && !(diagonal && j < i);
+      const int64_t row = diagonal ? (int64_t)i * W - ((int64_t)i * (i - 1)) / 2 - i : (int64_t)i * W;      // node = row + j
+      node[u] = in ? row + j : 0;
+      on[u] = in && (int)stamp[node[u]] > since;
+      any = any || on[u];
+    }
+    if (!__any(any)) continue;
+    int lab[UR], labp[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      lab[u] = labels[node[u]];
+      labp[u] = prev[node[u]];
+    }
+    float un[UR], unp[UR];
+    float4 w[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      un[u] = uT[(int64_t)lab[u] * n + node[u]];
+      unp[u] = uT[(int64_t)labp[u] * n + node[u]];
+      w[u] = fwd_w[node[u]];
+    }
+    int ln[UR][4], lp[UR][4];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int i = i0 + u * stride;
+      const int64_t row2 = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
+      const int jlo = diagonal ? i + 1 : 0;
+      const bool below = on[u] && i + 1 < H;
+      const int64_t me = node[u];
+      const int64_t c0 = (on[u] && j + 1 < W) ? me + 1 : me;                               // E
+      const int64_t c1 = (below && j - 1 >= jlo) ? row2 + j - 1 : me;                      // SW
+      const int64_t c2 = (below && j >= jlo) ? row2 + j : me;                              // S
+      const int64_t c3 = (below && j + 1 < W) ? row2 + j + 1 : me;                         // SE
+      ln[u][0] = labels[c0]; ln[u][1] = labels[c1]; ln[u][2] = labels[c2]; ln[u][3] = labels[c3];
+      lp[u][0] = prev[c0]; lp[u][1] = prev[c1]; lp[u][2] = prev[c2]; lp[u][3] = prev[c3];
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      if (!on[u]) continue;
+      const int l = lab[u], q = labp[u];
+      eu += (double)un[u] - (double)unp[u];
+      float s = 0.f;
+      s += (ln[u][0] != l ? w[u].x : 0.f) - (lp[u][0] != q ? w[u].x : 0.f);
+      s += (ln[u][1] != l ? w[u].y : 0.f) - (lp[u][1] != q ? w[u].y : 0.f);
+      s += (ln[u][2] != l ? w[u].z : 0.f) - (lp[u][2] != q ? w[u].z : 0.f);
+      s += (ln[u][3] != l ? w[u].w : 0.f) - (lp[u][3] != q ? w[u].w : 0.f);
+      ep += (double)s;
+    }
+  }
+  const double tu = block_sum(eu, red);
+  const double tp = block_sum(ep, red);
+  if (threadIdx.x == 0 && (tu != 0.0 || tp != 0.0)) energy_flush(accum, tu, tp, det);
+}
+
 // -------------------------------------------------------------------------------------------------
 // b3 posteriors + costs + sufficient statistics, fused (phylo_hmrf.py:334-355, :374-396, :311-314).
 //   pp[i,k]   = beta * sum_{e in inc(i)} w'_e [l_other != k]          (w' = w if estimate_type==3 else 1)
@@ -706,6 +784,24 @@ int launch_energy(const phmrf_block* b, float beta) {
   const int grid = grid_for(b->n, 256, 256 * 8);
   hipLaunchKernelGGL(energy_kernel, dim3(grid), dim3(256), 0, b->stream, b->logprob, b->n, b->K, b->D, b->nbr, b->wgt,
                      b->labels, b->accum, b->deterministic ? 1 : 0);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+// -> accum[ACC_ENERGY .. +1] += the change of (unary, pair) since the snapshot `labels_eval` / tick `eval_tick` (grid blocks
+// with current unary planes only: energy_delta_available)
+bool energy_delta_available(const phmrf_block* b) {
+  return b->has_grid && b->fwd_w && b->H > 0 && b->W > 0 && b->uT && b->uT_valid && b->stamp && b->tick > 0 && b->labels_eval &&
+         b->eval_tick >= 0;
+}
+
+int launch_energy_delta(const phmrf_block* b) {
+  const int gx = (b->W + 63) / 64;
+  int gy = (b->H + 3) / 4;
+  const int cap = 2048 / gx + 1;
+  if (gy > cap) gy = cap;
+  hipLaunchKernelGGL(energy_delta_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->uT, b->n, b->H, b->W, b->diagonal,
+                     b->fwd_w, b->labels, b->labels_eval, b->stamp, b->eval_tick, b->accum, b->deterministic ? 1 : 0);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
