@@ -799,3 +799,45 @@ def test_deterministic_mode_gives_identical_labellings():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
     runs = eval(line[len("RESULT"):])
     assert len(runs) == 3 and runs[0] == runs[1] == runs[2], runs
+
+
+@pytest.mark.parametrize("H,W,diagonal", [(520, 610, False), (800, 800, True)])
+def test_energy_of_later_rounds_from_the_touched_nodes_equals_the_full_pass(H, W, diagonal):
+    """From its second round on a solve of a large grid block adds the CHANGE of the energy on the nodes the round's moves
+    stamped to the previous evaluation (energy_delta_grid_kernel) instead of passing over the block again.  The energies it
+    reports -- cold start with many rounds, warm start, exact convergence and tolerance stop -- must be those of the full
+    pass (phmrf_mrf_energy), on a rectangular (off-diagonal) and on an upper-triangular block."""
+    import torch
+    from phylo_hmrf_amd import Block, synthetic
+    from phylo_hmrf_amd.tree import PhyloTree
+    S, K = 4, 12
+    n = H * (H + 1) // 2 if diagonal else H * W
+    assert n >= 1 << 18                                    # (smaller blocks always take the full pass)
+    tree = PhyloTree(synthetic.tree_for(S))
+    rng = np.random.default_rng(3)
+    P = synthetic.sample_ou_params(rng, tree, K)
+    mu, cv = tree.mean_cov(P)
+    cv = cv + 1e-3 * np.eye(S)
+    dev = torch.device("cuda", 0)
+    Xd = synthetic.device_observations(torch, dev, 4, H, W, diagonal, K, mu, cv)
+    torch.cuda.synchronize()
+    b = Block(n, S, K)
+    b.set_observations_dev(Xd.data_ptr())
+    b.sync()
+    b.build_grid_graph(H, W, diagonal, 8, 0.5)
+    P2 = np.clip(P * (1 + 0.1 * rng.standard_normal(P.shape)), 1e-3, 50)
+    mu2, cv2 = tree.mean_cov(P2)
+    b.emission(mu2, cv2 + 1e-3 * np.eye(S))
+    for kw in (dict(init_mode=1, energy_tol_ppb=1000), dict(energy_tol_ppb=0)):
+        res = b.solve(1.0, **kw)
+        assert res["rounds"] >= 2
+        e_tot, e_un, e_pw = b.energy(1.0)
+        np.testing.assert_allclose([res["energy"], res["energy_unary"], res["energy_pair"]], [e_tot, e_un, e_pw], rtol=1e-11)
+    P3 = np.clip(P2 * (1 + 0.03 * rng.standard_normal(P.shape)), 1e-3, 50)                 # the next EM iteration's warm start
+    mu3, cv3 = tree.mean_cov(P3)
+    b.emission(mu3, cv3 + 1e-3 * np.eye(S))
+    res = b.solve(1.0, energy_tol_ppb=1000)
+    e_tot, e_un, e_pw = b.energy(1.0)
+    assert res["rounds"] >= 2 and res["energy"] < res["energy_init"]
+    np.testing.assert_allclose([res["energy"], res["energy_unary"], res["energy_pair"]], [e_tot, e_un, e_pw], rtol=1e-11)
+    b.close()
