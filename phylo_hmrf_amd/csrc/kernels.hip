@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256) void energy_delta_grid_kernel(const float* __r
 //               one atomic flush per workgroup at the end (grid is capped, blocks stride over tiles)
 // -------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // GRID: the block is the reference's 8-neighbour stencil on a grid: the neighbours are found by geometry and their
 // weights come from the forward-edge records (16 B per node, each edge stored once) instead of the explicit adjacency
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
                                                         float* __restrict__ post_out, double* __restrict__ accum,
                                                         int gH, int gW, int gdiag, const float4* __restrict__ fwd_w) {
   extern __shared__ float lds[];
-  constexpr int M = 1 + S + S * S;
+  constexpr int M = 1 + S + S * (S + 1) / 2;      // features [1 | x | x_s x_t, s <= t]: x x^T is symmetric
   constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
   const int TB = blockDim.x;
   float* tile = lds;            // [TB][Kp]
@@ -626,34 +627,39 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
       f[0] = 1.f;
 #pragma unroll
       for (int s = 0; s < S; ++s) f[1 + s] = x[s];
+      {
+        int q = 1 + S;
 #pragma unroll
-      for (int s = 0; s < S; ++s)
+        for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int t = 0; t < S; ++t) f[1 + S + s * S + t] = x[s] * x[t];
+          for (int t = s; t < S; ++t) f[q++] = x[s] * x[t];
+      }
     }
     __syncthreads();
     if (WRITE_POST) tile_to_rows<VEC>(post_out + base * K, rows, K, Kp, tile);
     // phase 4: stats[k][m] += sum_r gamma[r][k] * feat[r][m] -- a (K x rows) x (rows x M) product per tile, on the matrix
-    // cores in exact f32 (v_mfma_f32_32x32x2_f32: A lane l = gamma^T[k = l & 31][r = l >> 5], B lane l = feat[r = l >> 5]
-    // [m = l & 31], 16 results per lane at column l & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).  Each wave sums
-    // its own 64 rows of the tile in f32 and adds the 32 x 32 block to the workgroup's f64 accumulators in LDS.
+    // cores in exact f32, in 16 x 16 blocks (v_mfma_f32_16x16x4_f32: A lane l = gamma^T[k = l & 15][r = l >> 4], B lane l =
+    // feat[r = l >> 4][m = l & 15], four results per lane at column l & 15, rows 4 (l >> 4) + reg): K = 20 states and the
+    // M = 15 features of S = 4 are 2 x 1 blocks, where the 32 x 32 form took twice the matrix-core time for a block that
+    // is 40 % padding.  Each wave sums its own 64 rows of the tile in f32 and adds the blocks to the workgroup's f64
+    // accumulators in LDS.
     {
-      const int r0 = wave * 64 + (lane >> 5), c = lane & 31;
-      for (int kb = 0; kb < K; kb += 32)
-        for (int mb = 0; mb < M; mb += 32) {
-          f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int r0 = wave * 64 + (lane >> 4), c = lane & 15;
+      for (int kb = 0; kb < K; kb += 16)
+        for (int mb = 0; mb < M; mb += 16) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
           const bool ka = kb + c < K, ma = mb + c < M;
 #pragma unroll 8
-          for (int st = 0; st < 32; ++st) {
-            const int r = r0 + 2 * st;
+          for (int st = 0; st < 16; ++st) {
+            const int r = r0 + 4 * st;
             const float a = (ka && r < rows) ? tile[r * Kp + kb + c] : 0.f;
             const float bq = (ma && r < rows) ? feat[r * Mp + mb + c] : 0.f;
-            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, d, 0, 0, 0);
           }
           if (ma && wave * 64 < rows) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const int k = kb + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            for (int q = 0; q < 4; ++q) {
+              const int k = kb + 4 * (lane >> 4) + q;
               if (k < K) atomicAdd(sacc + k * M + mb + c, (double)d[q]);
             }
           }
@@ -665,11 +671,17 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
   __syncthreads();
   for (int o = threadIdx.x; o < KM; o += TB) {
     const int k = o / M, m = o - k * M;
-    int dst;
-    if (m == 0) dst = k;
-    else if (m <= S) dst = K + k * S + (m - 1);
-    else dst = K + K * S + k * S * S + (m - 1 - S);
-    atomicAdd(accum + ACC_STATS + dst, sacc[o]);
+    if (m == 0) {
+      atomicAdd(accum + ACC_STATS + k, sacc[o]);
+    } else if (m <= S) {
+      atomicAdd(accum + ACC_STATS + K + k * S + (m - 1), sacc[o]);
+    } else {                                  // pair (s, t), s <= t, in the order the features were written; mirrored
+      int q = m - 1 - S, ps = 0;
+      while (q >= S - ps) { q -= S - ps; ++ps; }
+      const int pt = ps + q;
+      atomicAdd(accum + ACC_STATS + K + K * S + k * S * S + ps * S + pt, sacc[o]);
+      if (pt != ps) atomicAdd(accum + ACC_STATS + K + K * S + k * S * S + pt * S + ps, sacc[o]);
+    }
   }
   const double t0 = block_sum(c_pair, red);
   const double t1 = block_sum(c_pcn, red);
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
 
 template <int S>
 int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool write_post) {
-  constexpr int M = 1 + S + S * S;
+  constexpr int M = 1 + S + S * (S + 1) / 2;      // features [1 | x | x_s x_t, s <= t]: x x^T is symmetric
   constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
   const int K = b->K, Kp = padded_k(K);
   static const int tb_env = getenv("PHMRF_POST_TB") ? atoi(getenv("PHMRF_POST_TB")) : 0;     // development: tile rows
@@ -698,7 +710,8 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes;
   static const int cap_env = getenv("PHMRF_POST_GRID") ? atoi(getenv("PHMRF_POST_GRID")) : 0;   // development: grid cap
   // (grid cap swept on the 12.4 M-node block: 2048 -> 925 us, 1024 -> 1069, 768 = three resident workgroups per CU -> 885, 512 -> 1111)
-  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 50 * 1024 ? 256 * 3 : 256 * 8) * (256 / TB));
+  // (round 3, packed features: 39 KB at K = 20, S = 4 = four resident workgroups per CU: 768 -> 790 us, 1024 -> 680, 1280 -> 810)
+  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 40 * 1024 ? 256 * 4 : (lds <= 50 * 1024 ? 256 * 3 : 256 * 8)) * (256 / TB));
   const int use_w = estimate_type == 3 ? 1 : 0;
   // the grid form needs the 8-neighbour stencil's forward-edge records (phmrf_block_set_grid / build_grid_graph)
   const bool grid_form = b->has_grid && b->grid_complete && b->fwd_w && b->D == 8 && b->num_neighbor == 8;
