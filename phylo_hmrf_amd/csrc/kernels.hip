@@ -486,10 +486,13 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
                                                         int gH, int gW, int gdiag, const float4* __restrict__ fwd_w) {
   extern __shared__ float lds[];
   constexpr int M = 1 + S + S * (S + 1) / 2;      // features [1 | x | x_s x_t, s <= t]: x x^T is symmetric
-  constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
+  // ... and every one of them is a product of two entries of xa = [1 | x]: only xa goes to LDS (S + 1 floats per node
+  // instead of M), the product is formed where the statistics read it
+  constexpr int Mp = ((S + 1) % 2 == 0) ? S + 2 : S + 1;
+  constexpr int NMB = (M + 15) / 16;
   const int TB = blockDim.x;
   float* tile = lds;            // [TB][Kp]
-  float* feat = lds + TB * Kp;  // [TB][Mp]
+  float* feat = lds + TB * Kp;  // [TB][Mp]: xa
   __shared__ double red[8];
 
   const int KM = K * M;
@@ -498,6 +501,24 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
   for (int o = threadIdx.x; o < KM; o += TB) sacc[o] = 0.0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double c_pair = 0.0, c_pcn = 0.0, c_un = 0.0;
+  // the two factors of my feature column (lane & 15) in each 16-wide block of features: m = 0 -> (0, 0) = 1 * 1,
+  // 1 <= m <= S -> (0, m) = 1 * x_{m-1}, pairs s <= t in the order of the flush below -> (s + 1, t + 1)
+  int fa[NMB], fb[NMB];
+#pragma unroll
+  for (int q = 0; q < NMB; ++q) {
+    const int m = q * 16 + (lane & 15);
+    int a = 0, bq = 0;
+    if (m >= 1 && m <= S) {
+      bq = m;
+    } else if (m > S && m < M) {
+      int r = m - 1 - S, ps = 0;
+      while (r >= S - ps) { r -= S - ps; ++ps; }
+      a = ps + 1;
+      bq = ps + r + 1;
+    }
+    fa[q] = a;
+    fb[q] = bq;
+  }
   __syncthreads();
 
   for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
@@ -627,13 +648,6 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
       f[0] = 1.f;
 #pragma unroll
       for (int s = 0; s < S; ++s) f[1 + s] = x[s];
-      {
-        int q = 1 + S;
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-          for (int t = s; t < S; ++t) f[q++] = x[s] * x[t];
-      }
     }
     __syncthreads();
     if (WRITE_POST) tile_to_rows<VEC>(post_out + base * K, rows, K, Kp, tile);
@@ -646,14 +660,17 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     {
       const int r0 = wave * 64 + (lane >> 4), c = lane & 15;
       for (int kb = 0; kb < K; kb += 16)
-        for (int mb = 0; mb < M; mb += 16) {
+#pragma unroll
+        for (int qb = 0; qb < NMB; ++qb) {
+          const int mb = qb * 16;
           f32x4 d = {0.f, 0.f, 0.f, 0.f};
           const bool ka = kb + c < K, ma = mb + c < M;
+          const int ia = fa[qb], ib = fb[qb];
 #pragma unroll 8
           for (int st = 0; st < 16; ++st) {
             const int r = r0 + 4 * st;
             const float a = (ka && r < rows) ? tile[r * Kp + kb + c] : 0.f;
-            const float bq = (ma && r < rows) ? feat[r * Mp + mb + c] : 0.f;
+            const float bq = (ma && r < rows) ? feat[r * Mp + ia] * feat[r * Mp + ib] : 0.f;
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, d, 0, 0, 0);
           }
           if (ma && wave * 64 < rows) {
@@ -697,7 +714,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
 template <int S>
 int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool write_post) {
   constexpr int M = 1 + S + S * (S + 1) / 2;      // features [1 | x | x_s x_t, s <= t]: x x^T is symmetric
-  constexpr int Mp = (M % 2 == 0) ? M + 1 : M;
+  constexpr int Mp = ((S + 1) % 2 == 0) ? S + 2 : S + 1;      // LDS holds [1 | x] per node
   const int K = b->K, Kp = padded_k(K);
   static const int tb_env = getenv("PHMRF_POST_TB") ? atoi(getenv("PHMRF_POST_TB")) : 0;     // development: tile rows
   int TB = (tb_env == 64 || tb_env == 128 || tb_env == 256) ? tb_env : 256;
@@ -711,7 +728,7 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   static const int cap_env = getenv("PHMRF_POST_GRID") ? atoi(getenv("PHMRF_POST_GRID")) : 0;   // development: grid cap
   // (grid cap swept on the 12.4 M-node block: 2048 -> 925 us, 1024 -> 1069, 768 = three resident workgroups per CU -> 885, 512 -> 1111)
   // (round 3, packed features: 39 KB at K = 20, S = 4 = four resident workgroups per CU: 768 -> 790 us, 1024 -> 680, 1280 -> 810)
-  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 40 * 1024 ? 256 * 4 : (lds <= 50 * 1024 ? 256 * 3 : 256 * 8)) * (256 / TB));
+  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 40 * 1024 ? 256 * 4 : (lds <= 53 * 1024 ? 256 * 3 : 256 * 8)) * (256 / TB));
   const int use_w = estimate_type == 3 ? 1 : 0;
   // the grid form needs the 8-neighbour stencil's forward-edge records (phmrf_block_set_grid / build_grid_graph)
   const bool grid_form = b->has_grid && b->grid_complete && b->fwd_w && b->D == 8 && b->num_neighbor == 8;

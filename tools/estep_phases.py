@@ -5,7 +5,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from phylo_hmrf_amd import Block, synthetic
 from phylo_hmrf_amd.tree import PhyloTree
-K, S, N = int(sys.argv[1]), 4, int(sys.argv[2])
+K, S, N = int(sys.argv[1]), int(os.environ.get("PHMRF_TOOL_S", "4")), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 pert = float(sys.argv[4]) if len(sys.argv) > 4 else 0.005
 tree = PhyloTree(synthetic.tree_for(S)); rng = np.random.default_rng(0)
