@@ -55,7 +55,7 @@ PHMRF_API int phmrf_set_device(int device);
 /* ---- block lifetime --------------------------------------------------------------------------- */
 /* n nodes (Hi-C bin pairs), S species (leaves), K states.  K <= 64, S <= 16, n < 2^31 - 64.
  * Limits per entry point: the emission (b1) covers S <= 16; phmrf_posterior_stats (b3) covers S <= 8 at every K <= 64
- * (its LDS tile, 64 rows x (K + 1 + S + S(S+1)/2) floats plus K (1 + S + S(S+1)/2) doubles, is at most 51 KB of the CU's 160) and
+ * (its LDS tile, 64 rows x (K + 2 + S) floats plus K (1 + S + S(S+1)/2) doubles, is at most 42 KB of the CU's 160) and
  * returns PHMRF_ERR_UNSUPPORTED for S > 8; node degree <= 64 (phmrf_block_set_graph). */
 PHMRF_API int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out);
 /* Environment, read when a block is created: PHMRF_DETERMINISTIC=1 makes the label solver's reductions independent of

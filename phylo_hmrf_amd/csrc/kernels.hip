@@ -478,7 +478,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // weights come from the forward-edge records (16 B per node, each edge stored once) instead of the explicit adjacency
 // rows (64 B per node) -- the same neighbours in the same order, so the two forms agree bit for bit.
 template <int S, int VEC, bool WRITE_POST, bool GRID>
-__global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ X, const float* __restrict__ logprob,
+__global__ __launch_bounds__(256, 5) void posterior_kernel(const float* __restrict__ X, const float* __restrict__ logprob,
                                                         int64_t n, int K, int Kp, int D,
                                                         const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                         const uint8_t* __restrict__ labels, float beta, int use_w,
@@ -727,8 +727,9 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes;
   static const int cap_env = getenv("PHMRF_POST_GRID") ? atoi(getenv("PHMRF_POST_GRID")) : 0;   // development: grid cap
   // (grid cap swept on the 12.4 M-node block: 2048 -> 925 us, 1024 -> 1069, 768 = three resident workgroups per CU -> 885, 512 -> 1111)
-  // (round 3, packed features: 39 KB at K = 20, S = 4 = four resident workgroups per CU: 768 -> 790 us, 1024 -> 680, 1280 -> 810)
-  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 40 * 1024 ? 256 * 4 : (lds <= 53 * 1024 ? 256 * 3 : 256 * 8)) * (256 / TB));
+  // (round 3, packed features: 39 KB at K = 20, S = 4 = four resident workgroups per CU: 768 -> 790 us, 1024 -> 680, 1280 -> 810;
+  //  then only [1 | x] in LDS: 29 KB, and 84 registers under __launch_bounds__(256, 5) = five per CU: 1024 -> 700, 1280 -> 650)
+  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 32 * 1024 ? 256 * 5 : (lds <= 40 * 1024 ? 256 * 4 : (lds <= 53 * 1024 ? 256 * 3 : 256 * 8))) * (256 / TB));
   const int use_w = estimate_type == 3 ? 1 : 0;
   // the grid form needs the 8-neighbour stencil's forward-edge records (phmrf_block_set_grid / build_grid_graph)
   const bool grid_form = b->has_grid && b->grid_complete && b->fwd_w && b->D == 8 && b->num_neighbor == 8;
