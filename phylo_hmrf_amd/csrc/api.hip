@@ -1037,15 +1037,22 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
   tic(b);
   int n_launch = 0;
+  // The apply pass (a thread per fine node) returns at once when the child's two passes switched no super-cell: the
+  // child counts its switches in its own counter slot, one per label of this sweep (zeroed together up front), and the
+  // apply kernel reads it on the device -- the host does not wait for a count.
+  static const bool no_gate = getenv("PHMRF_COARSE_NO_GATE") != nullptr;      // development: A/B timing
+  PHMRF_HIP(hipMemsetAsync(c->counters, 0, 64 * sizeof(unsigned long long), b->stream));
   for (int a = alpha_lo; a < alpha_hi; ++a) {
+    c->counter_slot = a & 63;
     PHMRF_TRY(launch_coarsen(b, c, s, off, a, beta));
     // (measured: the filtered multi-label kernel is 15-20 % slower than the plain one on these one-label problems)
     PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, -1));
     PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, -1));
     if (b->tick) ++b->tick;
-    PHMRF_TRY(launch_coarse_apply(b, c, s, off, a));
+    PHMRF_TRY(launch_coarse_apply(b, c, s, off, a, no_gate ? nullptr : c->counters + (a & 63)));
     n_launch += 4;
   }
+  c->counter_slot = 0;
   toc(b, KC_COARSE, n_launch);
   return PHMRF_OK;
 }

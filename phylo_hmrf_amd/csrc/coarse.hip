@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
 __global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const uint8_t* __restrict__ c_labels, int alpha,
                                                            uint8_t* __restrict__ labels, uint16_t* __restrict__ stamp, int tick,
                                                            const int32_t* __restrict__ nbr, int D,
-                                                           unsigned long long* __restrict__ changed) {
+                                                           unsigned long long* __restrict__ changed,
+                                                           const unsigned long long* __restrict__ gate) {
+  if (gate && *gate == 0ull) return;            // the child's passes switched no super-cell: nothing to take over
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y * blockDim.y + threadIdx.y;
   bool moved = false;
@@ -198,11 +200,11 @@ int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int
   return PHMRF_OK;
 }
 
-int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha) {
+int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
   const dim3 blk(64, 4), grd((g.W + 63) / 64, (g.H + 3) / 4);
   hipLaunchKernelGGL(coarse_apply_kernel, grd, blk, 0, b->stream, g, child->labels, alpha, b->labels,
-                     b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot);
+                     b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot, gate);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

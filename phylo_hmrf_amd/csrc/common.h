@@ -178,7 +178,7 @@ int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool writ
 int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
 int64_t coarse_nodes(const phmrf_block* b, int s, int off);                        // nodes of the coarse grid (s, off)
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta);
-int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha);
+int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
 
 // ---- grid geometry for the kernels that find a node's neighbours by arithmetic (device code) ---------------------
