@@ -369,7 +369,7 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
 int phmrf_block_destroy(phmrf_block_t b) {
   if (!b) return PHMRF_OK;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  for (int lv = 0; lv < 3; ++lv)
+  for (int lv = 0; lv < 12; ++lv)
     if (b->coarse[lv]) {
       b->coarse[lv]->stream = b->coarse[lv]->own_stream;
       phmrf_block_destroy(b->coarse[lv]);
@@ -380,6 +380,7 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->labels);
   dev_free(b->labels_tmp);
   dev_free(b->labels_eval);
+  dev_free(b->coarse_flag);
   dev_free(b->sgain);
   for (int s = 0; s < 4; ++s) dev_free(b->saved[s]);
   dev_free(b->nbr);
@@ -422,7 +423,7 @@ int phmrf_block_set_stream(phmrf_block_t b, void* hip_stream) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   PHMRF_HIP(hipStreamSynchronize(b->stream));
   b->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : b->own_stream;
-  for (int lv = 0; lv < 3; ++lv)
+  for (int lv = 0; lv < 12; ++lv)
     if (b->coarse[lv]) b->coarse[lv]->stream = b->stream;
   return PHMRF_OK;
 }
@@ -1002,8 +1003,9 @@ static const int COARSE_SCALE[N_COARSE] = {2, 4, 8};
 static const int64_t COARSE_ON_DIV = 8;       // "moved at large": a solve changed >= 1/8 of the labels so far
 static const int64_t COARSE_ROUND_DIV = 4;    // "moving at large": a round changed >= 1/4 of the labels (a cold start)
 
-static int coarse_child(phmrf_block_t b, int level, phmrf_block** out) {
-  if (!b->coarse[level]) {
+static int coarse_child(phmrf_block_t b, int level_slot, phmrf_block** out) {       // level_slot = level * 4 + slot in a batch
+  const int level = level_slot / 4;
+  if (!b->coarse[level_slot]) {
     const int s = COARSE_SCALE[level];
     const int64_t nmax = coarse_nodes(b, s, s - 1);
     phmrf_block* c = nullptr;
@@ -1019,11 +1021,11 @@ static int coarse_child(phmrf_block_t b, int level, phmrf_block** out) {
     c->has_graph = true;
     c->has_logprob = true;
     c->D = 0;
-    b->coarse[level] = c;
+    b->coarse[level_slot] = c;
   }
-  b->coarse[level]->stream = b->stream;
-  b->coarse[level]->num_neighbor = b->num_neighbor;
-  *out = b->coarse[level];
+  b->coarse[level_slot]->stream = b->stream;
+  b->coarse[level_slot]->num_neighbor = b->num_neighbor;
+  *out = b->coarse[level_slot];
   return PHMRF_OK;
 }
 
@@ -1031,28 +1033,48 @@ static int coarse_child(phmrf_block_t b, int level, phmrf_block** out) {
 // super-cell grid -> apply.  4 launches per label.
 static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off, int shift_r, int shift_c, int alpha_lo,
                                 int alpha_hi) {
-  phmrf_block* c = nullptr;
-  PHMRF_TRY(coarse_child(b, level, &c));
   const int s = COARSE_SCALE[level];
   if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
+  // Labels in batches of four: one pass over the block builds the four child problems (the label-independent two thirds of
+  // coarsen_kernel's reads once instead of four times), then label by label the child's two strip passes and the apply
+  // pass, in order.  A label whose predecessors in the batch moved something gets its problem rebuilt first -- decided on
+  // the device (coarse_apply_kernel raises b->coarse_flag, the one-label rebuild returns at once while it is down): the
+  // sequence of labellings is the one-label-at-a-time sequence, the host never waits.  PHMRF_COARSE_BATCH=1: one by one.
+  static const int batch_env = getenv("PHMRF_COARSE_BATCH") ? atoi(getenv("PHMRF_COARSE_BATCH")) : 4;
+  const int batch = (batch_env == 1 || batch_env == 2) ? batch_env : 4;
+  static const bool no_gate = getenv("PHMRF_COARSE_NO_GATE") != nullptr;      // development: A/B timing
+  phmrf_block* ch[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int q = 0; q < batch; ++q) PHMRF_TRY(coarse_child(b, level * 4 + q, &ch[q]));
+  if (!b->coarse_flag) PHMRF_TRY(dev_alloc(&b->coarse_flag, (size_t)1));
   tic(b);
   int n_launch = 0;
-  // The apply pass (a thread per fine node) returns at once when the child's two passes switched no super-cell: the
-  // child counts its switches in its own counter slot, one per label of this sweep (zeroed together up front), and the
-  // apply kernel reads it on the device -- the host does not wait for a count.
-  static const bool no_gate = getenv("PHMRF_COARSE_NO_GATE") != nullptr;      // development: A/B timing
-  PHMRF_HIP(hipMemsetAsync(c->counters, 0, 64 * sizeof(unsigned long long), b->stream));
-  for (int a = alpha_lo; a < alpha_hi; ++a) {
-    c->counter_slot = a & 63;
-    PHMRF_TRY(launch_coarsen(b, c, s, off, a, beta));
-    // (measured: the filtered multi-label kernel is 15-20 % slower than the plain one on these one-label problems)
-    PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, -1));
-    PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, -1));
-    if (b->tick) ++b->tick;
-    PHMRF_TRY(launch_coarse_apply(b, c, s, off, a, no_gate ? nullptr : c->counters + (a & 63)));
-    n_launch += 4;
+  for (int a0 = alpha_lo; a0 < alpha_hi; a0 += batch) {
+    const int nl = std::min(batch, alpha_hi - a0);
+    int alphas[4] = {a0, a0 + 1, a0 + 2, a0 + 3};
+    PHMRF_HIP(hipMemsetAsync(b->coarse_flag, 0, sizeof(unsigned int), b->stream));
+    // The apply pass (a thread per fine node) returns at once when the child's two passes switched no super-cell: the
+    // child counts its switches in its own counter slot 0, and the apply kernel reads it on the device.
+    for (int q = 0; q < nl; ++q) {
+      ch[q]->counter_slot = 0;
+      PHMRF_HIP(hipMemsetAsync(ch[q]->counters, 0, sizeof(unsigned long long), b->stream));
+    }
+    PHMRF_TRY(launch_coarsen_batch(b, ch, alphas, nl == 3 ? 3 : nl, s, off, beta, nullptr));
+    ++n_launch;
+    for (int q = 0; q < nl; ++q) {
+      phmrf_block* c = ch[q];
+      if (q > 0) {        // rebuilt only if a label before it in the batch has moved (b->coarse_flag, read on the device)
+        phmrf_block* one[1] = {c};
+        PHMRF_TRY(launch_coarsen_batch(b, one, &alphas[q], 1, s, off, beta, b->coarse_flag));
+        ++n_launch;
+      }
+      // (measured: the filtered multi-label kernel is 15-20 % slower than the plain one on these one-label problems)
+      PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, -1));
+      PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, -1));
+      if (b->tick) ++b->tick;
+      PHMRF_TRY(launch_coarse_apply(b, c, s, off, alphas[q], no_gate ? nullptr : c->counters, b->coarse_flag));
+      n_launch += 3;
+    }
   }
-  c->counter_slot = 0;
   toc(b, KC_COARSE, n_launch);
   return PHMRF_OK;
 }
@@ -1084,7 +1106,7 @@ int phmrf_block_coarse_problem(phmrf_block_t b, double beta, int scale, int offs
   *nc = coarse_nodes(b, scale, offset);
   if (!D_out && !lam_out) return PHMRF_OK;
   phmrf_block* c = nullptr;
-  PHMRF_TRY(coarse_child(b, scale == 2 ? 0 : (scale == 4 ? 1 : 2), &c));
+  PHMRF_TRY(coarse_child(b, 4 * (scale == 2 ? 0 : (scale == 4 ? 1 : 2)), &c));
   if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
   PHMRF_TRY(launch_coarsen(b, c, scale, offset, alpha, (float)beta));
   if (D_out) PHMRF_TRY(download(D_out, c->uT + *nc, (size_t)*nc * sizeof(float), b->stream));

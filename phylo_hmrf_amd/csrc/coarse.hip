@@ -54,17 +54,36 @@ __device__ __forceinline__ float comp4(const float4& v, int e) { return e == 0 ?
 // above / below), and the s x s nodes of a super-cell are s adjacent lanes x s loop trips: their sums meet in an
 // s-lane butterfly.  A cross edge is seen from both of its super-cells: each adds its own unary share, the one the
 // pair's slot belongs to adds lambda.  No atomics.
-template <int SCALE>
+// NL labels per pass (round 3): the labels, the forward-edge records of the node and of its four backward neighbours and
+// the neighbours' labels -- two thirds of the kernel's time, and the same for every label -- are read once for up to four
+// labels; each label's problem goes to a child block of its own.  Per label the arithmetic is what the one-label pass
+// does, in the same order, so a problem built in a batch and one rebuilt alone (`rebuild`: only when a move since the
+// batch has changed the labelling, coarse_apply_kernel's flag) are the same numbers.
+struct CoarseOut {
+  float* c_uT[4];
+  float4* c_fwd[4];
+  uint8_t* c_labels[4];
+  int alpha[4];      // (slots past nl repeat the first label: computed, not written)
+  int nl;
+};
+
+template <int SCALE, int NL>
 __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, int64_t nc, const uint8_t* __restrict__ labels,
                                                       const float* __restrict__ uT, const float4* __restrict__ fwd_w,
-                                                      int alpha, float beta, float* __restrict__ c_uT,
-                                                      float4* __restrict__ c_fwd, uint8_t* __restrict__ c_labels) {
+                                                      CoarseOut out, float beta, const unsigned int* __restrict__ rebuild) {
+  if (rebuild && *rebuild == 0u) return;        // nothing has moved since the batch built this label's problem
   const int I = blockIdx.y;
   const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x) - g.off;      // (j + off) % SCALE == lane % SCALE
   const int J = (int)(blockIdx.x * blockDim.x + threadIdx.x) / SCALE;
   constexpr int FI[4] = {0, 1, 1, 1};
   constexpr int FJ[4] = {1, -1, 0, 1};
-  float D = 0.f, lam[4] = {0.f, 0.f, 0.f, 0.f};
+  float D[NL], lam[NL][4];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    D[q] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lam[q][e] = 0.f;
+  }
   float wcross = 0.f;                       // total weight of the fine edges that leave the super-cell
 #pragma unroll
   for (int di = 0; di < SCALE; ++di) {
@@ -72,7 +91,10 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
     const int node = fine_node(g, i, j);
     if (node < 0) continue;
     const int li = labels[node];
-    if (li != alpha) D += uT[(int64_t)alpha * n + node] - uT[(int64_t)li * n + node];
+    const float ucur = uT[(int64_t)li * n + node];
+#pragma unroll
+    for (int q = 0; q < NL; ++q)
+      if (li != out.alpha[q]) D[q] += uT[(int64_t)out.alpha[q] * n + node] - ucur;
     const float4 fw = fwd_w[node];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {           // edges this node holds
@@ -82,17 +104,22 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
       const int nn = fine_node(g, ni, nj);
       if (nn < 0) continue;
       const int lj = labels[nn];
-      const float t00 = (li != lj) ? w : 0.f, t01 = (li != alpha) ? w : 0.f, t10 = (alpha != lj) ? w : 0.f;
       const int dI = (ni + g.off) / SCALE - I, dJ = (nj + g.off) / SCALE - J;
-      if (dI == 0 && dJ == 0) {
-        D -= beta * t00;
-      } else {
-        const float lv = 0.5f * (t10 + t01 - t00);
-        D += beta * (t10 - t00 - lv);
-        wcross += w;
-        if (dI == 0 && dJ == 1) lam[0] += lv;
-        else if (dI == 1) lam[2 + dJ] += lv;           // SW (dJ -1) -> 1, S -> 2, SE -> 3
-        // (dI == 0, dJ == -1): the pair's slot is the E slot of the other super-cell, which adds it below
+      const bool inside = dI == 0 && dJ == 0;
+      if (!inside) wcross += w;
+#pragma unroll
+      for (int q = 0; q < NL; ++q) {
+        const int alpha = out.alpha[q];
+        const float t00 = (li != lj) ? w : 0.f, t01 = (li != alpha) ? w : 0.f, t10 = (alpha != lj) ? w : 0.f;
+        if (inside) {
+          D[q] -= beta * t00;
+        } else {
+          const float lv = 0.5f * (t10 + t01 - t00);
+          D[q] += beta * (t10 - t00 - lv);
+          if (dI == 0 && dJ == 1) lam[q][0] += lv;
+          else if (dI == 1) lam[q][2 + dJ] += lv;           // SW (dJ -1) -> 1, S -> 2, SE -> 3
+          // (dI == 0, dJ == -1): the pair's slot is the E slot of the other super-cell, which adds it below
+        }
       }
     }
 #pragma unroll
@@ -106,30 +133,41 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
       const float w = comp4(fwd_w[nn], e);
       if (w == 0.f) continue;
       const int lj = labels[nn];                      // holder nn = "i" of the table, this node = "j"
-      const float t00 = (lj != li) ? w : 0.f, t01 = (lj != alpha) ? w : 0.f, t10 = (alpha != li) ? w : 0.f;
-      const float lv = 0.5f * (t10 + t01 - t00);
-      D += beta * (t01 - t00 - lv);
       wcross += w;
-      if (dI == 0 && dJ == 1) lam[0] += lv;            // the holder sits in my E neighbour (a fine SW edge)
+#pragma unroll
+      for (int q = 0; q < NL; ++q) {
+        const int alpha = out.alpha[q];
+        const float t00 = (lj != li) ? w : 0.f, t01 = (lj != alpha) ? w : 0.f, t10 = (alpha != li) ? w : 0.f;
+        const float lv = 0.5f * (t10 + t01 - t00);
+        D[q] += beta * (t01 - t00 - lv);
+        if (dI == 0 && dJ == 1) lam[q][0] += lv;            // the holder sits in my E neighbour (a fine SW edge)
+      }
     }
   }
   // the SCALE columns of a super-cell are SCALE adjacent lanes (fixed summation tree: deterministic)
 #pragma unroll
   for (int m = 1; m < SCALE; m <<= 1) {
-    D += __shfl_xor(D, m, 64);
     wcross += __shfl_xor(wcross, m, 64);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) lam[q] += __shfl_xor(lam[q], m, 64);
+    for (int q = 0; q < NL; ++q) {
+      D[q] += __shfl_xor(D[q], m, 64);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lam[q][e] += __shfl_xor(lam[q][e], m, 64);
+    }
   }
   if ((threadIdx.x & (SCALE - 1)) != 0 || J >= g.Wc || (g.diagonal && J < I)) return;
   const int c = coarse_node(g, I, J);
-  c_uT[c] = 0.f;
-  // A super-cell whose switch cost exceeds everything its pairs could give back (lambda <= w on every cross edge) is in
-  // no optimal switch set: taking it out of any set lowers the energy.  It is pinned (strip.hip: unary >= 1e29 = no
-  // proposal), and a strip of pinned super-cells costs the strip kernel its staging only.
-  c_uT[nc + c] = (D > beta * wcross * 1.0001f + 1e-6f) ? 1.0e30f : D;
-  c_fwd[c] = make_float4(lam[0], lam[1], lam[2], lam[3]);
-  c_labels[c] = 0;
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    if (q >= out.nl) continue;
+    out.c_uT[q][c] = 0.f;
+    // A super-cell whose switch cost exceeds everything its pairs could give back (lambda <= w on every cross edge) is in
+    // no optimal switch set: taking it out of any set lowers the energy.  It is pinned (strip.hip: unary >= 1e29 = no
+    // proposal), and a strip of pinned super-cells costs the strip kernel its staging only.
+    out.c_uT[q][nc + c] = (D[q] > beta * wcross * 1.0001f + 1e-6f) ? 1.0e30f : D[q];
+    out.c_fwd[q][c] = make_float4(lam[q][0], lam[q][1], lam[q][2], lam[q][3]);
+    out.c_labels[q][c] = 0;
+  }
 }
 
 // One thread per fine node: take alpha where the node's super-cell switched.
@@ -137,7 +175,8 @@ __global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const u
                                                            uint8_t* __restrict__ labels, uint16_t* __restrict__ stamp, int tick,
                                                            const int32_t* __restrict__ nbr, int D,
                                                            unsigned long long* __restrict__ changed,
-                                                           const unsigned long long* __restrict__ gate) {
+                                                           const unsigned long long* __restrict__ gate,
+                                                           unsigned int* __restrict__ moved_flag) {
   if (gate && *gate == 0ull) return;            // the child's passes switched no super-cell: nothing to take over
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y * blockDim.y + threadIdx.y;
@@ -157,7 +196,10 @@ __global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const u
     }
   }
   const unsigned long long m = __ballot(moved);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(changed, (unsigned long long)__popcll(m));
+  if ((threadIdx.x & 63) == 0 && m) {
+    atomicAdd(changed, (unsigned long long)__popcll(m));
+    if (moved_flag) *moved_flag = 1u;           // the labelling has changed: later labels of the batch rebuild their problems
+  }
 }
 
 }  // namespace
@@ -179,32 +221,56 @@ int64_t coarse_nodes(const phmrf_block* b, int s, int off) {
   return g.diagonal ? (int64_t)g.Hc * (g.Hc + 1) / 2 : (int64_t)g.Hc * g.Wc;
 }
 
-// Point the child block at the coarse grid of (s, off) and fill its unary planes / forward weights / labels for alpha.
-int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta) {
+// Point the child blocks at the coarse grid of (s, off) and fill their unary planes / forward weights / labels for up to
+// four labels in one pass (alphas[q] < 0: unused).  rebuild != nullptr: the pass runs only if *rebuild != 0 (device).
+int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, const int* alphas, int nl, int s, int off, float beta,
+                         const unsigned int* rebuild) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
-  child->H = g.Hc;
-  child->W = g.Wc;
-  child->diagonal = g.diagonal;
-  child->n = coarse_nodes(b, s, off);
+  CoarseOut out;
+  for (int q = 0; q < 4; ++q) {
+    phmrf_block* child = children[q < nl ? q : 0];
+    if (q < nl) {
+      child->H = g.Hc;
+      child->W = g.Wc;
+      child->diagonal = g.diagonal;
+      child->n = coarse_nodes(b, s, off);
+    }
+    out.c_uT[q] = child->uT;
+    out.c_fwd[q] = child->fwd_w;
+    out.c_labels[q] = child->labels;
+    out.alpha[q] = q < nl ? alphas[q] : alphas[0];
+  }
+  out.nl = nl;
+  const int64_t nc = children[0]->n;
   const dim3 blk(256), grd((g.Wc * s + 255) / 256, g.Hc);
-  if (s == 2)
-    hipLaunchKernelGGL(coarsen_kernel<2>, grd, blk, 0, b->stream, g, b->n, child->n, b->labels, b->uT, b->fwd_w, alpha, beta,
-                       child->uT, child->fwd_w, child->labels);
-  else if (s == 4)
-    hipLaunchKernelGGL(coarsen_kernel<4>, grd, blk, 0, b->stream, g, b->n, child->n, b->labels, b->uT, b->fwd_w, alpha, beta,
-                       child->uT, child->fwd_w, child->labels);
-  else
-    hipLaunchKernelGGL(coarsen_kernel<8>, grd, blk, 0, b->stream, g, b->n, child->n, b->labels, b->uT, b->fwd_w, alpha, beta,
-                       child->uT, child->fwd_w, child->labels);
+#define PHMRF_LAUNCH_COARSEN(S_, NL_)                                                                                     \
+  hipLaunchKernelGGL((coarsen_kernel<S_, NL_>), grd, blk, 0, b->stream, g, b->n, nc, b->labels, b->uT, b->fwd_w, out, beta, rebuild)
+#define PHMRF_LAUNCH_COARSEN_S(S_)                                                                                        \
+  {                                                                                                                       \
+    if (nl == 1) PHMRF_LAUNCH_COARSEN(S_, 1);                                                                             \
+    else if (nl == 2) PHMRF_LAUNCH_COARSEN(S_, 2);                                                                        \
+    else PHMRF_LAUNCH_COARSEN(S_, 4);                                                                                     \
+  }
+  if (s == 2) PHMRF_LAUNCH_COARSEN_S(2)
+  else if (s == 4) PHMRF_LAUNCH_COARSEN_S(4)
+  else PHMRF_LAUNCH_COARSEN_S(8)
+#undef PHMRF_LAUNCH_COARSEN_S
+#undef PHMRF_LAUNCH_COARSEN
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
 
-int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate) {
+int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta) {
+  phmrf_block* one[1] = {child};
+  return launch_coarsen_batch(b, one, &alpha, 1, s, off, beta, nullptr);
+}
+
+int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate,
+                        unsigned int* moved_flag) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
   const dim3 blk(64, 4), grd((g.W + 63) / 64, (g.H + 3) / 4);
   hipLaunchKernelGGL(coarse_apply_kernel, grd, blk, 0, b->stream, g, child->labels, alpha, b->labels,
-                     b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot, gate);
+                     b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot, gate, moved_flag);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

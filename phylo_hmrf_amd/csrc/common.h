@@ -105,7 +105,8 @@ struct phmrf_block {
   float* uT = nullptr;                      // device [K][n]: unary planes, uT[k][i] = -logprob[i][k]
   bool uT_valid = false;                    //   ... current with logprob
   // coarse alpha-expansions (coarse.hip): child blocks holding the two-label problem of the super-cells, side 2, 4, 8
-  phmrf_block* coarse[3] = {nullptr, nullptr, nullptr};
+  phmrf_block* coarse[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [level * 4 + slot in a batch of labels]
+  unsigned int* coarse_flag = nullptr;      // device: set by coarse_apply_kernel when a label of the batch has moved
   int prop_tick = -1;                       // tick of the last proposal launch of this solve (-1: none)
   int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
   // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS
@@ -178,7 +179,10 @@ int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool writ
 int launch_fwd_weights(phmrf_block* b);                                             // ELL -> fwd_w (grid blocks)
 int64_t coarse_nodes(const phmrf_block* b, int s, int off);                        // nodes of the coarse grid (s, off)
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta);
-int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr);
+int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, const int* alphas, int nl, int s, int off, float beta,
+                         const unsigned int* rebuild);
+int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr,
+                        unsigned int* moved_flag = nullptr);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
 
 // ---- grid geometry for the kernels that find a node's neighbours by arithmetic (device code) ---------------------
