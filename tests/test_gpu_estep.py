@@ -801,6 +801,26 @@ def test_deterministic_mode_gives_identical_labellings():
     assert len(runs) == 3 and runs[0] == runs[1] == runs[2], runs
 
 
+def test_coarse_labels_in_batches_give_the_one_by_one_sequence():
+    """The coarse alpha-expansions build four labels' child problems per pass and rebuild a label's problem only after a move
+    (decided on the device, api.hip coarse_sweep_nocount).  The labellings must be those of the one-label-at-a-time order
+    (PHMRF_COARSE_BATCH=1): with PHMRF_DETERMINISTIC=1 both runs of the cold-start script give the same label hash, round
+    count and energy, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for batch in ("4", "1"):
+        env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", PHMRF_COARSE_BATCH=batch)
+        out = subprocess.run([sys.executable, "-c", DET_SCRIPT.replace("range(3)", "range(1)")], capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        runs.append(eval(line[len("RESULT"):])[0])
+    assert runs[0] == runs[1], runs
+    assert runs[0][1] >= 3                       # (several rounds: the coarse scales did run)
+
+
 @pytest.mark.parametrize("H,W,diagonal", [(520, 610, False), (800, 800, True)])
 def test_energy_of_later_rounds_from_the_touched_nodes_equals_the_full_pass(H, W, diagonal):
     """From its second round on a solve of a large grid block adds the CHANGE of the energy on the nodes the round's moves
