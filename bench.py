@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--block-threads", type=int, default=12,
+    ap.add_argument("--block-threads", type=int, default=14,
                     help="host threads driving blocks concurrently, each block on its own HIP stream (1 = sequential)")
     ap.add_argument("--mstep-workers", type=int, default=0,
                     help="processes fitting the states in the M-step (0 = min(K, cores); 1 = in this process, no fork: "

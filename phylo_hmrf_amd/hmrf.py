@@ -32,7 +32,7 @@ class phyloHMRF(_BaseGraph):
                  means_prior=0, means_weight=0, covars_prior=1e-2, covars_weight=1, algorithm="viterbi",
                  random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
                  learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
-                 solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=12,
+                 solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=14,
                  init_method="minibatch"):
         _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
                             startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
