@@ -23,10 +23,17 @@ Extra objects on the JSON line:
                       units the launches actually processed, COUNTED ON THE DEVICE) / the time during which at least one
                       kernel of the class was running (HIP events on the blocks' streams, merged on one time line, so the
                       class's time per step can never exceed ms_per_step), against the 8 TB/s HBM peak.
-  "roofline_limiter"  what actually bounds that kernel: it is neither HBM nor the LDS pipe but instruction issue and the
-                      latency of dependent loads at 3 waves per SIMD -- the SQ counters of the committed rocprofv3 --pmc
-                      pass (profiles/r2_sq_issue_by_kernel.json) next to the LDS bytes counted live on the device.
+  "roofline_limiter"  what actually bounds that kernel, from this run's device counters only (LDS bytes, pairs, cells, DP
+                      steps); the explanation -- instruction issue of in-order waves at 4 waves per SIMD -- and the
+                      measurements behind it are in DESIGN.md 3.3 and profiles/README.md.
   "cpu_baseline"      (rank 0, N=1) the reference's CPU path on a bounded sample -- see cpu_baseline().
+  "cold_first_iteration_ms"  the first EM iteration of the warm-up (from argmax labels; child blocks allocated).
+  "fit"               the whole fit under the reference's own stopping rules, run after the timed region (not part of
+                      `value`): iterations executed, wall, node-iterations/s over the whole fit, per-iteration E-step ms.
+
+Multi-GPU, round 4: a block that holds more than --split-above x a rank's share of the nodes is cut into ROW TILES held by
+different ranks (phylo_hmrf_amd/tiles.py: lockstep rounds, one small all-reduce per block and round), and the M-step's K
+states are dealt to the ranks.  --emulate-world N --emulate-rank R rehearses one rank's load on one GPU.
 """
 import argparse
 import json
@@ -51,6 +58,14 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the workload's blocks dealt to the ranks (total work fixed); weak = N copies of "
                          "the workload dealt to the ranks (work per GPU fixed)")
+    ap.add_argument("--split-above", type=float, default=1.0,
+                    help="N > 1: a block that holds more than this many times a rank's share of the nodes is cut into row "
+                         "tiles that different ranks hold (phylo_hmrf_amd/tiles.py)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one process, one GPU: build and time only what rank --emulate-rank of a run on this many GPUs holds")
+    ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--no-fit", action="store_true",
+                    help="skip the whole-fit measurement after the timed region (the `fit` object of the JSON line)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
@@ -131,12 +146,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+    # --emulate-world N --emulate-rank R (one process, one GPU): build and time ONLY what rank R of an N-rank run would hold
+    # -- its whole blocks, its row tiles (their neighbours absent: the halo rows stay as they are) and its share of the
+    # M-step's states.  A rehearsal of one rank's load for the scaling projection in DESIGN.md, not the metric.
+    emulating = a.emulate_world > 1
+    if emulating and world > 1:
+        raise SystemExit("--emulate-world is a one-process rehearsal: run it without torch.distributed.run")
+    eworld = a.emulate_world if emulating else world
+    erank = a.emulate_rank if emulating else rank
+    if not 0 <= erank < eworld:
+        raise SystemExit("--emulate-rank must be in [0, --emulate-world)")
 
-    from phylo_hmrf_amd import mstep, workloads
+    from phylo_hmrf_amd import mstep, tiles, workloads
     blocks_def, S, K, nn, desc = workloads.workload(a.workload)
-    workers = a.mstep_workers if a.mstep_workers > 0 else min(K, os.cpu_count() or 1)
-    if rank == 0:
-        mstep._pool(workers)                  # fork the M-step workers BEFORE anything initialises the GPU
+    my_states = [c for c in range(K) if c % eworld == erank]      # the M-step's states are dealt to the ranks
+    workers = a.mstep_workers if a.mstep_workers > 0 else max(1, min(len(my_states), os.cpu_count() or 1))
+    if not mstep.native_available():
+        mstep._pool(workers)                  # (Python fall-back of the M-step only: fork BEFORE anything initialises the GPU)
 
     import torch
     import torch.distributed as dist
@@ -152,7 +178,7 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.load().phmrf_set_device(local_rank))
     dev = torch.device("cuda", local_rank)
-    # PHMRF_FORCE_DIST=1 exercises the RCCL path (all-reduce, broadcast, barrier) with a single rank
+    # PHMRF_FORCE_DIST=1 exercises the RCCL path (all-reduce, barrier) with a single rank
     use_dist = world > 1 or os.environ.get("PHMRF_FORCE_DIST") == "1"
     backend = os.environ.get("PHMRF_DIST_BACKEND", "nccl")
     coll_dev = dev if backend == "nccl" else torch.device("cpu")     # where the collectives' tensors live
@@ -173,52 +199,77 @@ def main():
     means_true, cov_true = tree.mean_cov(params_true)
     cov_true = cov_true + 1e-3 * np.eye(S)                     # EM-time covariances carry 2e-3 (phylo_hmrf.py:1522-1524)
     t_setup = time.time()
-    # blocks -> ranks: longest block first (dist.lpt_assign); this rank builds and keeps only its own blocks
-    all_blocks, owner = workloads.shard(blocks_def, world, a.scaling)
+    # units of work -> ranks: whole blocks, and ROW TILES of the blocks that hold more than --split-above x a rank's share
+    # (phylo_hmrf_amd/tiles.py), dealt longest first; this rank builds and keeps only its own
+    all_blocks = list(blocks_def) * (world if a.scaling == "weak" else 1)
+    units = tiles.plan(all_blocks, eworld, a.split_above)
+    owner = tiles.assign(units, eworld)
     sizes = [workloads.block_nodes(*bd) for bd in all_blocks]
     n_global = int(sum(sizes))
-    nodes_per_rank = [int(sum(sz for sz, o in zip(sizes, owner) if o == r)) for r in range(world)]
+    nodes_per_rank = [int(sum(u["nodes"] for u, o in zip(units, owner) if o == r)) for r in range(eworld)]
     need_gb = max(nodes_per_rank) * workloads.BYTES_PER_NODE * (K / 20.0) / 1e9
     if need_gb > 260:
         raise SystemExit("workload %s needs about %.0f GB on the fullest of %d GPU(s) (288 GB each): run it on more GPUs "
-                         "(cfg5 needs >= 4) or use --workload cfg5-chr1" % (a.workload, need_gb, world))
-    blocks, n_total = [], 0
+                         "(cfg5 needs >= 4) or use --workload cfg5-chr1" % (a.workload, need_gb, eworld))
+    blocks, groups = [], []                                    # whole blocks / tile groups of split blocks on this rank
+    tile_comm_dev = coll_dev if backend == "nccl" else None
     for bi, (H, W, diag) in enumerate(all_blocks):
-        if owner[bi] != rank:
+        mine = [(i, u) for i, u in enumerate(units) if u["block"] == bi]
+        owners = [owner[i] for i, _ in mine]
+        split = len(mine) > 1
+        comm = tiles.GroupComm(owners, tile_comm_dev) if (split and world > 1) else None   # (collective: every rank, block order)
+        if erank not in owners:
             continue
-        n = workloads.block_nodes(H, W, diag)
-        b = Block(n, S, K)
         Xd = synthetic.device_observations(torch, dev, a.seed * 1000 + bi, H, W, diag, K, means_true, cov_true)
         torch.cuda.synchronize()
-        b.set_observations_dev(Xd.data_ptr())
-        b.sync()
+        if not split:
+            b = Block(workloads.block_nodes(H, W, diag), S, K)
+            b.set_observations_dev(Xd.data_ptr())
+            b.sync()
+            b.build_grid_graph(H, W, diag, nn, a.beta1)        # stencil graph + w = exp(-beta1 d) built on the device
+            blocks.append(b)
+        else:
+            def load(tl, Xd=Xd):
+                tl.b.set_observations_dev(Xd.data_ptr() + tl.node0 * S * 4)     # the tile's stored rows of the block
+                tl.b.sync()
+            groups.append(tiles.make_group(bi, (H, W, diag), [(u["r0"], u["r1"]) for _, u in mine], owners, erank, S, K,
+                                           Block, load, comm, nn, a.beta1))
         del Xd
-        b.build_grid_graph(H, W, diag, nn, a.beta1)            # stencil graph + w = exp(-beta1 d) built on the device
-        blocks.append(b)
-        n_total += n
     torch.cuda.empty_cache()
+    conductor = tiles.Conductor(groups)
+    local_tiles = [g.local[t] for g in conductor.groups for t in sorted(g.local)]
+    unit_blocks = blocks + [tl.b for tl in local_tiles]         # every Block this rank drives (stats row = position here)
+    n_local = int(sum(b.n for b in blocks) + sum(tl.own_hi - tl.own_lo for tl in local_tiles))
+    n_norm = n_local if emulating else n_global                # the nodes the statistics of an E-step refer to
     n_stats = K * (1 + S + S * S)
     # EM starts from perturbed parameters; first labels = argmax_k logprob + one ICM sweep -> labels_local
     params_cur = np.clip(params_true * (1.0 + 0.15 * rng.standard_normal(params_true.shape)), 1e-3, 50.0)
     init_ou = params_cur.copy()
     means, covars = tree.mean_cov(params_cur)
     covars = covars + 1e-3 * np.eye(S)
-    for b in blocks:
+    SLOT_INIT = 3
+    for b in unit_blocks:
         b.emission(means, covars)
         b.solve_fast(a.beta, max_rounds=1, use_chains=False, use_components=False, use_strips=False, use_expansion=False,
                      init_mode=1)
+    for g in conductor.groups:
+        g.sync_halos()                                         # (the ICM sweep saw a tile's halo rows without their other side)
+    for b in unit_blocks:
         b.save_labels(SLOT_LOCAL)
+        b.save_labels(SLOT_INIT)
         b.sync()
     setup_s = time.time() - t_setup
-    stats_dev = torch.zeros((max(len(blocks), 1), n_stats + 4), dtype=torch.float64, device=dev)
-    state = dict(min_cost=1e30, params=params_cur, means=means, covars=covars)
+    stats_dev = torch.zeros((max(len(unit_blocks), 1), n_stats + 4), dtype=torch.float64, device=dev)
+    state = dict(min_cost=1e30, params=params_cur.copy(), means=means, covars=covars)
     solver = dict(max_rounds=64, use_chains=True, use_components=True, use_strips=True, use_expansion=not a.no_expansion,
                   energy_tol_ppb=a.energy_tol_ppb)
     t_e, t_m = [], []
+    untimed = [0.0]                                            # emulation only: the other ranks' M-step states, fitted here
 
     # The blocks are independent (the reference forks one process per block, base.py:357-362): a few host threads
     # drive them concurrently, each block on its own HIP stream, largest first, so the latency-bound launches of the
     # small blocks fill the GPU next to the large ones.  ctypes drops the GIL for the duration of a library call.
+    # The row tiles of split blocks run their lockstep rounds on THIS thread meanwhile (tiles.Conductor).
     from phylo_hmrf_amd.concurrent import BlockRunner
     runner = BlockRunner(a.block_threads, local_rank)
     order = sorted(range(len(blocks)), key=lambda i: -blocks[i].n)
@@ -236,45 +287,77 @@ def main():
         if block_trace is not None:
             block_trace.append((i, b.n, tb0, time.time()))
 
-    cost1_log = []                                             # cost1 of every EM iteration (warm-up included)
+    def tile_prepare(tl):
+        tl.b.restore_labels(SLOT_LOCAL)
+        tl.b.emission(state["means"], state["covars"])
 
-    def em_step():
-        t0 = time.time()
+    def tile_finish(tl):
+        tl.b.posterior_stats_dev(a.beta, 3, stats_dev[len(blocks) + local_tiles.index(tl)].data_ptr())
+
+    def estep_all(sequential=False):
         if block_trace is not None:
             del block_trace[:]
-        runner.map(estep_block, order)
+        t0 = time.time()
+        if sequential:
+            for i in order:
+                estep_block(i)
+            pending = None
+        else:
+            pending = runner.start(estep_block, order)
+        if conductor.groups:
+            conductor.solve(a.beta, solver, prepare=tile_prepare, finish=tile_finish)
+            for tl in local_tiles:
+                tl.b.sync()
+        if pending is not None:
+            pending.results()
         if block_trace is not None and rank == 0:
             sys.stderr.write("[block trace] E-step %.2f ms: " % ((time.time() - t0) * 1e3) + " ".join(
                 "%d:%.1fM[%.1f-%.1f]" % (i, n / 1e6, (s0 - t0) * 1e3, (s1 - t0) * 1e3) for i, n, s0, s1 in sorted(block_trace, key=lambda r: r[2])) + "\n")
         tot = stats_dev.sum(dim=0).to(coll_dev)
         if use_dist:
             dist.all_reduce(tot)                               # RCCL: K(1+S+S^2)+4 doubles
-        tot = tot.cpu().numpy()
-        stats = unpack_stats(tot[:n_stats], K, S)
-        cost1 = tot[n_stats + 3] / n_global
-        cost1_log.append(float(cost1))
-        if cost1 < state["min_cost"]:                          # base.py:416-420
-            state["min_cost"] = cost1
-            for b in blocks:
-                b.save_labels(SLOT_LOCAL)
-        t1 = time.time()
-        if rank == 0:
-            p, mu, cv, _ = mstep.do_mstep(tree, stats, state["params"], init_ou, n_global, 1.0, 0, 0.3, 0.1, 1.0, rng,
-                                          workers=workers)
-            packed = np.concatenate([p.ravel(), mu.ravel(), cv.ravel()])
-        else:
-            packed = np.zeros(K * (tree.n_params + S + S * S))
-        if use_dist:
+        return tot.cpu().numpy()
+
+    def mstep_all(stats, gen):
+        """the K states dealt to the ranks (state c -> rank c mod N), one all-reduce of the rows (phyloHMRF._do_mstep)"""
+        base = int(gen.integers(0, 2 ** 62))
+        p, mu, cv, _ = mstep.do_mstep(tree, stats, state["params"], init_ou, n_norm, 1.0, 0, 0.3, 0.1, 1.0, gen,
+                                      workers=workers, states=my_states if eworld > 1 else None, base=base)
+        packed = np.concatenate([p.ravel(), mu.ravel(), cv.ravel()])
+        if use_dist and world > 1:
             t = torch.from_numpy(packed).to(coll_dev)
-            dist.broadcast(t, src=0)
+            dist.all_reduce(t)
             packed = t.cpu().numpy()
+        elif emulating:      # the states of the absent ranks, so that the EM trajectory is a real one (not part of the timings)
+            tu = time.time()
+            others = [c for c in range(K) if c not in my_states]
+            p2, mu2, cv2, _ = mstep.do_mstep(tree, stats, state["params"], init_ou, n_norm, 1.0, 0, 0.3, 0.1, 1.0, gen,
+                                             workers=min(len(others), os.cpu_count() or 1), states=others, base=base)
+            packed = packed + np.concatenate([p2.ravel(), mu2.ravel(), cv2.ravel()])
+            untimed[0] += time.time() - tu
         P = tree.n_params
         state["params"] = packed[:K * P].reshape(K, P)
         state["means"] = packed[K * P:K * P + K * S].reshape(K, S)
         state["covars"] = packed[K * P + K * S:].reshape(K, S, S)
+
+    cost1_log = []                                             # cost1 of every EM iteration (warm-up included)
+
+    def em_step():
+        t0 = time.time()
+        tot = estep_all()
+        stats = unpack_stats(tot[:n_stats], K, S)
+        cost1 = tot[n_stats + 3] / n_norm
+        cost1_log.append(float(cost1))
+        if cost1 < state["min_cost"]:                          # base.py:416-420
+            state["min_cost"] = cost1
+            for b in unit_blocks:
+                b.save_labels(SLOT_LOCAL)
+        t1 = time.time()
+        u0 = untimed[0]
+        mstep_all(stats, rng)
         t2 = time.time()
         t_e.append(t1 - t0)
-        t_m.append(t2 - t1)
+        t_m.append(t2 - t1 - (untimed[0] - u0))
 
     def barrier():
         torch.cuda.synchronize()
@@ -282,12 +365,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    cold_first_ms = None
+    for w_it in range(a.warmup):
+        tc = time.time()
         em_step()
-    for b in blocks:
+        if w_it == 0:
+            cold_first_ms = (time.time() - tc) * 1e3           # the cold first EM iteration (= --steps 1 --warmup 0)
+    for b in unit_blocks:
         b.enable_timing(not a.no_kernel_timing)
         b.reset_timing()
     del t_e[:], t_m[:]
+    untimed[0] = 0.0
     barrier()
     from phylo_hmrf_amd.block import time_base_reset
     time_base_reset()                                          # t = 0 of the kernel-interval time line
@@ -295,7 +383,7 @@ def main():
     for _ in range(a.steps):
         em_step()
     barrier()
-    elapsed = time.time() - t0
+    elapsed = time.time() - t0 - untimed[0]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,7 +408,7 @@ def main():
         """per kernel class [stream ms, launches, algorithmic bytes] and the device-counted work, over this rank's blocks"""
         agg_, work_ = {}, dict(units=0, cells=0, staged_cells=0, dp_steps=0, launches=0, swept_cells=0, label_cells=0,
                                proposal_nodes=0)
-        for b in blocks:
+        for b in unit_blocks:
             for name, (ms, ln) in b.timing().items():
                 d = agg_.setdefault(name, [0.0, 0, 0.0])
                 d[0] += ms
@@ -339,23 +427,80 @@ def main():
         return agg_, work_
 
     agg, work = collect()
-    busy = {name: union_ms(np.concatenate([b.intervals(name) for b in blocks] or [np.zeros((0, 2))]))
-            for name in agg} if not a.no_kernel_timing and blocks else {}
+    busy = {name: union_ms(np.concatenate([b.intervals(name) for b in unit_blocks] or [np.zeros((0, 2))]))
+            for name in agg} if not a.no_kernel_timing and unit_blocks else {}
 
     # ---- the same E-step once more, ONE BLOCK AT A TIME (after the timed region; not part of `value`): with a single
     #      stream in flight a launch's event time is the kernel's own duration, which the concurrent streams of the timed
-    #      region cannot give (there a launch shares the GPU with up to eleven others)
+    #      region cannot give (there a launch shares the GPU with up to thirteen others)
     isolated = {}
-    if not a.no_kernel_timing and blocks:
-        for b in blocks:
+    if not a.no_kernel_timing and unit_blocks:
+        for b in unit_blocks:
             b.reset_timing()
-        for i in order:
-            estep_block(i)
+        estep_all(sequential=True)
         torch.cuda.synchronize()
         agg_i, _ = collect()
         isolated = {k: {"launches": int(v[1]), "avg_launch_us": round(v[0] * 1e3 / max(v[1], 1), 2),
                         "GBps": (round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[2] > 0 else None)}
                     for k, v in agg_i.items()}
+
+    # ---- the WHOLE FIT (not part of `value`): the same workload from the same start under the reference's own stopping
+    #      rules -- threshold 0.001 and at most 60 iterations (phylo_hmrf.py:1555, :1561), the relative-change tests after
+    #      iteration 5 and the 50-iterations-past-the-minimum test (base.py:428-435), no M-step after the last E-step --
+    #      cold first iteration included.  Same code path as the timed region; kernel timers off.
+    fit = None
+    if not a.no_fit:
+        for b in unit_blocks:
+            b.enable_timing(False)
+            b.restore_labels(SLOT_INIT)
+            b.save_labels(SLOT_LOCAL)
+        state.update(min_cost=1e30, params=params_cur.copy(), means=means, covars=covars)
+        gen = np.random.default_rng(a.seed + 4242)
+        threshold, m_iter, max_iter1 = 0.001, 60, 50
+        pre = [0.001, 0.001, 0.001]
+        min_cost, min_cost1 = [0, 1000.0], [0, 1000.0]
+        e_ms, m_ms, c1 = [], [], []
+        untimed[0] = 0.0
+        barrier()
+        tf0 = time.time()
+        stop = "m_iter"
+        for it in range(m_iter):
+            ta = time.time()
+            tot = estep_all()
+            stats = unpack_stats(tot[:n_stats], K, S)
+            _, pairwise_cost, unary_cost, cost1 = (tot[n_stats:n_stats + 4] / n_norm).tolist()
+            d1, d2, d3 = (abs((pairwise_cost - pre[0]) / pre[0]), abs((unary_cost - pre[1]) / pre[1]),
+                          abs((cost1 - pre[2]) / pre[2]))
+            pre = [pairwise_cost, unary_cost, cost1]
+            c1.append(round(float(cost1), 6))
+            if cost1 < min_cost[1]:                                # base.py:416-420
+                min_cost = [it, cost1]
+                for b in unit_blocks:
+                    b.save_labels(SLOT_LOCAL)
+            if cost1 < min_cost1[1] and it >= 3:                   # base.py:422-426
+                min_cost1 = [it, cost1]
+            e_ms.append((time.time() - ta) * 1e3)
+            if ((d1 < threshold and d2 < threshold) or d3 < threshold) and it > 5:      # base.py:428-429
+                stop = "relative change below the threshold"
+                break
+            if it - min_cost1[0] > max_iter1:                      # base.py:434-435
+                stop = "50 iterations past the minimum"
+                break
+            tb = time.time()
+            u0 = untimed[0]
+            mstep_all(stats, gen)
+            m_ms.append((time.time() - tb - (untimed[0] - u0)) * 1e3)
+        barrier()
+        fit_wall = time.time() - tf0 - untimed[0]
+        if use_dist:
+            t = torch.tensor([fit_wall], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fit_wall = float(t.item())
+        iters = len(e_ms)
+        fit = {"iterations": iters, "stopped_by": stop, "wall_s": round(fit_wall, 4),
+               "value": n_norm * iters / fit_wall, "unit": "node-iterations/s over the whole fit (cold first iteration included)",
+               "estep_ms": [round(x, 2) for x in e_ms], "mstep_ms_mean": round(float(np.mean(m_ms)), 3) if m_ms else None,
+               "cost1": c1, "rules": "threshold 0.001, m_iter 60 (phylo_hmrf.py:1555,1561); base.py:416-435"}
 
     roofline = roofline_limiter = None
     # the dominant class among those with a byte model (the coarse expansions' gathers have none)
@@ -364,10 +509,9 @@ def main():
     if dom_name and busy.get(dom_name, 0) > 0 and agg[dom_name][2] > 0:
         dom_ms, dom_launches, dom_bytes = agg[dom_name]
         ach = dom_bytes / (busy[dom_name] * 1e-3) / 1e9
-        kernel_names = {"strip": ["strip_cols_kernel"], "fusion": ["strip_kernel"], "propose": ["propose_grid_kernel", "propose_kernel"],
-                        "emission": ["emission_kernel"], "energy": ["energy_grid_kernel", "energy_kernel"],
-                        "posterior_stats": ["posterior_kernel"]}.get(dom_name, [])
+        kernel_names = KERNELS_OF_CLASS.get(dom_name, [])
         traffic, traffic_note = pmc_traffic(a.workload, kernel_names)
+        iso = isolated.get(dom_name) or {}
         roofline = {"bound": "hbm", "kernel": dom_name, "kernel_names": kernel_names, "achieved": round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_note, "launches": int(dom_launches),
@@ -375,13 +519,16 @@ def main():
                     "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2),
                     "busy_ms_per_step": round(busy[dom_name] / a.steps, 3),
                     "isolated": isolated.get(dom_name),
+                    "kernel_frac_isolated": (round(iso["GBps"] / HBM_PEAK_GBS, 5) if iso.get("GBps") else None),
                     "note": "achieved = algorithmic bytes (SURVEY.md 8d accounting x the cells the launches processed, "
                             "counted on the device) / time during which >= 1 launch of the class was running (blocks "
-                            "run concurrently on their own streams); avg_launch_us = mean launch duration in the timed "
-                            "region, incl. the share of the GPU other streams took; isolated = the same E-step run one "
-                            "block at a time right after the timed region (a launch's own duration, and the rate at "
-                            "it); traffic = PMC FETCH_SIZE + WRITE_SIZE per launch of the named kernels from the "
-                            "committed rocprofv3 passes, only if they were taken with this build (traffic_source)"}
+                            "run concurrently on their own streams: a CLASS throughput); avg_launch_us = mean launch "
+                            "duration in the timed region, incl. the share of the GPU other streams took; isolated = the "
+                            "same E-step run one block at a time right after the timed region -- a launch's own duration "
+                            "and the rate at it, kernel_frac_isolated = that rate / peak: the fraction to compare with "
+                            "the rocprofv3 kernel durations under profiles/; traffic = PMC FETCH_SIZE + WRITE_SIZE per "
+                            "launch of the named kernels from the committed rocprofv3 passes, only if they were taken "
+                            "with this build (traffic_source)"}
         if dom_name in ("strip", "fusion"):
             # what the strip kernels move through LDS (device counters): a DP step reads 64 lanes x 8 B and its cell's
             # table (128 B) was written once; staging writes 17 B per staged cell and reads 9 x 5 B back per strip cell
@@ -407,31 +554,43 @@ def main():
                for k, v in agg.items()}
 
     if rank == 0:
-        value = n_global * a.steps / elapsed
+        value = n_norm * a.steps / elapsed
+        n_split = len(set(u["block"] for u in units if u["ntiles"] > 1))
         out = {
             "metric": "EM-iterations/sec x nodes (bin-pairs)", "value": value, "unit": "node-iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": a.workload + ": " + desc,
-                       "sharding": ("%d blocks (%d nodes) dealt to %d rank(s) by longest-processing-time-first; %s"
-                                    % (len(all_blocks), n_global, world,
+                       "sharding": ("%d blocks (%d nodes) as %d units (%d blocks cut into row tiles: those above %.2f x a rank's "
+                                    "share) dealt to %d rank(s) by longest-processing-time-first; %s"
+                                    % (len(all_blocks), n_global, len(units), n_split, a.split_above, eworld,
                                        "total work fixed" if a.scaling == "strong" else "%d copies of the workload" % world)),
-                       "blocks_per_rank": [int(sum(1 for o in owner if o == r)) for r in range(world)],
+                       "units_per_rank": [int(sum(1 for o in owner if o == r)) for r in range(eworld)],
                        "nodes_per_rank": nodes_per_rank,
                        "S": S, "K": K, "num_neighbor": nn, "beta": a.beta, "beta1": a.beta1,
-                       "step": "full EM iteration: GPU E-step of every block + stats reduction + host M-step (SLSQP, %d host threads)" % workers,
+                       "step": "full EM iteration: GPU E-step of every block + stats reduction + host M-step (SLSQP; the K states "
+                               "dealt to the ranks, %d of them on %d host threads here)" % (len(my_states), workers),
                        "mrf_solver": solver},
             "estep_ms": float(np.mean(t_e) * 1e3), "mstep_ms": float(np.mean(t_m) * 1e3),
+            "cold_first_iteration_ms": cold_first_ms,
+            "fit": fit,
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
-            "value_estep_only": n_global * a.steps / float(np.sum(t_e)),
+            "value_estep_only": n_norm * a.steps / float(np.sum(t_e)),
             "setup_s": setup_s, "block_threads": runner.n_threads, "kernels": kernels, "roofline": roofline,
             "roofline_limiter": roofline_limiter,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if emulating:
+            out["emulated"] = {"world": eworld, "rank": erank, "nodes": n_local, "whole_blocks": len(blocks),
+                               "tiles": [[g.block_id, t] for g in conductor.groups for t in sorted(g.local)],
+                               "mstep_states": len(my_states),
+                               "note": "a ONE-GPU REHEARSAL of what this rank of the N-rank run holds: its blocks, its row tiles "
+                                       "(neighbour tiles absent: no halo traffic) and its share of the M-step's states; EM on "
+                                       "this rank's nodes only.  `value` is this rank's nodes x steps / wall, not the metric"}
+        if world == 1 and not a.no_cpu_baseline and not emulating:
             out["cpu_baseline"] = cpu_baseline(a, S, K, nn, len(all_blocks), n_global, max(sizes))
     runner.close()
-    for b in blocks:
+    for b in unit_blocks:
         b.close()
     mstep.close_pool()
     if use_dist:
@@ -444,6 +603,12 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+KERNELS_OF_CLASS = {"strip": ["strip_cols_kernel"], "fusion": ["fusion_cols_kernel", "strip_kernel"],
+                    "propose": ["propose_grid_kernel", "propose_kernel"], "emission": ["emission_kernel"],
+                    "energy": ["energy_grid_kernel", "energy_delta_grid_kernel", "energy_kernel"],
+                    "posterior_stats": ["posterior_kernel"]}
 
 
 def pmc_traffic(workload, kernel_names):

@@ -46,6 +46,11 @@ extern "C" {
 typedef struct phmrf_block* phmrf_block_t;
 
 /* ---- library ---------------------------------------------------------------------------------- */
+/* ABI version = major * 100 + minor.  110 (round 4): PHMRF_NUM_KERNEL_CLASSES is 10 and phmrf_block_get_timing takes the
+ * capacity of the caller's arrays; phmrf_block_get_work writes 8 values; the resumable solve (phmrf_mrf_solve_begin ...
+ * _end) and the row-tile entry points are new.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
+ * (phylo_hmrf_amd/_lib.py does). */
+#define PHMRF_VERSION 110
 PHMRF_API int phmrf_version(void);
 PHMRF_API const char* phmrf_last_error(void);
 PHMRF_API const char* phmrf_status_string(int status);
@@ -55,14 +60,18 @@ PHMRF_API int phmrf_set_device(int device);
 /* ---- block lifetime --------------------------------------------------------------------------- */
 /* n nodes (Hi-C bin pairs), S species (leaves), K states.  K <= 64, S <= 16, n < 2^31 - 64.
  * Limits per entry point: the emission (b1) covers S <= 16; phmrf_posterior_stats (b3) covers S <= 8 at every K <= 64
- * (its LDS tile, 64 rows x (K + 2 + S) floats plus K (1 + S + S(S+1)/2) doubles, is at most 42 KB of the CU's 160) and
- * returns PHMRF_ERR_UNSUPPORTED for S > 8; node degree <= 64 (phmrf_block_set_graph). */
+ * (its LDS tile -- 256, 128 or 64 nodes x (K + 1 + S + 1) floats plus K (1 + S + S(S+1)/2) doubles: 29 KB at K = 20, S = 4,
+ * up to 158 KB of the CU's 160 at K = 64, S = 8) and returns PHMRF_ERR_UNSUPPORTED for S > 8; node degree <= 64
+ * (phmrf_block_set_graph). */
 PHMRF_API int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out);
 /* Environment, read when a block is created: PHMRF_DETERMINISTIC=1 makes the label solver's reductions independent of
  * the order in which atomics land (the component moves' per-component sums and the round-by-round energies are then
  * accumulated as fixed-point integers; 8 instead of 4 bytes per node and label of scratch for the component table): two
  * solves of the same inputs return identical labels.  Default: f32 / f64 atomics, labellings that can differ in a few
- * nodes from run to run (the reference is not deterministic either: random restarts, k-means). */
+ * nodes from run to run (the reference is not deterministic either: random restarts, k-means).
+ * SCOPE: the label solver only (phmrf_mrf_solve and the move passes).  The posterior statistics (f64 atomics across
+ * workgroups) and the k-means moments of the initialisation (f32 LDS / f64 global atomics) stay order-dependent in their
+ * last bits, so a seeded FIT is reproducible to rounding, not bit for bit. */
 PHMRF_API int phmrf_block_destroy(phmrf_block_t b);
 /* Run this block's kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
  * block's own stream. */
@@ -80,7 +89,9 @@ PHMRF_API int phmrf_block_set_observations_dev(phmrf_block_t b, const float* X_d
  * across EM iterations (phylo_hmrf.py:101). */
 PHMRF_API int phmrf_block_set_graph(phmrf_block_t b, int64_t E, const int64_t* edges, const double* w);
 /* Optional geometry of the block (len_vec fields 3,4,8: H, W, type):
- * diagonal=1: H==W, nodes are the upper triangle row-major; diagonal=0: full H x W row-major.
+ * diagonal=1: nodes are the first H <= W rows of the W x W upper triangle, row-major (row i holds columns i .. W-1; the
+ * reference's diagonal blocks have H == W; H < W is a ROW TILE of one, see phmrf_block_set_tile); diagonal=0: full H x W
+ * row-major.
  * num_neighbor 8 or 4 (utility.py:1898-1905).  Checked against the edge list (every edge must join
  * grid neighbours); enables the 1-D chain moves (rows / columns / diagonals). */
 PHMRF_API int phmrf_block_set_grid(phmrf_block_t b, int H, int W, int diagonal, int num_neighbor);
@@ -121,7 +132,10 @@ PHMRF_API int phmrf_emission_dev(const float* X_dev, int64_t n, int S, int K, co
 
 /* ---- b2: MRF labelling ------------------------------------------------------------------------ */
 typedef struct phmrf_solve_opts {
-  int max_rounds;      /* <=0: default 64.  One round = chain moves + ICM sweep + component moves + strip fusion */
+  int max_rounds;      /* <=0: default 64.  One round = every ACTIVE move type once: component moves (first round, after
+                          rounds that moved the labelling at large, verification rounds), one strip fusion pass and one
+                          strip alpha-expansion launch per orientation, coarse alpha-expansions while the solve moves at
+                          large; chain moves and the ICM sweep run in verification rounds only on grid blocks            */
   int use_chains;      /* 1: exact 1-D chain moves when geometry is known                                      */
   int use_components;  /* 1: whole-component relabel moves                                                     */
   int init_mode;       /* 0: start from the block's current labels (reference warm start, phylo_hmrf.py:479)
@@ -159,6 +173,42 @@ typedef struct phmrf_solve_result {
 /* Minimise E_float by energy-non-increasing moves from the current labels; labels stay on the device
  * (phmrf_block_get_labels to fetch).  opts NULL = defaults, res may be NULL. */
 PHMRF_API int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res);
+/* The same solve in pieces (phmrf_mrf_solve is exactly begin; {launch; collect; decide} while *status == 0; end):
+ *   begin    resets the solve's state (stamps, memos, schedule); want_init_energy: also evaluate the starting energy
+ *   launch   queues one round's kernels and the read-back of its change counters and energy on the block's stream
+ *   collect  waits for them: counters[128] (changes per move type, the slots of phmrf_mrf_solve) and
+ *            energy[2] = (unary sum, pair sum without beta) after the round
+ *   decide   runs the schedule on (counters, energy) -- this block's, or the SUMS over the row tiles of one block that
+ *            live in different blocks / on different GPUs, which then all take the same decisions --;
+ *            *status: 0 another round, 1 converged, 2 stopped by max_rounds or the launch budget
+ *   end      fills res (may be NULL) and ends the solve.
+ * Replaces, with phmrf_block_set_tile, the reference's one-process-per-block loop (base.py:357-372) for blocks that are
+ * larger than one GPU's share. */
+PHMRF_API int phmrf_mrf_solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, int want_init_energy);
+PHMRF_API int phmrf_mrf_solve_round_launch(phmrf_block_t b);
+PHMRF_API int phmrf_mrf_solve_round_collect(phmrf_block_t b, uint64_t* counters /*[128]*/, double* energy /*[2]*/);
+PHMRF_API int phmrf_mrf_solve_round_decide(phmrf_block_t b, const uint64_t* counters /*[128]*/, const double* energy /*[2]*/,
+                                           int* status);
+PHMRF_API int phmrf_mrf_solve_end(phmrf_block_t b, phmrf_solve_result* res);
+
+/* ---- row tiles: one grid block on several GPUs ------------------------------------------------------------------
+ * The reference makes a block smaller only by the centromere split into independent pieces (utility.py:381-393).  Here a
+ * grid block is cut into row tiles; a tile is a block of its own that stores the rows it owns plus one HALO row per
+ * neighbouring tile (top / bottom != 0: there is a neighbour above / below; the first / last stored row is its halo).
+ * Rows r0 .. r1 of an upper-triangular block are the first rows of a smaller upper triangle (diagonal=1, H < W), of a
+ * full block a full block, so a tile has the geometry every kernel already handles.  After phmrf_block_set_tile
+ *   - phmrf_mrf_energy, the solve's energies, phmrf_posterior_stats and phmrf_kmeans_* count the OWNED rows only (their
+ *     sums over the tiles are the whole block's); sched_n = the whole block's node count (the schedule's thresholds);
+ *   - phmrf_block_tile_pins(n_top, n_bottom) freezes the first n_top / last n_bottom rows (0, 1 or 2; the halo row counts):
+ *     a pinned node's unary terms become +1e9 for every label but its own, so no move type relabels it; the real terms
+ *     come back when the pin is lifted (phmrf_emission lifts all).  The two rows at a cut are pinned in turn, round by
+ *     round, so that neighbouring tiles never move two adjacent nodes in the same round (tile.hip);
+ *   - phmrf_block_tile_get_boundary / _put_halo move the one label row per cut that the neighbour needs (host buffers:
+ *     the caller ships them with whatever transport it has -- torch.distributed in phylo_hmrf_amd/tiles.py).         */
+PHMRF_API int phmrf_block_set_tile(phmrf_block_t b, int top, int bottom, int64_t sched_n);
+PHMRF_API int phmrf_block_tile_pins(phmrf_block_t b, int n_top, int n_bottom);
+PHMRF_API int phmrf_block_tile_get_boundary(phmrf_block_t b, uint8_t* top_out, uint8_t* bottom_out);
+PHMRF_API int phmrf_block_tile_put_halo(phmrf_block_t b, const uint8_t* top_in, const uint8_t* bottom_in);
 /* One colour-ordered ICM sweep / one sweep of one chain family / one component-move pass (exposed
  * for move-level parity tests against oracle/mrf_moves.py).  family: 0 rows, 1 columns,
  * 2 diagonals, 3 anti-diagonals. */
@@ -225,11 +275,12 @@ PHMRF_API int phmrf_kmeans_moments(phmrf_block_t b, const double* centers /* [K,
 /* Accumulated device time (ms, hipEvent on the block's stream) and launch count per kernel class
  * since the last reset: 0 emission, 1 icm, 2 chain, 3 component, 4 energy, 5 posterior_stats, 6 strip (the strip
  * alpha-expansions: strip_cols_kernel, every listed label of a cut in one launch), 7 propose, 8 coarse (coarse
- * alpha-expansions: coarsen + strip kernels on the super-cell grid + apply), 9 fusion (strip_kernel: the fusion passes and
- * the single-label strip passes of the API). */
+ * alpha-expansions: coarsen_kernel + strip_kernel on the super-cell grid + coarse_apply_kernel), 9 fusion (the fusion passes
+ * of a solve: fusion_cols_kernel; the single-label strip passes of the API: strip_kernel). */
 #define PHMRF_NUM_KERNEL_CLASSES 10
 PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
-PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, double* ms /*[9]*/, int64_t* launches /*[9]*/);
+/* capacity = the length of the caller's arrays; min(capacity, PHMRF_NUM_KERNEL_CLASSES) entries are written */
+PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, int capacity, double* ms /*[capacity]*/, int64_t* launches /*[capacity]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
 /* Work the strip kernels (class 6) actually did since the last reset, counted ON THE DEVICE (inside a solve a strip
  * whose inputs did not change since its last quiet run is skipped after a look at its stamps and counts nothing):

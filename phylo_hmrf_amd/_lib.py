@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PHMRF_LIB") or os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
+ABI_VERSION = 110             # include/phmrf.h PHMRF_VERSION: checked against the library in load()
 NUM_KERNEL_CLASSES = 10
 KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose", "coarse", "fusion")
 
@@ -73,6 +74,15 @@ SIGNATURES = {
     "phmrf_emission_pack": [_i, _i, _dp, _dp, _fp],
     "phmrf_emission_dev": [_vp, _i64, _i, _i, _vp, _vp, _vp],
     "phmrf_mrf_solve": [_vp, _d, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveResult)],
+    "phmrf_mrf_solve_begin": [_vp, _d, ctypes.POINTER(SolveOpts), _i],
+    "phmrf_mrf_solve_round_launch": [_vp],
+    "phmrf_mrf_solve_round_collect": [_vp, ctypes.POINTER(ctypes.c_uint64), _dp],
+    "phmrf_mrf_solve_round_decide": [_vp, ctypes.POINTER(ctypes.c_uint64), _dp, ctypes.POINTER(_i)],
+    "phmrf_mrf_solve_end": [_vp, ctypes.POINTER(SolveResult)],
+    "phmrf_block_set_tile": [_vp, _i, _i, _i64],
+    "phmrf_block_tile_pins": [_vp, _i, _i],
+    "phmrf_block_tile_get_boundary": [_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)],
+    "phmrf_block_tile_put_halo": [_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)],
     "phmrf_mrf_icm_sweep": [_vp, _d, _lp],
     "phmrf_mrf_chain_sweep": [_vp, _d, _i, _lp],
     "phmrf_mrf_component_pass": [_vp, _d, _lp],
@@ -86,7 +96,7 @@ SIGNATURES = {
     "phmrf_kmeans_step": [_vp, _dp, _i, _dp],
     "phmrf_kmeans_moments": [_vp, _dp, _i, _dp],
     "phmrf_block_enable_timing": [_vp, _i],
-    "phmrf_block_get_timing": [_vp, _dp, _lp],
+    "phmrf_block_get_timing": [_vp, _i, _dp, _lp],
     "phmrf_block_reset_timing": [_vp],
     "phmrf_block_get_work": [_vp, _lp],
     "phmrf_time_base_reset": [],
@@ -113,6 +123,10 @@ def load():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        got = L.phmrf_version()
+        if got != ABI_VERSION:
+            raise ImportError("%s has ABI version %d, this binding expects %d (include/phmrf.h PHMRF_VERSION): rebuild it "
+                              "with `make -C phylo_hmrf_amd/csrc`" % (LIB_PATH, got, ABI_VERSION))
         _lib = L
     return _lib
 

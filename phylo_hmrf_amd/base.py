@@ -82,6 +82,10 @@ class _BaseGraph(object):
         """-> (stats dict, cost numerators[4] summed over the region's nodes).  Labels stay on the device."""
         raise NotImplementedError
 
+    def _estep_tiles(self):
+        """-> [(stats dict, cost numerators[4], owned nodes)] of the row tiles this rank holds (none by default)"""
+        return []
+
     # ---- the fit loop ----------------------------------------------------------------------------
     def fit_accumulate_test(self, X, len_vec, threshold, annotation, m_iter, lengths=None):
         """Estimate model parameters.  Returns
@@ -116,12 +120,18 @@ class _BaseGraph(object):
             # E-step of the regions this rank owns; un-normalised cost sums travel with the statistics
             local = np.zeros(K * (1 + S + S * S) + 5)
             by_size = sorted(self.my_regions, key=lambda r: -int(len_vec[r][0]))          # largest block first
-            done = dict(zip(by_size, self.runner.map(self._estep_region, by_size)))       # concurrent streams
+            pending = self.runner.start(self._estep_region, by_size)                      # concurrent streams
+            tiled = self._estep_tiles()         # row tiles of split blocks: lockstep rounds, on this thread meanwhile
+            done = dict(zip(by_size, pending.results()))
             for region_id in self.my_regions:                                             # fixed summation order
                 st, costs = done[region_id]
                 local[:-5] += pack_stats(st)
                 local[-5:-1] += costs
                 local[-1] += int(len_vec[region_id][0])
+            for st, costs, n_owned in tiled:
+                local[:-5] += pack_stats(st)
+                local[-5:-1] += costs
+                local[-1] += int(n_owned)
             total = self.reducer.allreduce(local)
             self.timing_["estep"].append(time.time() - start)
             self._log("use time %d:" % it)

@@ -123,6 +123,64 @@ class Block(object):
                       int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb))
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), None))
 
+    # -- the solve in pieces (lockstep rounds of the row tiles of one block: tiles.py) ----------------
+    def solve_begin(self, beta, want_init_energy=False, max_rounds=64, use_chains=True, use_components=True, init_mode=0,
+                    use_strips=True, use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True):
+        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
+                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb))
+        check(self._L.phmrf_mrf_solve_begin(self._h, float(beta), ctypes.byref(o), int(bool(want_init_energy))))
+
+    def solve_round_launch(self):
+        check(self._L.phmrf_mrf_solve_round_launch(self._h))
+
+    def solve_round_collect(self):
+        """-> (counters uint64[128], energy float64[2] = unary sum, pair sum without beta) of this block after the round"""
+        c = np.zeros(128, dtype=np.uint64)
+        e = np.zeros(2, dtype=np.float64)
+        check(self._L.phmrf_mrf_solve_round_collect(self._h, c.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ptr_d(e)))
+        return c, e
+
+    def solve_round_decide(self, counters, energy):
+        """-> 0 another round, 1 converged, 2 stopped by max_rounds / the launch budget"""
+        c = np.ascontiguousarray(counters, dtype=np.uint64)
+        e = np.ascontiguousarray(energy, dtype=np.float64)
+        st = ctypes.c_int(0)
+        check(self._L.phmrf_mrf_solve_round_decide(self._h, c.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ptr_d(e),
+                                                   ctypes.byref(st)))
+        return st.value
+
+    def solve_end(self, want_result=False):
+        if not want_result:
+            check(self._L.phmrf_mrf_solve_end(self._h, None))
+            return None
+        r = SolveResult()
+        check(self._L.phmrf_mrf_solve_end(self._h, ctypes.byref(r)))
+        return dict(energy=r.energy, energy_unary=r.energy_unary, energy_pair=r.energy_pair,
+                    energy_init=r.energy_init, rounds=r.rounds, converged=bool(r.converged), changed=r.changed)
+
+    # -- row tiles ---------------------------------------------------------------------------------
+    def set_tile(self, top, bottom, sched_n=0):
+        check(self._L.phmrf_block_set_tile(self._h, int(bool(top)), int(bool(bottom)), int(sched_n)))
+
+    def tile_pins(self, n_top, n_bottom):
+        check(self._L.phmrf_block_tile_pins(self._h, int(n_top), int(n_bottom)))
+
+    def tile_get_boundary(self, top_len, bottom_len):
+        """-> (first owned row or None, last owned row or None) as uint8 arrays of the given lengths (0: no such cut)"""
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        top = np.empty(top_len, dtype=np.uint8) if top_len else None
+        bot = np.empty(bottom_len, dtype=np.uint8) if bottom_len else None
+        check(self._L.phmrf_block_tile_get_boundary(self._h, top.ctypes.data_as(u8) if top_len else None,
+                                                    bot.ctypes.data_as(u8) if bottom_len else None))
+        return top, bot
+
+    def tile_put_halo(self, top, bottom):
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        t = None if top is None else np.ascontiguousarray(top, dtype=np.uint8)
+        b = None if bottom is None else np.ascontiguousarray(bottom, dtype=np.uint8)
+        check(self._L.phmrf_block_tile_put_halo(self._h, None if t is None else t.ctypes.data_as(u8),
+                                                None if b is None else b.ctypes.data_as(u8)))
+
     def icm_sweep(self, beta):
         c = ctypes.c_int64(0)
         check(self._L.phmrf_mrf_icm_sweep(self._h, float(beta), ctypes.byref(c)))
@@ -224,7 +282,7 @@ class Block(object):
     def timing(self):
         ms = (ctypes.c_double * _lib.NUM_KERNEL_CLASSES)()
         ln = (ctypes.c_int64 * _lib.NUM_KERNEL_CLASSES)()
-        check(self._L.phmrf_block_get_timing(self._h, ms, ln))
+        check(self._L.phmrf_block_get_timing(self._h, _lib.NUM_KERNEL_CLASSES, ms, ln))
         return {name: (ms[i], ln[i]) for i, name in enumerate(_lib.KERNEL_CLASSES)}
 
     def work(self):

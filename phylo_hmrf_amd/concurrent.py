@@ -29,7 +29,23 @@ class BlockRunner(object):
             return [fn(it) for it in items]
         return list(self._pool.map(fn, items))
 
+    def start(self, fn, items):
+        """submit fn(item) for every item and return at once; .results() waits (exceptions propagate there)"""
+        items = list(items)
+        if self._pool is None:
+            return _Deferred(lambda: [fn(it) for it in items])
+        futures = [self._pool.submit(fn, it) for it in items]
+        return _Deferred(lambda: [f.result() for f in futures])
+
     def close(self):
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
+
+
+class _Deferred(object):
+    def __init__(self, wait):
+        self._wait = wait
+
+    def results(self):
+        return self._wait()

@@ -275,7 +275,7 @@ using namespace phmrf;
 extern "C" {
 
 // ---- library ------------------------------------------------------------------------------------
-int phmrf_version(void) { return 100; }
+int phmrf_version(void) { return PHMRF_VERSION; }
 
 const char* phmrf_last_error(void) { return g_error.c_str(); }
 
@@ -400,6 +400,16 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->uT);
   dev_free(b->emis_params);
   dev_free(b->posteriors);
+  for (int r = 0; r < 2; ++r) {
+    dev_free(b->pin_save[r]);
+    dev_free(b->pin_label[r]);
+  }
+  dev_free(b->xfer);
+  if (b->xfer_host) (void)hipHostFree(b->xfer_host);
+  if (b->ss) {
+    delete b->ss;
+    b->ss = nullptr;
+  }
   dev_free(b->accum);
   dev_free(b->counters);
   dev_free(b->work_acc);
@@ -546,7 +556,7 @@ int phmrf_block_set_grid(phmrf_block_t b, int H, int W, int diagonal, int num_ne
   PHMRF_CHECK(b->has_graph, PHMRF_ERR_STATE, "set_graph must precede set_grid");
   PHMRF_CHECK(H >= 1 && W >= 1, PHMRF_ERR_INVALID, "H, W must be >= 1");
   PHMRF_CHECK(num_neighbor == 8 || num_neighbor == 4, PHMRF_ERR_INVALID, "num_neighbor must be 8 or 4");
-  PHMRF_CHECK(!diagonal || H == W, PHMRF_ERR_INVALID, "a diagonal block must be square");
+  PHMRF_CHECK(!diagonal || H <= W, PHMRF_ERR_INVALID, "a diagonal block is the first H <= W rows of a W x W upper triangle");
   Geometry g(H, W, diagonal);
   PHMRF_CHECK(g.count() == b->n, PHMRF_ERR_INVALID, "H, W, diagonal do not match the node count");
   const int64_t n = b->n;
@@ -592,7 +602,7 @@ int phmrf_block_build_grid_graph(phmrf_block_t b, int H, int W, int diagonal, in
   PHMRF_CHECK(b->has_X, PHMRF_ERR_STATE, "observations must be set before the graph is built from them");
   PHMRF_CHECK(H >= 1 && W >= 1, PHMRF_ERR_INVALID, "H, W must be >= 1");
   PHMRF_CHECK(num_neighbor == 8 || num_neighbor == 4, PHMRF_ERR_INVALID, "num_neighbor must be 8 or 4");
-  PHMRF_CHECK(!diagonal || H == W, PHMRF_ERR_INVALID, "a diagonal block must be square");
+  PHMRF_CHECK(!diagonal || H <= W, PHMRF_ERR_INVALID, "a diagonal block is the first H <= W rows of a W x W upper triangle");
   PHMRF_CHECK(beta1 >= 0.0 && std::isfinite(beta1), PHMRF_ERR_INVALID, "beta1 must be finite and >= 0");
   Geometry g(H, W, diagonal);
   PHMRF_CHECK(g.count() == b->n, PHMRF_ERR_INVALID, "H, W, diagonal do not match the node count");
@@ -738,6 +748,8 @@ int phmrf_emission(phmrf_block_t b, const double* means, const double* covars) {
   toc(b, KC_EMISSION, 1);
   b->has_logprob = true;
   b->uT_valid = b->uT != nullptr;
+  b->pin_saved = false;                     // (every row is real again: whatever was pinned is not any more)
+  b->pin_rows[0] = b->pin_rows[1] = 0;
   return PHMRF_OK;
 }
 
@@ -759,6 +771,8 @@ int phmrf_block_set_logprob(phmrf_block_t b, const double* logprob) {
   PHMRF_TRY(upload(b->logprob, tmp.data(), cnt * sizeof(float), b->stream));
   b->has_logprob = true;
   b->uT_valid = false;
+  b->pin_saved = false;
+  b->pin_rows[0] = b->pin_rows[1] = 0;
   return PHMRF_OK;
 }
 
@@ -831,43 +845,39 @@ static int energy_now(phmrf_block_t b, double beta, double* eu, double* ep) {
   return PHMRF_OK;
 }
 
-// The energy after a round of a solve.  The first evaluation of a solve is the full pass; later ones on a large grid block
-// add the change since the previous evaluation, taken from the nodes the round's moves have stamped (energy_delta_grid_
-// kernel) -- a mop-up round touches a few per cent of the block.  Each evaluation leaves a snapshot of the labels and
-// its tick behind for the next.  (PHMRF_ENERGY_FULL=1: always the full pass; PHMRF_ENERGY_CHECK=1: both, compared.)
-static int energy_after_round(phmrf_block_t b, double beta, double* eu, double* ep, double* eu_raw_prev, double* ep_raw_prev) {
+// The energy after a round of a solve, in two halves: energy_round_launch queues the evaluation behind the round's moves,
+// energy_round_collect reads it once the stream has been synchronised.  The first evaluation of a solve is the full pass;
+// later ones on a large grid block add the change since the previous evaluation, taken from the nodes the round's moves have
+// stamped (energy_delta_grid_kernel) -- a mop-up round touches a few per cent of the block.  Each evaluation leaves a
+// snapshot of the labels and its tick behind for the next.  (PHMRF_ENERGY_FULL=1: always the full pass;
+// PHMRF_ENERGY_CHECK=1: both, compared.)  The carried values are (unary, pair without beta).
+static int energy_round_launch(phmrf_block_t b, bool* incremental_out, bool* snapshot_out) {
   static const bool always_full = getenv("PHMRF_ENERGY_FULL") != nullptr;
-  static const bool check = getenv("PHMRF_ENERGY_CHECK") != nullptr;
   const bool grid = b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->stamp && b->tick > 0 && b->n >= (1 << 18);
-  if (!grid || always_full) return energy_now(b, beta, eu, ep);
-  bool incremental = energy_delta_available(b);
-  if (incremental) {
-    PHMRF_TRY(zero_accum(b, 4, 2));
-    tic(b);
-    PHMRF_TRY(launch_energy_delta(b));
-    toc(b, KC_ENERGY, 1);
-    PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  const bool snapshot = grid && !always_full;
+  const bool incremental = snapshot && energy_delta_available(b);
+  PHMRF_TRY(zero_accum(b, 4, 2));
+  tic(b);
+  if (incremental) PHMRF_TRY(launch_energy_delta(b));
+  else PHMRF_TRY(launch_energy(b, 0.f));
+  toc(b, KC_ENERGY, 1);
+  PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));   // (+ slot 6: pin violations)
+  if (snapshot) {       // the snapshot for the next evaluation: every launch from here on carries a later tick
+    if (!b->labels_eval) PHMRF_TRY(dev_alloc(&b->labels_eval, (size_t)b->n));
+    PHMRF_HIP(hipMemcpyAsync(b->labels_eval, b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
+    b->eval_tick = b->tick;
+    ++b->tick;
   }
-  if (!b->labels_eval) PHMRF_TRY(dev_alloc(&b->labels_eval, (size_t)b->n));
-  if (!incremental) {
-    PHMRF_TRY(energy_now(b, beta, eu, ep));          // synchronises
-    *eu_raw_prev = *eu;
-    if (b->deterministic) {
-      long long q1;
-      std::memcpy(&q1, b->accum_host + 5, sizeof(q1));
-      *ep_raw_prev = (double)q1 / 1048576.0;
-    } else {
-      *ep_raw_prev = b->accum_host[5];
-    }
-  }
-  // the snapshot for the next evaluation: every launch from here on carries a later tick
-  PHMRF_HIP(hipMemcpyAsync(b->labels_eval, b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
-  b->eval_tick = b->tick;
-  ++b->tick;
-  if (!incremental) return PHMRF_OK;
-  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  *incremental_out = incremental;
+  *snapshot_out = snapshot;
+  return PHMRF_OK;
+}
+
+// (the stream has been synchronised)  -> *eu, *ep_raw: unary and pair sum (without beta) after the round
+static int energy_round_collect(phmrf_block_t b, double beta, bool incremental, double* eu_carry, double* ep_carry) {
+  static const bool check = getenv("PHMRF_ENERGY_CHECK") != nullptr;
   double du, dp;
-  if (b->deterministic) {
+  if (b->deterministic) {             // 2^-20 fixed-point integers in the two slots (kernels.hip energy_flush)
     long long q[2];
     std::memcpy(q, b->accum_host + 4, sizeof(q));
     du = (double)q[0] / 1048576.0;
@@ -876,17 +886,21 @@ static int energy_after_round(phmrf_block_t b, double beta, double* eu, double* 
     du = b->accum_host[4];
     dp = b->accum_host[5];
   }
-  *eu_raw_prev += du;
-  *ep_raw_prev += dp;
-  *eu = *eu_raw_prev;
-  *ep = beta * *ep_raw_prev;
-  if (check) {
+  if (incremental) {
+    *eu_carry += du;
+    *ep_carry += dp;
+  } else {
+    *eu_carry = du;
+    *ep_carry = dp;
+  }
+  if (check && incremental) {
     double fu, fp;
     PHMRF_TRY(energy_now(b, beta, &fu, &fp));
+    const double eu = *eu_carry, ep = beta * *ep_carry;
     const double tol = 1e-9 * std::fabs(fu + fp) + 1e-3;
-    if (std::fabs(fu - *eu) > tol || std::fabs(fp - *ep) > tol)
-      fprintf(stderr, "[phmrf energy check] incremental %.6f + %.6f, full %.6f + %.6f (diff %.3e, %.3e)\n", *eu, *ep, fu, fp,
-              *eu - fu, *ep - fp);
+    if (!b->tile_top && !b->tile_bot && (std::fabs(fu - eu) > tol || std::fabs(fp - ep) > tol))
+      fprintf(stderr, "[phmrf energy check] incremental %.6f + %.6f, full %.6f + %.6f (diff %.3e, %.3e)\n", eu, ep, fu, fp,
+              eu - fu, ep - fp);
   }
   return PHMRF_OK;
 }
@@ -1114,9 +1128,34 @@ int phmrf_block_coarse_problem(phmrf_block_t b, double beta, int scale, int offs
   return PHMRF_OK;
 }
 
-int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res) {
+// ---- the label solver as a resumable state machine ------------------------------------------------------------------
+// phmrf_mrf_solve = begin; { round_launch; round_collect; round_decide } until decided; end.  The pieces are entry points
+// of their own so that the tiles of ONE block that live on different GPUs can run their rounds in lockstep: between
+// collect and decide the host adds up the tiles' change counters and energies (one small all-gather per round), every tile
+// takes the same decision from the sums, and the boundary label rows are exchanged (phylo_hmrf_amd/tiles.py).
+}  // extern "C"
+
+namespace {
+const int N_COARSE_LV = 3;
+const int GEOM_R[3] = {0, 2, 4}, GEOM_C[3] = {0, 21, 42};
+
+void solve_scope_exit(phmrf_block* b) {
+  phmrf_solve_state* s = b->ss;
+  if (s) b->geom_phase = (s->geom + 1) % 3;
+  b->tick = 0;
+  b->eval_tick = -1;
+  b->counter_slot = 0;
+  b->prop_tick = -1;
+  delete s;
+  b->ss = nullptr;
+}
+
+int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool want_init_energy) {
   PHMRF_TRY(check_solvable(b));
-  phmrf_solve_opts o;
+  if (b->ss) solve_scope_exit(b);                 // (an abandoned solve)
+  phmrf_solve_state* s = new phmrf_solve_state();
+  b->ss = s;
+  phmrf_solve_opts& o = s->o;
   std::memset(&o, 0, sizeof(o));
   o.max_rounds = 64;
   o.use_chains = 1;
@@ -1128,60 +1167,54 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     o = *opts;
     if (o.max_rounds <= 0) o.max_rounds = 64;
   }
-  const float bf = (float)beta;
+  s->beta = beta;
+  s->bf = (float)beta;
+  s->sched_n = b->sched_n > 0 ? b->sched_n : b->n;
+  struct Abort {                                  // a failure below leaves no half-begun solve behind
+    phmrf_block* blk;
+    bool armed = true;
+    ~Abort() { if (armed) solve_scope_exit(blk); }
+  } abort_guard{b};
   if (o.init_mode == 1) {
     PHMRF_TRY(launch_argmax_labels(b));
     b->has_labels = true;
   }
-  double eu0 = 0, ep0 = 0;
-  if (res) PHMRF_TRY(energy_now(b, beta, &eu0, &ep0));
-  int64_t total = 0;
-  int rounds = 0, converged = 0;
-  const bool chains = o.use_chains && b->has_grid;
-  const bool strips = o.use_strips && b->has_grid;
-  const int64_t tol = o.min_changed > 0 ? o.min_changed : 0;
+  if (want_init_energy) {
+    PHMRF_TRY(energy_now(b, beta, &s->eu0, &s->ep0));
+    s->have_init_energy = true;
+  }
+  s->chains = o.use_chains && b->has_grid;
+  s->strips = o.use_strips && b->has_grid;
+  s->tol = o.min_changed > 0 ? o.min_changed : 0;
   const int K = b->K;
   // move types and their change counters (slot in b->counters): chain families 72..75, ICM 76, components 77,
   // strip fusion 78/79, strip expansion of label a: 8 + a.
-  const bool expansions = strips && o.use_expansion;
-  const int n_fam = chains ? (int)b->families.size() : 0;
-  std::vector<int> slots;
-  for (int f = 0; f < n_fam; ++f) slots.push_back(72 + f);
-  slots.push_back(76);
-  if (o.use_components) slots.push_back(77);
-  if (strips) {
-    slots.push_back(78);
-    slots.push_back(79);
+  s->expansions = s->strips && o.use_expansion;
+  s->n_fam = s->chains ? (int)b->families.size() : 0;
+  for (int f = 0; f < s->n_fam; ++f) s->slots.push_back(72 + f);
+  s->slots.push_back(76);
+  if (o.use_components) s->slots.push_back(77);
+  if (s->strips) {
+    s->slots.push_back(78);
+    s->slots.push_back(79);
   }
-  if (expansions)
-    for (int a = 0; a < K; ++a) slots.push_back(8 + a);
+  if (s->expansions)
+    for (int a = 0; a < K; ++a) s->slots.push_back(8 + a);
   // coarse alpha-expansions: slots 80 (2 x 2 super-cells), 81 (4 x 4), 82 (8 x 8)
-  const bool coarse = strips && o.use_coarse && b->H >= 4 && b->W >= 4;
-  if (coarse)
-    for (int lv = 0; lv < N_COARSE; ++lv) slots.push_back(80 + lv);
-  int64_t last_changed = 0;            // labels changed by the previous round
-  int64_t coarse_changed[N_COARSE] = {0, 0, 0};  // ... by the coarse scales in their last run
-  bool coarse_ran[N_COARSE] = {false, false, false};
-  bool force_coarse = false;           // the tolerance wants to stop, but the coarse scales have not had their say
-  bool coarse_checked = false;
-  std::vector<char> active(128, 0);
-  for (int sl : slots) active[sl] = 1;
-  // labels changed by each move type in its LAST RUN (a type that did not run in a round -- chain families and ICM outside
-  // verification rounds, the component pass in mop-up rounds, coarse scales that are off -- keeps that count: the resting
-  // budget below must not read "did not run" as "changed nothing"); -1: has not run in this solve
-  std::vector<long long> last_count(128, -1);
-  std::vector<char> ran(128, 0);
-  bool all_active = true;
-  bool verifying = false;
+  s->coarse = s->strips && o.use_coarse && b->H >= 4 && b->W >= 4;
+  if (s->coarse)
+    for (int lv = 0; lv < N_COARSE_LV; ++lv) s->slots.push_back(80 + lv);
+  s->active.assign(128, 0);
+  for (int sl : s->slots) s->active[sl] = 1;
+  s->last_count.assign(128, -1);
+  s->ran.assign(128, 0);
   // change stamps + per-strip memo of quiet expansions (exact skip of strips whose inputs did not change)
-  static const int GEOM_R[3] = {0, 2, 4}, GEOM_C[3] = {0, 21, 42};
   if (!b->stamp) PHMRF_TRY(dev_alloc(&b->stamp, (size_t)b->n));
   PHMRF_HIP(hipMemsetAsync(b->stamp, 0, (size_t)b->n * sizeof(uint16_t), b->stream));
   b->tick = 1;
   b->eval_tick = -1;                   // (no energy evaluation in this solve yet: the first one is a full pass)
-  double eu_carry = 0.0, ep_carry = 0.0;
   b->prop_tick = -1;
-  if (chains) {                       // segment memos of all families: one buffer, one memset
+  if (s->chains) {                       // segment memos of all families: one buffer, one memset
     size_t total = 0;
     for (auto& f : b->families)
       for (int p = 0; p < 2; ++p)
@@ -1200,7 +1233,7 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
         }
     PHMRF_HIP(hipMemsetAsync(b->chain_memo, 0, (total ? total : 1) * sizeof(uint16_t), b->stream));
   }
-  if (strips) {                         // (the fusion passes keep a memo, too: slot K)
+  if (s->strips) {                         // (the fusion passes keep a memo, too: slot K)
     int64_t max_strips = 0;
     for (int orient = 0; orient < 2; ++orient) {
       const int Hs = orient ? b->W : b->H, Ws = orient ? b->H : b->W;
@@ -1214,275 +1247,527 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
     }
     PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * (K + 1) * sizeof(uint16_t), b->stream));
   }
-  struct SolveScope {
-    phmrf_block* blk;
-    ~SolveScope() {
-      blk->tick = 0;
-      blk->eval_tick = -1;
-      blk->counter_slot = 0;
-      blk->prop_tick = -1;
-    }
-  } scope{b};
   // One round runs every ACTIVE move type: chain families, ICM, component moves, strip fusion per orientation, strip
   // alpha-expansion per label.  A type stays active while it still changes labels.  When a round is quiet (at most
   // `min_changed` labels changed, or the energy did not go down) a VERIFICATION round with every type active (and the
-  // chain segments cut at their other set of separators) decides: quiet again -> done.  (The energy test also ends the alternation between two labellings of exactly equal energy
-  // that different move types prefer; gco stops on the same criterion, GCoptimization.cpp:1298.)
+  // chain segments cut at their other set of separators) decides: quiet again -> done.  (The energy test also ends the
+  // alternation between two labellings of exactly equal energy that different move types prefer; gco stops on the same
+  // criterion, GCoptimization.cpp:1298.)
   // the energy before the first round (only needed when the caller asked for it: the first round of a solve that
-  // changes labels always improves, and the tolerance refers to the energy after the round)
-  double e_prev = res ? eu0 + ep0 : std::numeric_limits<double>::infinity();
+  // changes labels always improves, and the tolerance refers to the energy after the round).  The tiles of a split block
+  // start without it: their schedule runs on sums over the tiles, which begin with the first round's.
+  s->e_prev = (s->have_init_energy && !b->tile_top && !b->tile_bot) ? s->eu0 + s->ep0 : std::numeric_limits<double>::infinity();
   // The strip alpha-expansions run on one of three fixed cuts (so that the per-strip memo of quiet runs applies).  The
   // cut ADVANCES after a round that moved the labelling at large (>= 1/64 of the labels: the memo is worth little
   // then), when a verification round begins, and from one solve to the next (b->geom_phase); it STAYS while the solve
   // is mopping up, so those rounds only revisit the strips whose inputs changed -- a warm start pays for one full
   // sweep per solve instead of one per round.
-  int geom = b->geom_phase % 3;
-  bool prev_moving = false;            // the previous round moved >= 1/64 of the labels
-  struct GeomScope {
-    phmrf_block* blk;
-    int* g;
-    ~GeomScope() { blk->geom_phase = (*g + 1) % 3; }
-  } geom_scope{b, &geom};
-  while (rounds < o.max_rounds && b->tick < 60000) {      // (the change stamps are 16-bit launch ticks)
-    const int r = rounds;
-    PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
-    std::fill(ran.begin(), ran.end(), 0);
-    {
-      // Chain moves (exact 1-D Viterbi over all K labels): with the strip expansions in place they run in verification
-      // rounds only.  Measured (round 2, live-gco parity cases and the whole-genome bench): in ordinary rounds they make
-      // 60 % of a warm start's label changes but the strips find the same energy without them -- the 2,001,000-node
-      // K=10 cold start even ends 2e-4 LOWER and in 12 rounds instead of 32 (1-D moves leave row / column streaks that
-      // the 2-D moves then have to undo) -- and they were 14 % of the device time.  Without strip expansions (general
-      // graphs have no chains at all; `use_expansion = 0`) rows and columns run in every round as before.
-      const int n_ord_fams = expansions ? 0 : 2;
-      int n_chain = 0;
-      for (int f = 0; f < n_fam; ++f)
-        if (active[72 + f] && (f < n_ord_fams || verifying)) n_chain += b->families[f].n_colours;
-      if (n_chain > 0) {
-        tic(b);
-        for (int f = 0; f < n_fam; ++f)
-          if (active[72 + f] && (f < n_ord_fams || verifying)) {
-            b->counter_slot = 72 + f;
-            ran[72 + f] = 1;
-            // cut phase 0 in ordinary rounds (so the segment memo applies from the second round on); the other set of
-            // separators is used by the verification rounds
-            PHMRF_TRY(chain_sweep_nocount(b, bf, f, verifying ? 1 : 0, false));
-          }
-        toc(b, KC_CHAIN, n_chain);
-      }
-    }
-    // single-site ICM: every strip cell and every chain node is already optimal given the rest, so ICM only earns its
-    // launches on the fixed separator cells; it runs in verification rounds and on graphs without grid moves
-    if (active[76] && (verifying || !(chains || strips))) {
-      b->counter_slot = 76;
-      ran[76] = 1;
-      PHMRF_TRY(icm_sweep_nocount(b, bf));
-    }
-    // component moves: a full pass over the block (seven kernels) whatever the number of labels that changed.  On grid
-    // blocks they run in a solve's first round, after a round that moved the labelling at large, and in verification
-    // rounds; the mop-up rounds in between (a few hundred changed labels, of which the pass would take a dozen) skip
-    // them.  On general graphs, where they are one of two move types, they run in every round.
-    const bool comp_round = rounds == 0 || verifying || prev_moving || !(chains || strips);
-    // (after a round that moved the labelling at large the pass runs whether or not it was rested: its last count is old)
-    if (o.use_components && (active[77] || prev_moving) && comp_round) {
-      b->counter_slot = 77;
-      ran[77] = 1;
-      if (b->tick) ++b->tick;
+  s->geom = b->geom_phase % 3;
+  if (b->tile_top || b->tile_bot) PHMRF_TRY(zero_accum(b, 6, 1));       // the pin-violation counter (tile.hip)
+  abort_guard.armed = false;
+  return PHMRF_OK;
+}
+
+// queue one round: every active move type, then the energy evaluation and the read-back of the change counters
+int solve_round_launch(phmrf_block_t b) {
+  phmrf_solve_state* s = b->ss;
+  PHMRF_CHECK(s, PHMRF_ERR_STATE, "no solve in progress (phmrf_mrf_solve_begin)");
+  PHMRF_CHECK(!s->launched, PHMRF_ERR_STATE, "the previous round has not been decided");
+  if (s->status != 0) return PHMRF_OK;
+  const phmrf_solve_opts& o = s->o;
+  const float bf = s->bf;
+  const int K = b->K;
+  const int r = s->rounds;
+  const bool verifying = s->verifying;
+  std::vector<char>& active = s->active;
+  std::vector<char>& ran = s->ran;
+  PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
+  std::fill(ran.begin(), ran.end(), 0);
+  {
+    // Chain moves (exact 1-D Viterbi over all K labels): with the strip expansions in place they run in verification
+    // rounds only.  Measured (round 2, live-gco parity cases and the whole-genome bench): in ordinary rounds they make
+    // 60 % of a warm start's label changes but the strips find the same energy without them -- the 2,001,000-node
+    // K=10 cold start even ends 2e-4 LOWER and in 12 rounds instead of 32 (1-D moves leave row / column streaks that
+    // the 2-D moves then have to undo) -- and they were 14 % of the device time.  Without strip expansions (general
+    // graphs have no chains at all; `use_expansion = 0`) rows and columns run in every round as before.
+    const int n_ord_fams = s->expansions ? 0 : 2;
+    int n_chain = 0;
+    for (int f = 0; f < s->n_fam; ++f)
+      if (active[72 + f] && (f < n_ord_fams || verifying)) n_chain += b->families[f].n_colours;
+    if (n_chain > 0) {
       tic(b);
-      PHMRF_TRY(launch_component_pass(b, bf));
-      toc(b, KC_COMPONENT, 1);
-    }
-    if (strips) {
-      for (int orient = 0; orient < 2; ++orient) {
-        if (active[78 + orient]) {
-          b->counter_slot = 78 + orient;
-          ran[78 + orient] = 1;
-          // the fusion pass runs on a cut of its own that moves with the expansions' (so that its memo of quiet strips
-          // applies while the cut stays): the expansion cut shifted by half a band / half a segment
-          PHMRF_TRY(strip_pass_nocount(b, bf, orient, (GEOM_R[geom] + 3) % 6, (GEOM_C[geom] + 31) % 64, -1, geom));
+      for (int f = 0; f < s->n_fam; ++f)
+        if (active[72 + f] && (f < n_ord_fams || verifying)) {
+          b->counter_slot = 72 + f;
+          ran[72 + f] = 1;
+          // cut phase 0 in ordinary rounds (so the segment memo applies from the second round on); the other set of
+          // separators is used by the verification rounds
+          PHMRF_TRY(chain_sweep_nocount(b, bf, f, verifying ? 1 : 0, false));
         }
-        if (expansions) {
-          // every active label's expansion of the cut in ONE launch: a wave owns a strip, stages it once and runs the
-          // labels back to back behind the exact filter (strip_multi_kernel)
-          unsigned long long lmask = 0ull;
-          for (int a = 0; a < K; ++a)
-            if (active[8 + a]) {
-              lmask |= 1ull << a;
-              ran[8 + a] = 1;
-            }
-          if (lmask) {
-            if (!b->uT_valid) {
-              tic(b);
-              PHMRF_TRY(launch_unary_planes(b));
-              toc(b, KC_PROPOSE, 1);
-            }
-            tic(b);
-            ++b->tick;
-            PHMRF_TRY(launch_strip_multi(b, bf, orient, GEOM_R[geom], GEOM_C[geom], lmask, geom));
-            b->tick += K;                           // one tick per label inside the launch
-            b->work[4] += 1;
-            toc(b, KC_STRIP, 1);
-          }
-        }
-      }
-    }
-    // coarse alpha-expansions.  Coarse scales switch on while the labelling is still moving at large (the previous round changed >= 25 % of the
-    // labels: a cold start).  A solve that has moved >= 12.5 % of the labels in all (a far-off warm start of an EM
-    // iteration) gets them once at the end, before the tolerance may stop it (force_coarse below); the warm start of a
-    // later EM iteration, which moves 1-3 %, does not pay for them at all.
-    // A scale that changed labels in its last run stays on (like every move type), with the super-cell grid shifted by
-    // one node per round; a verification round tries every shift of both scales.
-    if (coarse) {
-      for (int lv = 0; lv < N_COARSE; ++lv) {
-        const int s = COARSE_SCALE[lv];
-        // (a verification round tries every shift of every scale -- as long as the solve has moved the labelling at
-        //  large or runs to the exact fixed point; the warm start of a later EM iteration under a stopping tolerance,
-        //  which moves 1-3 % of the labels, would pay several times its own cost for them)
-        const bool verify_coarse = verifying && (o.energy_tol_ppb == 0 || total * COARSE_ON_DIV >= b->n);
-        const bool on = verify_coarse || force_coarse || (active[80 + lv] && (last_changed * COARSE_ROUND_DIV >= b->n || coarse_changed[lv] > 0));
-        coarse_ran[lv] = on;
-        if (!on) continue;
-        b->counter_slot = 80 + lv;
-        ran[80 + lv] = 1;
-        for (int off = 0; off < s; ++off)
-          if (verify_coarse || off == r % s)
-            PHMRF_TRY(coarse_sweep_nocount(b, bf, lv, off, (2 * r + lv + off) % 6, (17 * r + 5 * lv + 13 * off) % 64, 0, K));
-      }
-    }
-    b->counter_slot = 0;
-    if (b->timing) PHMRF_TRY(work_fetch_async(b));
-    PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                             b->stream));
-    double eu = 0, ep = 0;
-    PHMRF_TRY(energy_after_round(b, beta, &eu, &ep, &eu_carry, &ep_carry));       // synchronises the stream
-    const double e_now = eu + ep;
-    int64_t ch = 0;
-    for (int sl : slots) {
-      ch += (int64_t)b->counters_host[sl];
-      if (ran[sl]) last_count[sl] = (long long)b->counters_host[sl];
-    }
-    total += ch;
-    last_changed = ch;
-    // "this round moved the labelling at large" (the cut advances, the component pass runs again): >= 1/64 of the labels
-    // in a solve that has moved at large in all (a cold or far-off start: every new cut finds more), >= 1/16 otherwise --
-    // the first round of a warm-started E-step moves 1-3 %, and with the rule at 1/64 its second round was a full sweep on
-    // a new cut plus a component pass: 162 instead of 121 ms per E-step on the whole-genome workload for 1e-6 of energy
-    const bool moving = ch * (total * COARSE_ON_DIV >= b->n ? 64 : 16) >= b->n;
-    prev_moving = moving;
-    if (moving) geom = (geom + 1) % 3;
-    for (int lv = 0; lv < N_COARSE; ++lv)
-      if (coarse_ran[lv]) coarse_changed[lv] = (int64_t)b->counters_host[80 + lv];
-    if (b->timing) work_fold(b);
-    ++rounds;
-    const bool improved = std::isinf(e_prev) ? ch > 0 : e_now < e_prev - 1e-11 * std::fabs(e_prev);
-    static const bool trace = getenv("PHMRF_SOLVE_TRACE") != nullptr;   // development aid (one block at a time)
-    if (trace) {
-      int n_active = 0;
-      for (int sl : slots) n_active += active[sl];
-      fprintf(stderr, "[phmrf solve] round %d active %d/%d changed %lld energy %.6f delta %.3e\n", r, n_active,
-              (int)slots.size(), (long long)ch, e_now, e_now - e_prev);
-      if (b->timing) {                                // per-round time of each kernel class (ms)
-        static double seen[PHMRF_NUM_KERNEL_CLASSES] = {};
-        resolve_timing(b);
-        fprintf(stderr, "[phmrf solve]   ms:");
-        static const char* NM[PHMRF_NUM_KERNEL_CLASSES] = {"emis", "icm", "chain", "comp", "energy", "post", "strip", "prop", "coarse", "fusion"};
-        for (int kc = 0; kc < PHMRF_NUM_KERNEL_CLASSES; ++kc) {
-          fprintf(stderr, " %s %.2f", NM[kc], b->ms[kc] - seen[kc]);
-          seen[kc] = b->ms[kc];
-        }
-        fprintf(stderr, "  changed by slot:");
-        for (int sl : slots)
-          if (b->counters_host[sl]) fprintf(stderr, " %d:%llu", sl, b->counters_host[sl]);
-        fprintf(stderr, "\n");
-        if (b->counters_host[100])
-          fprintf(stderr, "[phmrf solve]   expansion strips: launched %llu, past memo+mask %llu, into DP %llu, DP steps %llu, with a move %llu\n",
-                  b->counters_host[100], b->counters_host[101], b->counters_host[102], b->counters_host[103],
-                  b->counters_host[104]);
-      }
-    }
-    const double gain = e_prev - e_now;
-    if (e_now < e_prev) e_prev = e_now;
-    // accepted tolerance: the round (all active types; the rested ones were worth at most a quarter of the tolerance
-    // together, see below) changed the energy by less than the tolerance.  A round that RAISED the energy by the
-    // tolerance or more (f32 move arithmetic against the f64 energy) is not "converged": it is quiet, and the
-    // verification round decides.
-    bool coarse_moved = false, coarse_just_ran = coarse;
-    for (int lv = 0; lv < N_COARSE; ++lv) {
-      coarse_moved = coarse_moved || (coarse && coarse_ran[lv] && coarse_changed[lv] > 0);
-      coarse_just_ran = coarse_just_ran && coarse_ran[lv];
-    }
-    if (coarse_moved) coarse_checked = false;
-    force_coarse = false;
-    // (|gain| below the tolerance on either side: a round that moved three labels and changed the f64 energy sum by
-    //  2e-13 of itself, up or down, has converged; a rise of the tolerance's size or more has not -- the verification
-    //  round decides then)
-    if (o.energy_tol_ppb > 0 && std::fabs(gain) < 1e-9 * o.energy_tol_ppb * std::fabs(e_prev)) {
-      // A solve that has moved the labelling at large (>= 12.5 % of the labels so far: a cold or far-off start, not the
-      // warm start of a later EM iteration) does not stop before the coarse scales have run once more and gained less
-      // than the tolerance, too: their gains come in few large steps, not in the trickle the tolerance watches.
-      if (coarse && !coarse_checked && !coarse_just_ran && total * COARSE_ON_DIV >= b->n) {
-        coarse_checked = true;
-        force_coarse = true;
-        for (int sl : slots) active[sl] = 1;
-        continue;
-      }
-      converged = 1;
-      break;
-    }
-    const bool quiet = ch <= tol || !improved;
-    if (quiet) {
-      if (all_active && verifying) {
-        converged = 1;
-        break;
-      }
-      for (int sl : slots) active[sl] = 1;           // verification round, on the next cut
-      all_active = true;
-      verifying = true;
-      if (!moving) geom = (geom + 1) % 3;
-      continue;
-    }
-    verifying = false;
-    // A type stays active while it changes labels.  With an energy tolerance the types whose last run changed the
-    // fewest labels are rested until the verification round, as long as ALL rested types together were worth at most a
-    // quarter of the stopping tolerance at this round's average gain per changed label (so the moves a tolerance stop
-    // leaves undone are bounded by 1.25 x the tolerance, however many types there are).
-    int n_act = 0;
-    for (int sl : slots) active[sl] = 1;
-    if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0) {
-      const double budget_labels = 1e-9 * o.energy_tol_ppb * std::fabs(e_prev) / 4.0 / (gain / (double)ch);
-      // (only types that have run in this solve can be rested, on the count of their last run)
-      std::vector<int> by_count;
-      for (int sl : slots)
-        if (last_count[sl] >= 0) by_count.push_back(sl);
-      std::sort(by_count.begin(), by_count.end(), [&](int a, int c) { return last_count[a] < last_count[c]; });
-      double used = 0.0;
-      for (int sl : by_count) {
-        used += (double)last_count[sl];
-        if (used > budget_labels) break;
-        active[sl] = 0;
-      }
-    } else {
-      for (int sl : slots) active[sl] = last_count[sl] != 0 ? 1 : 0;
-    }
-    for (int sl : slots) n_act += active[sl];
-    all_active = n_act == (int)slots.size();
-    if (n_act == 0) {
-      for (int sl : slots) active[sl] = 1;
-      all_active = true;
+      toc(b, KC_CHAIN, n_chain);
     }
   }
+  // single-site ICM: every strip cell and every chain node is already optimal given the rest, so ICM only earns its
+  // launches on the fixed separator cells; it runs in verification rounds and on graphs without grid moves
+  if (active[76] && (verifying || !(s->chains || s->strips))) {
+    b->counter_slot = 76;
+    ran[76] = 1;
+    PHMRF_TRY(icm_sweep_nocount(b, bf));
+  }
+  // component moves: a full pass over the block (seven kernels) whatever the number of labels that changed.  On grid
+  // blocks they run in a solve's first round, after a round that moved the labelling at large, and in verification
+  // rounds; the mop-up rounds in between (a few hundred changed labels, of which the pass would take a dozen) skip
+  // them.  On general graphs, where they are one of two move types, they run in every round.
+  const bool comp_round = s->rounds == 0 || verifying || s->prev_moving || !(s->chains || s->strips);
+  // (after a round that moved the labelling at large the pass runs whether or not it was rested: its last count is old)
+  if (o.use_components && (active[77] || s->prev_moving) && comp_round) {
+    b->counter_slot = 77;
+    ran[77] = 1;
+    if (b->tick) ++b->tick;
+    tic(b);
+    PHMRF_TRY(launch_component_pass(b, bf));
+    toc(b, KC_COMPONENT, 1);
+  }
+  if (s->strips) {
+    const int geom = s->geom;
+    for (int orient = 0; orient < 2; ++orient) {
+      if (active[78 + orient]) {
+        b->counter_slot = 78 + orient;
+        ran[78 + orient] = 1;
+        // the fusion pass runs on a cut of its own that moves with the expansions' (so that its memo of quiet strips
+        // applies while the cut stays): the expansion cut shifted by half a band / half a segment
+        PHMRF_TRY(strip_pass_nocount(b, bf, orient, (GEOM_R[geom] + 3) % 6, (GEOM_C[geom] + 31) % 64, -1, geom));
+      }
+      if (s->expansions) {
+        // every active label's expansion of the cut in ONE launch: a wave owns a strip, stages it once and runs the
+        // labels back to back behind the exact filter (strip_cols_kernel)
+        unsigned long long lmask = 0ull;
+        for (int a = 0; a < K; ++a)
+          if (active[8 + a]) {
+            lmask |= 1ull << a;
+            ran[8 + a] = 1;
+          }
+        if (lmask) {
+          if (!b->uT_valid) {
+            tic(b);
+            PHMRF_TRY(launch_unary_planes(b));
+            toc(b, KC_PROPOSE, 1);
+          }
+          tic(b);
+          ++b->tick;
+          PHMRF_TRY(launch_strip_multi(b, bf, orient, GEOM_R[geom], GEOM_C[geom], lmask, geom));
+          b->tick += K;                           // one tick per label inside the launch
+          b->work[4] += 1;
+          toc(b, KC_STRIP, 1);
+        }
+      }
+    }
+  }
+  // coarse alpha-expansions.  Coarse scales switch on while the labelling is still moving at large (the previous round
+  // changed >= 25 % of the labels: a cold start).  A solve that has moved >= 12.5 % of the labels in all (a far-off warm
+  // start of an EM iteration) gets them once at the end, before the tolerance may stop it (force_coarse below); the warm
+  // start of a later EM iteration, which moves 1-3 %, does not pay for them at all.
+  // A scale that changed labels in its last run stays on (like every move type), with the super-cell grid shifted by
+  // one node per round; a verification round tries every shift of both scales.
+  if (s->coarse) {
+    for (int lv = 0; lv < N_COARSE_LV; ++lv) {
+      const int sc = COARSE_SCALE[lv];
+      // (a verification round tries every shift of every scale -- as long as the solve has moved the labelling at
+      //  large or runs to the exact fixed point; the warm start of a later EM iteration under a stopping tolerance,
+      //  which moves 1-3 % of the labels, would pay several times its own cost for them)
+      const bool verify_coarse = verifying && (o.energy_tol_ppb == 0 || s->total * COARSE_ON_DIV >= s->sched_n);
+      const bool on = verify_coarse || s->force_coarse ||
+                      (active[80 + lv] && (s->last_changed * COARSE_ROUND_DIV >= s->sched_n || s->coarse_changed[lv] > 0));
+      s->coarse_ran[lv] = on;
+      if (!on) continue;
+      b->counter_slot = 80 + lv;
+      ran[80 + lv] = 1;
+      for (int off = 0; off < sc; ++off)
+        if (verify_coarse || off == r % sc)
+          PHMRF_TRY(coarse_sweep_nocount(b, bf, lv, off, (2 * r + lv + off) % 6, (17 * r + 5 * lv + 13 * off) % 64, 0, K));
+    }
+  }
+  b->counter_slot = 0;
+  if (b->timing) PHMRF_TRY(work_fetch_async(b));
+  PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           b->stream));
+  PHMRF_TRY(energy_round_launch(b, &s->incremental, &s->snapshot));
+  s->launched = true;
+  s->collected = false;
+  return PHMRF_OK;
+}
+
+// wait for the round; -> this block's change counters [128] and its (unary, pair without beta) energy after the round
+int solve_round_collect(phmrf_block_t b, unsigned long long* counters, double* energy) {
+  phmrf_solve_state* s = b->ss;
+  PHMRF_CHECK(s, PHMRF_ERR_STATE, "no solve in progress (phmrf_mrf_solve_begin)");
+  if (s->status != 0 && !s->launched) {            // decided already: nothing ran
+    if (counters) std::memset(counters, 0, 128 * sizeof(unsigned long long));
+    if (energy) { energy[0] = s->eu_carry; energy[1] = s->ep_carry; }
+    return PHMRF_OK;
+  }
+  PHMRF_CHECK(s->launched, PHMRF_ERR_STATE, "no round has been launched");
+  if (!s->collected) {
+    PHMRF_HIP(hipStreamSynchronize(b->stream));
+    PHMRF_TRY(energy_round_collect(b, s->beta, s->incremental, &s->eu_carry, &s->ep_carry));
+    if (b->timing) work_fold(b);
+    s->collected = true;
+    if (b->tile_top || b->tile_bot) {
+      unsigned long long viol = 0;
+      std::memcpy(&viol, b->accum_host + 6, sizeof(viol));
+      PHMRF_CHECK(viol == 0, PHMRF_ERR_STATE, "internal: a pinned row of a tile has moved");
+    }
+  }
+  if (counters) std::memcpy(counters, b->counters_host, 128 * sizeof(unsigned long long));
+  if (energy) { energy[0] = s->eu_carry; energy[1] = s->ep_carry; }
+  return PHMRF_OK;
+}
+
+// the schedule: what the round's change counters and energy (of this block, or the sums over the tiles of a split block)
+// mean for the next round.  *status: 0 another round, 1 converged, 2 stopped by max_rounds / the launch budget
+int solve_round_decide(phmrf_block_t b, const unsigned long long* counters, const double* energy, int* status) {
+  phmrf_solve_state* s = b->ss;
+  PHMRF_CHECK(s, PHMRF_ERR_STATE, "no solve in progress (phmrf_mrf_solve_begin)");
+  if (s->status != 0) {
+    if (status) *status = s->status;
+    return PHMRF_OK;
+  }
+  PHMRF_CHECK(s->launched && s->collected, PHMRF_ERR_STATE, "round_decide needs a launched and collected round");
+  s->launched = false;
+  const phmrf_solve_opts& o = s->o;
+  std::vector<char>& active = s->active;
+  const std::vector<int>& slots = s->slots;
+  const int r = s->rounds;
+  const double e_now = energy[0] + s->beta * energy[1];
+  int64_t ch = 0;
+  for (int sl : slots) {
+    ch += (int64_t)counters[sl];
+    if (s->ran[sl]) s->last_count[sl] = (long long)counters[sl];
+  }
+  s->total += ch;
+  s->last_changed = ch;
+  // "this round moved the labelling at large" (the cut advances, the component pass runs again): >= 1/64 of the labels
+  // in a solve that has moved at large in all (a cold or far-off start: every new cut finds more), >= 1/16 otherwise --
+  // the first round of a warm-started E-step moves 1-3 %, and with the rule at 1/64 its second round was a full sweep on
+  // a new cut plus a component pass: 162 instead of 121 ms per E-step on the whole-genome workload for 1e-6 of energy
+  const bool moving = ch * (s->total * COARSE_ON_DIV >= s->sched_n ? 64 : 16) >= s->sched_n;
+  s->prev_moving = moving;
+  if (moving) s->geom = (s->geom + 1) % 3;
+  for (int lv = 0; lv < N_COARSE_LV; ++lv)
+    if (s->coarse_ran[lv]) s->coarse_changed[lv] = (int64_t)counters[80 + lv];
+  ++s->rounds;
+  const bool improved = std::isinf(s->e_prev) ? ch > 0 : e_now < s->e_prev - 1e-11 * std::fabs(s->e_prev);
+  static const bool trace = getenv("PHMRF_SOLVE_TRACE") != nullptr;   // development aid (one block at a time)
+  if (trace) {
+    int n_active = 0;
+    for (int sl : slots) n_active += active[sl];
+    fprintf(stderr, "[phmrf solve] round %d active %d/%d changed %lld energy %.6f delta %.3e\n", r, n_active,
+            (int)slots.size(), (long long)ch, e_now, e_now - s->e_prev);
+    if (b->timing) {                                // per-round time of each kernel class (ms)
+      static double seen[PHMRF_NUM_KERNEL_CLASSES] = {};
+      resolve_timing(b);
+      fprintf(stderr, "[phmrf solve]   ms:");
+      static const char* NM[PHMRF_NUM_KERNEL_CLASSES] = {"emis", "icm", "chain", "comp", "energy", "post", "strip", "prop", "coarse", "fusion"};
+      for (int kc = 0; kc < PHMRF_NUM_KERNEL_CLASSES; ++kc) {
+        fprintf(stderr, " %s %.2f", NM[kc], b->ms[kc] - seen[kc]);
+        seen[kc] = b->ms[kc];
+      }
+      fprintf(stderr, "  changed by slot:");
+      for (int sl : slots)
+        if (counters[sl]) fprintf(stderr, " %d:%llu", sl, counters[sl]);
+      fprintf(stderr, "\n");
+      if (b->counters_host[100])
+        fprintf(stderr, "[phmrf solve]   expansion strips: launched %llu, past memo+mask %llu, into DP %llu, DP steps %llu, with a move %llu\n",
+                b->counters_host[100], b->counters_host[101], b->counters_host[102], b->counters_host[103],
+                b->counters_host[104]);
+    }
+  }
+  const double gain = s->e_prev - e_now;
+  if (e_now < s->e_prev) s->e_prev = e_now;
+  auto finish = [&](int st) {
+    s->status = st;
+    if (status) *status = st;
+    return PHMRF_OK;
+  };
+  auto next_round = [&]() {               // (the change stamps are 16-bit launch ticks)
+    if (s->rounds >= o.max_rounds || b->tick >= 60000) return finish(2);
+    if (status) *status = 0;
+    return (int)PHMRF_OK;
+  };
+  // accepted tolerance: the round (all active types; the rested ones were worth at most a quarter of the tolerance
+  // together, see below) changed the energy by less than the tolerance.  A round that RAISED the energy by the
+  // tolerance or more (f32 move arithmetic against the f64 energy) is not "converged": it is quiet, and the
+  // verification round decides.
+  bool coarse_moved = false, coarse_just_ran = s->coarse;
+  for (int lv = 0; lv < N_COARSE_LV; ++lv) {
+    coarse_moved = coarse_moved || (s->coarse && s->coarse_ran[lv] && s->coarse_changed[lv] > 0);
+    coarse_just_ran = coarse_just_ran && s->coarse_ran[lv];
+  }
+  if (coarse_moved) s->coarse_checked = false;
+  s->force_coarse = false;
+  // (|gain| below the tolerance on either side: a round that moved three labels and changed the f64 energy sum by
+  //  2e-13 of itself, up or down, has converged; a rise of the tolerance's size or more has not -- the verification
+  //  round decides then)
+  if (o.energy_tol_ppb > 0 && std::fabs(gain) < 1e-9 * o.energy_tol_ppb * std::fabs(s->e_prev)) {
+    // A solve that has moved the labelling at large (>= 12.5 % of the labels so far: a cold or far-off start, not the
+    // warm start of a later EM iteration) does not stop before the coarse scales have run once more and gained less
+    // than the tolerance, too: their gains come in few large steps, not in the trickle the tolerance watches.
+    if (s->coarse && !s->coarse_checked && !coarse_just_ran && s->total * COARSE_ON_DIV >= s->sched_n) {
+      s->coarse_checked = true;
+      s->force_coarse = true;
+      for (int sl : slots) active[sl] = 1;
+      return next_round();
+    }
+    s->converged = 1;
+    return finish(1);
+  }
+  const bool quiet = ch <= s->tol || !improved;
+  if (quiet) {
+    if (s->all_active && s->verifying) {
+      s->converged = 1;
+      return finish(1);
+    }
+    for (int sl : slots) active[sl] = 1;           // verification round, on the next cut
+    s->all_active = true;
+    s->verifying = true;
+    if (!moving) s->geom = (s->geom + 1) % 3;
+    return next_round();
+  }
+  s->verifying = false;
+  // A type stays active while it changes labels.  With an energy tolerance the types whose last run changed the
+  // fewest labels are rested until the verification round, as long as ALL rested types together were worth at most a
+  // quarter of the stopping tolerance at this round's average gain per changed label (so the moves a tolerance stop
+  // leaves undone in one round of the types that have run are bounded by 1.25 x the tolerance, however many types there are).
+  int n_act = 0;
+  for (int sl : slots) active[sl] = 1;
+  if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0) {
+    const double budget_labels = 1e-9 * o.energy_tol_ppb * std::fabs(s->e_prev) / 4.0 / (gain / (double)ch);
+    // (only types that have run in this solve can be rested, on the count of their last run)
+    std::vector<int> by_count;
+    for (int sl : slots)
+      if (s->last_count[sl] >= 0) by_count.push_back(sl);
+    std::sort(by_count.begin(), by_count.end(), [&](int a, int c) { return s->last_count[a] < s->last_count[c]; });
+    double used = 0.0;
+    for (int sl : by_count) {
+      used += (double)s->last_count[sl];
+      if (used > budget_labels) break;
+      active[sl] = 0;
+    }
+  } else {
+    for (int sl : slots) active[sl] = s->last_count[sl] != 0 ? 1 : 0;
+  }
+  for (int sl : slots) n_act += active[sl];
+  s->all_active = n_act == (int)slots.size();
+  if (n_act == 0) {
+    for (int sl : slots) active[sl] = 1;
+    s->all_active = true;
+  }
+  return next_round();
+}
+
+int solve_end(phmrf_block_t b, phmrf_solve_result* res) {
+  phmrf_solve_state* s = b->ss;
+  PHMRF_CHECK(s, PHMRF_ERR_STATE, "no solve in progress (phmrf_mrf_solve_begin)");
+  if (s->launched && !s->collected) (void)hipStreamSynchronize(b->stream);
   b->has_labels = true;
+  int st = PHMRF_OK;
   if (res) {
     double eu = 0, ep = 0;
-    PHMRF_TRY(energy_now(b, beta, &eu, &ep));
+    st = energy_now(b, s->beta, &eu, &ep);
     res->energy = eu + ep;
     res->energy_unary = eu;
     res->energy_pair = ep;
-    res->energy_init = eu0 + ep0;
-    res->rounds = rounds;
-    res->converged = converged;
-    res->changed = total;
+    res->energy_init = s->have_init_energy ? s->eu0 + s->ep0 : std::numeric_limits<double>::quiet_NaN();
+    res->rounds = s->rounds;
+    res->converged = s->converged;
+    res->changed = s->total;
   }
+  solve_scope_exit(b);
+  return st;
+}
+}  // namespace
+
+extern "C" {
+
+int phmrf_mrf_solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, int want_init_energy) {
+  return solve_begin(b, beta, opts, want_init_energy != 0);
+}
+int phmrf_mrf_solve_round_launch(phmrf_block_t b) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  return solve_round_launch(b);
+}
+int phmrf_mrf_solve_round_collect(phmrf_block_t b, uint64_t* counters, double* energy) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  return solve_round_collect(b, reinterpret_cast<unsigned long long*>(counters), energy);
+}
+int phmrf_mrf_solve_round_decide(phmrf_block_t b, const uint64_t* counters, const double* energy, int* status) {
+  PHMRF_CHECK(b && counters && energy, PHMRF_ERR_INVALID, "NULL argument");
+  return solve_round_decide(b, reinterpret_cast<const unsigned long long*>(counters), energy, status);
+}
+int phmrf_mrf_solve_end(phmrf_block_t b, phmrf_solve_result* res) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  return solve_end(b, res);
+}
+
+int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res) {
+  PHMRF_TRY(solve_begin(b, beta, opts, res != nullptr));
+  struct Scope {                               // an error inside the loop still ends the solve
+    phmrf_block* blk;
+    ~Scope() { if (blk->ss) solve_scope_exit(blk); }
+  } scope{b};
+  int status = 0;
+  unsigned long long counters[128];
+  double energy[2];
+  while (status == 0) {
+    if (b->ss->rounds >= b->ss->o.max_rounds || b->tick >= 60000) break;
+    PHMRF_TRY(solve_round_launch(b));
+    PHMRF_TRY(solve_round_collect(b, counters, energy));
+    PHMRF_TRY(solve_round_decide(b, counters, energy, &status));
+  }
+  return solve_end(b, res);
+}
+
+
+// ---- row tiles (tile.hip) -----------------------------------------------------------------------
+static int64_t row_first(const phmrf_block* b, int i) {      // first node of grid row i (i == H: n)
+  return b->diagonal ? (int64_t)i * b->W - ((int64_t)i * (i - 1)) / 2 : (int64_t)i * b->W;
+}
+
+int phmrf_block_set_tile(phmrf_block_t b, int top, int bottom, int64_t sched_n) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "row tiles need the grid geometry (phmrf_block_set_grid / build_grid_graph)");
+  PHMRF_CHECK(!b->ss, PHMRF_ERR_STATE, "a solve is in progress");
+  top = top ? 1 : 0;
+  bottom = bottom ? 1 : 0;
+  PHMRF_CHECK(b->H >= 2 * (top + bottom) + 2, PHMRF_ERR_INVALID, "a tile needs two rows per cut and two more");
+  for (int r = 0; r < 2; ++r) {
+    dev_free(b->pin_save[r]);
+    dev_free(b->pin_label[r]);
+    b->pin_first[r] = b->pin_count[r] = b->pin_split[r] = 0;
+    b->pin_rows[r] = 0;
+  }
+  b->pin_saved = false;
+  b->tile_top = top;
+  b->tile_bot = bottom;
+  b->sched_n = sched_n > 0 ? sched_n : 0;
+  if (!top && !bottom) {
+    b->own0 = 0;
+    b->own1 = -1;
+    b->own_r0 = 0;
+    b->own_r1 = -1;
+    return PHMRF_OK;
+  }
+  b->own_r0 = top ? 1 : 0;
+  b->own_r1 = b->H - (bottom ? 1 : 0);
+  b->own0 = row_first(b, b->own_r0);
+  b->own1 = row_first(b, b->own_r1);
+  if (top) {
+    b->pin_first[0] = 0;
+    b->pin_count[0] = row_first(b, 2);
+    b->pin_split[0] = row_first(b, 1);
+  }
+  if (bottom) {
+    b->pin_first[1] = row_first(b, b->H - 2);
+    b->pin_count[1] = b->n - b->pin_first[1];
+    b->pin_split[1] = row_first(b, b->H - 1) - b->pin_first[1];
+  }
+  int64_t cap = 0;
+  for (int r = 0; r < 2; ++r)
+    if (b->pin_count[r] > 0) {
+      PHMRF_TRY(dev_alloc(&b->pin_save[r], (size_t)b->pin_count[r] * b->K));
+      PHMRF_TRY(dev_alloc(&b->pin_label[r], (size_t)b->pin_count[r]));
+      cap += b->pin_count[r];
+    }
+  if (cap > b->xfer_cap) {
+    dev_free(b->xfer);
+    if (b->xfer_host) (void)hipHostFree(b->xfer_host);
+    b->xfer_host = nullptr;
+    PHMRF_TRY(dev_alloc(&b->xfer, (size_t)cap));
+    PHMRF_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->xfer_host), (size_t)cap));
+    b->xfer_cap = cap;
+  }
+  return PHMRF_OK;
+}
+
+// the node range of the first (from the top) / last (from the bottom) `rows` rows of a pin region
+static void pin_range(const phmrf_block* b, int region, int rows, int64_t* first, int64_t* count) {
+  *first = b->pin_first[region];
+  *count = 0;
+  if (rows <= 0 || b->pin_count[region] == 0) return;
+  if (rows >= 2) {
+    *count = b->pin_count[region];
+  } else if (region == 0) {
+    *count = b->pin_split[0];
+  } else {
+    *first = b->pin_first[1] + b->pin_split[1];
+    *count = b->pin_count[1] - b->pin_split[1];
+  }
+}
+
+int phmrf_block_tile_pins(phmrf_block_t b, int n_top, int n_bottom) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(b->tile_top || b->tile_bot, PHMRF_ERR_STATE, "the block is not a tile (phmrf_block_set_tile)");
+  PHMRF_CHECK(b->has_logprob, PHMRF_ERR_STATE, "logprob not set");
+  PHMRF_CHECK(n_top >= 0 && n_top <= 2 && n_bottom >= 0 && n_bottom <= 2, PHMRF_ERR_INVALID, "0, 1 or 2 rows per cut");
+  const int want[2] = {b->tile_top ? n_top : 0, b->tile_bot ? n_bottom : 0};
+  if (b->tick) ++b->tick;                  // (one tick whatever the tile's cuts: the tiles of a block count alike)
+  for (int r = 0; r < 2; ++r) {
+    if (b->pin_count[r] == 0) continue;
+    int64_t pf, pc, wf, wc;
+    pin_range(b, r, want[r], &pf, &pc);
+    pin_range(b, r, b->pin_saved ? b->pin_rows[r] : 0, &wf, &wc);
+    PHMRF_TRY(launch_tile_pins(b, r, b->pin_first[r], b->pin_count[r], pf, pc, wf, wc, !b->pin_saved));
+    b->pin_rows[r] = want[r];
+  }
+  b->pin_saved = true;
+  return PHMRF_OK;
+}
+
+// the rows the neighbour tiles need: top_out = the first row this tile owns, bottom_out = the last (either may be NULL)
+int phmrf_block_tile_get_boundary(phmrf_block_t b, uint8_t* top_out, uint8_t* bottom_out) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(b->tile_top || b->tile_bot, PHMRF_ERR_STATE, "the block is not a tile (phmrf_block_set_tile)");
+  int64_t off = 0, tf = 0, tc = 0, bf = 0, bc = 0;
+  if (top_out && b->tile_top) {
+    tf = row_first(b, 1);
+    tc = row_first(b, 2) - tf;
+    PHMRF_HIP(hipMemcpyAsync(b->xfer_host, b->labels + tf, (size_t)tc, hipMemcpyDeviceToHost, b->stream));
+    off = tc;
+  }
+  if (bottom_out && b->tile_bot) {
+    bf = row_first(b, b->H - 2);
+    bc = row_first(b, b->H - 1) - bf;
+    PHMRF_HIP(hipMemcpyAsync(b->xfer_host + off, b->labels + bf, (size_t)bc, hipMemcpyDeviceToHost, b->stream));
+  }
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  if (tc) std::memcpy(top_out, b->xfer_host, (size_t)tc);
+  if (bc) std::memcpy(bottom_out, b->xfer_host + off, (size_t)bc);
+  return PHMRF_OK;
+}
+
+// the neighbours' rows: top_in -> this tile's first row (its upper halo), bottom_in -> its last row (either may be NULL)
+int phmrf_block_tile_put_halo(phmrf_block_t b, const uint8_t* top_in, const uint8_t* bottom_in) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(b->tile_top || b->tile_bot, PHMRF_ERR_STATE, "the block is not a tile (phmrf_block_set_tile)");
+  if (b->tick) ++b->tick;
+  int64_t off = 0;
+  if (top_in && b->tile_top) {
+    const int64_t c = row_first(b, 1);
+    for (int64_t q = 0; q < c; ++q) PHMRF_CHECK(top_in[q] < b->K, PHMRF_ERR_INVALID, "label out of range [0,K)");
+    std::memcpy(b->xfer_host, top_in, (size_t)c);
+    PHMRF_HIP(hipMemcpyAsync(b->xfer, b->xfer_host, (size_t)c, hipMemcpyHostToDevice, b->stream));
+    PHMRF_TRY(launch_put_labels(b, 0, c, b->xfer));
+    off = c;
+  }
+  if (bottom_in && b->tile_bot) {
+    const int64_t f = row_first(b, b->H - 1), c = b->n - f;
+    for (int64_t q = 0; q < c; ++q) PHMRF_CHECK(bottom_in[q] < b->K, PHMRF_ERR_INVALID, "label out of range [0,K)");
+    std::memcpy(b->xfer_host + off, bottom_in, (size_t)c);
+    PHMRF_HIP(hipMemcpyAsync(b->xfer + off, b->xfer_host + off, (size_t)c, hipMemcpyHostToDevice, b->stream));
+    PHMRF_TRY(launch_put_labels(b, f, c, b->xfer + off));
+  }
+  // (the staging buffers are reused by the next call: the copies must have left the host buffer)
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
   return PHMRF_OK;
 }
 
@@ -1577,10 +1862,11 @@ int phmrf_block_enable_timing(phmrf_block_t b, int enable) {
   return PHMRF_OK;
 }
 
-int phmrf_block_get_timing(phmrf_block_t b, double* ms, int64_t* launches) {
+int phmrf_block_get_timing(phmrf_block_t b, int capacity, double* ms, int64_t* launches) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(capacity >= 0, PHMRF_ERR_INVALID, "capacity < 0");
   resolve_timing(b);
-  for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES; ++i) {
+  for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES && i < capacity; ++i) {
     if (ms) ms[i] = b->ms[i];
     if (launches) launches[i] = b->launches[i];
   }

@@ -218,7 +218,8 @@ static CoarseGeom make_coarse_geom(const phmrf_block* b, int s, int off) {
 
 int64_t coarse_nodes(const phmrf_block* b, int s, int off) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
-  return g.diagonal ? (int64_t)g.Hc * (g.Hc + 1) / 2 : (int64_t)g.Hc * g.Wc;
+  // (upper-triangular blocks: rows 0 .. Hc-1 of the Wc x Wc triangle -- Hc < Wc for a row tile of a diagonal block)
+  return g.diagonal ? (int64_t)g.Hc * g.Wc - (int64_t)g.Hc * (g.Hc - 1) / 2 : (int64_t)g.Hc * g.Wc;
 }
 
 // Point the child blocks at the coarse grid of (s, off) and fill their unary planes / forward weights / labels for up to

@@ -60,6 +60,7 @@ struct ChainFamily {
 //   labels   u8  [n]           current labelling
 //   nbr      i32 [n, D]        ELL adjacency, neighbours ascending, -1 padded; D = max degree rounded up to 4
 //   wgt      f32 [n, D]        edge weights w_ij (0 in padding)
+struct phmrf_solve_state;
 struct phmrf_block {
   int64_t n = 0;
   int S = 0, K = 0;
@@ -142,6 +143,60 @@ struct phmrf_block {
   int64_t work[8] = {};                     // strips staged, their cells, staged cells, DP steps, strip launches (since reset_timing)
   struct Interval { int kclass; float t0, t1; };
   std::vector<Interval> intervals;          // resolved timed intervals on the library's common time base (ms)
+
+  // ---- row tiles (tile.hip, phmrf_block_set_tile): this block is rows [r0 - top, r1 + bottom) of a larger grid block whose
+  // other rows live in other blocks (other GPUs).  The first / last stored row is then a HALO: a copy of the neighbour
+  // tile's boundary row, never moved here, not counted in energies, costs and statistics.
+  int tile_top = 0, tile_bot = 0;           // 1: there is a neighbour tile above / below (the first / last row is its halo)
+  int64_t own0 = 0, own1 = -1;              // nodes [own0, own1) are the ones this block counts (own1 < 0: all n)
+  int own_r0 = 0, own_r1 = -1;              // ... = grid rows [own_r0, own_r1)
+  int64_t sched_n = 0;                      // node count the solver's schedule thresholds refer to (0: n; tiles: the whole block's)
+  // pinned rows: the two rows at a cut are frozen in turn (round parity) so that the tiles on either side never move two
+  // adjacent nodes at once.  A pinned node keeps its label because its unary terms say so: u(k) = PIN_COST for k != label.
+  float* pin_save[2] = {nullptr, nullptr};  // device: the real logprob rows of the two top / two bottom rows, [rows][K]
+  uint8_t* pin_label[2] = {nullptr, nullptr};   // device: their labels when the pins were last set (a pinned label must not move)
+  uint8_t* xfer = nullptr;                  // device staging for the halo rows (2 rows)
+  uint8_t* xfer_host = nullptr;             // pinned mirror
+  int64_t xfer_cap = 0;
+  int64_t pin_first[2] = {0, 0}, pin_count[2] = {0, 0};   // node range of the two top / two bottom rows
+  int64_t pin_split[2] = {0, 0};            // nodes of the FIRST of the two rows (top region) / of the first of the two bottom rows
+  int pin_rows[2] = {0, 0};                 // how many rows of each region are pinned right now (top: counted from the top, bottom: from the bottom)
+  bool pin_saved = false;                   // pin_save holds the rows of the current logprob (set by tile_pins after an emission)
+  struct phmrf_solve_state* ss = nullptr;   // a solve in progress (phmrf_mrf_solve_begin .. _end)
+};
+
+// the label solver between phmrf_mrf_solve_begin and _end (api.hip)
+struct phmrf_solve_state {
+  phmrf_solve_opts o;
+  double beta = 0;
+  float bf = 0;
+  bool have_init_energy = false;
+  double eu0 = 0, ep0 = 0;
+  int64_t total = 0;
+  int rounds = 0, converged = 0;
+  bool chains = false, strips = false, expansions = false, coarse = false;
+  int n_fam = 0;
+  int64_t tol = 0;
+  int64_t sched_n = 0;
+  std::vector<int> slots;
+  int64_t last_changed = 0;            // labels changed by the previous round
+  int64_t coarse_changed[3] = {0, 0, 0};  // ... by the coarse scales in their last run
+  bool coarse_ran[3] = {false, false, false};
+  bool force_coarse = false;           // the tolerance wants to stop, but the coarse scales have not had their say
+  bool coarse_checked = false;
+  std::vector<char> active, ran;
+  // labels changed by each move type in its LAST RUN (a type that did not run in a round -- chain families and ICM outside
+  // verification rounds, the component pass in mop-up rounds, coarse scales that are off -- keeps that count: the resting
+  // budget below must not read "did not run" as "changed nothing"); -1: has not run in this solve
+  std::vector<long long> last_count;
+  bool all_active = true, verifying = false;
+  double eu_carry = 0, ep_carry = 0;   // (unary, pair without beta) at the last evaluation
+  double e_prev = 0;
+  int geom = 0;
+  bool prev_moving = false;            // the previous round moved >= 1/64 of the labels
+  // between round_launch and round_decide
+  bool launched = false, collected = false, incremental = false, snapshot = false;
+  int status = 0;                      // 0: another round; 1: converged; 2: out of rounds / launch budget
 };
 
 namespace phmrf {
@@ -184,6 +239,12 @@ int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, con
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr,
                         unsigned int* moved_flag = nullptr);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
+// row tiles (tile.hip)
+constexpr float PIN_COST = 1.0e9f;      // unary term of every label but its own at a pinned node (<< f32 max: sums of a strip's
+                                        // or a component's terms stay finite; >> any real term: no move takes it)
+int launch_tile_pins(phmrf_block* b, int region, int64_t first, int64_t count, int64_t pinned_first, int64_t pinned_count,
+                     int64_t was_first, int64_t was_count, bool save_first);
+int launch_put_labels(phmrf_block* b, int64_t first, int64_t count, const uint8_t* src_dev);
 
 // ---- grid geometry for the kernels that find a node's neighbours by arithmetic (device code) ---------------------
 // Diagonal blocks hold the upper triangle row-major: row i starts at start(i) = i W - i (i - 1) / 2 with column i.

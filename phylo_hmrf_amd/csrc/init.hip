@@ -19,7 +19,9 @@ namespace {
 template <int S, bool OUTER>
 __global__ __launch_bounds__(256) void kmeans_step_kernel(const float* __restrict__ X, int64_t n, int K,
                                                           const float* __restrict__ centers, uint8_t* __restrict__ labels,
-                                                          double* __restrict__ acc /* [K*S sums | K counts | inertia | K*S*S] */) {
+                                                          double* __restrict__ acc /* [K*S sums | K counts | inertia | K*S*S] */,
+                                                          int64_t own0, int64_t own1) {
+  // (every node is labelled; only the nodes [own0, own1) -- all of them unless the block is a row tile -- enter the sums)
   extern __shared__ float part[];                 // [K*S sums | K counts | 1 inertia | K*S*S second moments]
   const int NP = K * S + K + 1 + (OUTER ? K * S * S : 0);
   for (int q = threadIdx.x; q < NP; q += blockDim.x) part[q] = 0.f;
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256) void kmeans_step_kernel(const float* __restric
         if (d < best) { best = d; bk = k; }
       }
       if (labels) labels[i] = (uint8_t)bk;
+      if (i >= own0 && i < own1) {
 #pragma unroll
       for (int s = 0; s < S; ++s) atomicAdd(part + bk * S + s, x[s]);     // LDS float atomics
       atomicAdd(part + K * S + bk, 1.f);
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(256) void kmeans_step_kernel(const float* __restric
         for (int s = 0; s < S; ++s)
 #pragma unroll
           for (int t = 0; t < S; ++t) atomicAdd(oo + s * S + t, x[s] * x[t]);
+      }
       }
     }
     __syncthreads();
@@ -82,15 +86,16 @@ int launch_kmeans_step(const phmrf_block* b, const float* centers_dev, bool writ
   const size_t lds = (size_t)(K * b->S + K + 1 + (outer ? K * b->S * b->S : 0)) * sizeof(float);
   int64_t g64 = (b->n + 255) / 256;
   const int grid = (int)(g64 > 2048 ? 2048 : g64);
+  const int64_t own0 = b->own1 >= 0 ? b->own0 : 0, own1 = b->own1 >= 0 ? b->own1 : b->n;
   switch (b->S) {
 #define PHMRF_CASE(S_)                                                                                               \
   case S_:                                                                                                           \
     if (outer && S_ <= 8)                                                                                            \
       hipLaunchKernelGGL((kmeans_step_kernel<(S_ <= 8 ? S_ : 1), true>), dim3(grid), dim3(256), lds, b->stream, b->X, b->n, \
-                         K, centers_dev, write_labels ? b->labels : nullptr, acc_dev);                               \
+                         K, centers_dev, write_labels ? b->labels : nullptr, acc_dev, own0, own1);                   \
     else                                                                                                             \
       hipLaunchKernelGGL((kmeans_step_kernel<S_, false>), dim3(grid), dim3(256), lds, b->stream, b->X, b->n, K,      \
-                         centers_dev, write_labels ? b->labels : nullptr, acc_dev);                                  \
+                         centers_dev, write_labels ? b->labels : nullptr, acc_dev, own0, own1);                      \
     break;
     PHMRF_CASE(1) PHMRF_CASE(2) PHMRF_CASE(3) PHMRF_CASE(4) PHMRF_CASE(5) PHMRF_CASE(6) PHMRF_CASE(7) PHMRF_CASE(8)
     PHMRF_CASE(9) PHMRF_CASE(10) PHMRF_CASE(11) PHMRF_CASE(12) PHMRF_CASE(13) PHMRF_CASE(14) PHMRF_CASE(15) PHMRF_CASE(16)

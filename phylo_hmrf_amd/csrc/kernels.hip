@@ -321,7 +321,9 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restrict__ logprob, const float* __restrict__ uT,
                                                           int64_t n, int K, int H, int W,
                                                           int diagonal, const float4* __restrict__ fwd_w,
-                                                          const uint8_t* __restrict__ labels, double* __restrict__ accum, int det) {
+                                                          const uint8_t* __restrict__ labels, double* __restrict__ accum, int det,
+                                                          int row0, int row1) {
+  // (rows [row0, row1): a row tile counts the rows it owns -- unary terms and forward edges; its halo rows below supply labels)
   __shared__ double red[8];
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   double eu = 0.0, ep = 0.0;
@@ -331,14 +333,14 @@ __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restric
   // coalesce, where the node-major rows cost a 64-byte sector per node).
   constexpr int UR = 4;
   const int stride = gridDim.y * 4;
-  for (int i0 = blockIdx.y * 4 + (threadIdx.x >> 6); i0 < H; i0 += stride * UR) {
+  for (int i0 = row0 + blockIdx.y * 4 + (threadIdx.x >> 6); i0 < row1; i0 += stride * UR) {
     int64_t node[UR];
     int lab[UR];
     bool on[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const int i = i0 + u * stride;
-      on[u] = i < H && j < W && !(diagonal && j < i);
+      on[u] = i < row1 && j < W && !(diagonal && j < i);
       const int64_t row = diagonal ? (int64_t)i * W - ((int64_t)i * (i - 1)) / 2 - i : (int64_t)i * W;      // node = row + j
       node[u] = on[u] ? row + j : 0;
       lab[u] = labels[node[u]];
@@ -483,7 +485,9 @@ __global__ __launch_bounds__(256, 5) void posterior_kernel(const float* __restri
                                                         const int32_t* __restrict__ nbr, const float* __restrict__ wgt,
                                                         const uint8_t* __restrict__ labels, float beta, int use_w,
                                                         float* __restrict__ post_out, double* __restrict__ accum,
-                                                        int gH, int gW, int gdiag, const float4* __restrict__ fwd_w) {
+                                                        int gH, int gW, int gdiag, const float4* __restrict__ fwd_w,
+                                                        int64_t n_first) {
+  // (nodes [n_first, n): a row tile counts the nodes it owns; their neighbours may lie outside the range)
   extern __shared__ float lds[];
   constexpr int M = 1 + S + S * (S + 1) / 2;      // features [1 | x | x_s x_t, s <= t]: x x^T is symmetric
   // ... and every one of them is a product of two entries of xa = [1 | x]: only xa goes to LDS (S + 1 floats per node
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256, 5) void posterior_kernel(const float* __restri
   }
   __syncthreads();
 
-  for (int64_t base = (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
+  for (int64_t base = n_first + (int64_t)blockIdx.x * TB; base < n; base += (int64_t)gridDim.x * TB) {
     const int64_t rem = n - base;
     const int rows = rem < TB ? (int)rem : TB;
     const int64_t i = base + threadIdx.x;
@@ -729,7 +733,8 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   // (grid cap swept on the 12.4 M-node block: 2048 -> 925 us, 1024 -> 1069, 768 = three resident workgroups per CU -> 885, 512 -> 1111)
   // (round 3, packed features: 39 KB at K = 20, S = 4 = four resident workgroups per CU: 768 -> 790 us, 1024 -> 680, 1280 -> 810;
   //  then only [1 | x] in LDS: 29 KB, and 84 registers under __launch_bounds__(256, 5) = five per CU: 1024 -> 700, 1280 -> 650)
-  const int grid = grid_for(b->n, TB, cap_env > 0 ? cap_env : (lds <= 32 * 1024 ? 256 * 5 : (lds <= 40 * 1024 ? 256 * 4 : (lds <= 53 * 1024 ? 256 * 3 : 256 * 8))) * (256 / TB));
+  const int64_t n_first = b->own1 >= 0 ? b->own0 : 0, n_last = b->own1 >= 0 ? b->own1 : b->n;
+  const int grid = grid_for(n_last - n_first, TB, cap_env > 0 ? cap_env : (lds <= 32 * 1024 ? 256 * 5 : (lds <= 40 * 1024 ? 256 * 4 : (lds <= 53 * 1024 ? 256 * 3 : 256 * 8))) * (256 / TB));
   const int use_w = estimate_type == 3 ? 1 : 0;
   // the grid form needs the 8-neighbour stencil's forward-edge records (phmrf_block_set_grid / build_grid_graph)
   const bool grid_form = b->has_grid && b->grid_complete && b->fwd_w && b->D == 8 && b->num_neighbor == 8;
@@ -739,8 +744,8 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
       PHMRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&posterior_kernel<S, VEC_, WP_, G_>),             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
     hipLaunchKernelGGL((posterior_kernel<S, VEC_, WP_, G_>), dim3(grid), dim3(TB), lds, b->stream, b->X, b->logprob, \
-                       b->n, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, use_w, b->posteriors, b->accum, b->H, b->W, \
-                       b->diagonal, b->fwd_w);                                                                      \
+                       n_last, K, Kp, b->D, b->nbr, b->wgt, b->labels, beta, use_w, b->posteriors, b->accum, b->H, b->W, \
+                       b->diagonal, b->fwd_w, n_first);                                                             \
   }
 #define PHMRF_LAUNCH_POST(VEC_, WP_)                                                                                \
   if (grid_form) PHMRF_LAUNCH_POST_G(VEC_, WP_, true) else PHMRF_LAUNCH_POST_G(VEC_, WP_, false)
@@ -806,9 +811,10 @@ int launch_energy(const phmrf_block* b, float beta) {
     int gy = (b->H + 3) / 4;
     const int cap = 2048 / gx + 1;          // ~2048 workgroups: each sums many rows before its two f64 atomics
     if (gy > cap) gy = cap;
+    const int row0 = b->own_r1 >= 0 ? b->own_r0 : 0, row1 = b->own_r1 >= 0 ? b->own_r1 : b->H;
     hipLaunchKernelGGL(energy_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->logprob,
                        (b->uT && b->uT_valid) ? b->uT : nullptr, b->n, b->K, b->H, b->W, b->diagonal, b->fwd_w, b->labels, b->accum,
-                       b->deterministic ? 1 : 0);
+                       b->deterministic ? 1 : 0, row0, row1);
     PHMRF_HIP(hipGetLastError());
     return PHMRF_OK;
   }

@@ -33,7 +33,7 @@ class phyloHMRF(_BaseGraph):
                  random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
                  learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
                  solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=14,
-                 init_method="minibatch"):
+                 init_method="minibatch", split_above=1.0, tile_parts=None):
         _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
                             startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
                             random_state=random_state, n_iter=n_iter, tol=tol, params=params, verbose=verbose,
@@ -68,7 +68,9 @@ class phyloHMRF(_BaseGraph):
         env_rank, env_world, _ = env_rank_world()
         self.world = env_world if world is None else world
         self.rank = env_rank if rank is None else rank
-        if self.rank == 0 and block_factory is None:
+        if block_factory is None and not _mstep.native_available():
+            # (only when the native M-step -- all states in one library call on host threads -- is unavailable: the Python
+            #  fall-back fits the states in worker processes, which must be forked before this process touches the GPU)
             import os as _os
             want = min(n_components, _os.cpu_count() or 1) if mstep_workers is None else int(mstep_workers)
             _mstep._pool(want)
@@ -108,10 +110,36 @@ class phyloHMRF(_BaseGraph):
             initial_mode, initial_weight, initial_weight1, initial_magnitude)
         self.stats = dict()
 
-        # block ownership
-        sizes = [lv[0] for lv in self.len_vec]
-        self.owner = lpt_assign(sizes, self.world)
-        self.my_regions = [r for r in range(len(self.len_vec)) if self.owner[r] == self.rank]
+        # block ownership: whole syntenic blocks are dealt to the ranks longest first; a block that holds more than
+        # split_above x (all nodes / world) is cut into row tiles first (tiles.py), which are dealt like blocks
+        from . import tiles as _tiles
+        geo = []
+        for lv in self.len_vec:
+            n, H, W = lv[0], lv[3], lv[4]
+            diag = bool(lv[8]) if len(lv) > 8 else (H == W and n == H * (H + 1) // 2)
+            geo.append((H, W, diag, n == (H * (H + 1) // 2 if diag else H * W) and num_neighbor == 8))
+        can_split = block_factory is None
+        force = {int(r): int(p) for r, p in (tile_parts or {}).items()} if can_split else {}
+        units = []
+        share = sum(lv[0] for lv in self.len_vec) / float(max(self.world, 1))
+        for r, (H, W, diag, grid_ok) in enumerate(geo):
+            parts = 1
+            if can_split and grid_ok:
+                if r in force:
+                    parts = force[r]
+                elif self.world > 1 and self.len_vec[r][0] > split_above * share:
+                    parts = int(np.ceil(self.len_vec[r][0] / (split_above * share)))
+            rows = _tiles.split_rows(H, W, diag, parts) if parts > 1 else [(0, H)]
+            if len(rows) == 1:
+                units.append(dict(block=r, tile=0, ntiles=1, r0=0, r1=H, nodes=self.len_vec[r][0]))
+            else:
+                for t, (r0, r1) in enumerate(rows):
+                    units.append(dict(block=r, tile=t, ntiles=len(rows), r0=r0, r1=r1, nodes=_tiles.rows_nodes(r0, r1, W, diag)))
+        unit_owner = _tiles.assign(units, self.world)
+        self.units, self.unit_owner = units, unit_owner
+        self.owner = [unit_owner[i] for i, u in enumerate(units) if u["tile"] == 0]      # (of a split block: its first tile's)
+        self.my_regions = [u["block"] for i, u in enumerate(units) if u["ntiles"] == 1 and unit_owner[i] == self.rank]
+        self.split_regions = sorted(set(u["block"] for u in units if u["ntiles"] > 1))
 
         # one process per GPU: this rank's device is LOCAL_RANK (blocks, their streams and the worker threads use it)
         device = None
@@ -135,7 +163,7 @@ class phyloHMRF(_BaseGraph):
         for r in self.my_regions:
             lv = self.len_vec[r]
             n, s1, s2, H, W = lv[0], lv[1], lv[2], lv[3], lv[4]
-            diag = bool(lv[8]) if len(lv) > 8 else (H == W and n == H * (H + 1) // 2)
+            diag = geo[r][2]
             b = factory(n, n_features, n_components)
             b.set_observations(X[s1:s2])
             grid_ok = (n == (H * (H + 1) // 2 if diag else H * W)) and num_neighbor in (4, 8)
@@ -159,6 +187,50 @@ class phyloHMRF(_BaseGraph):
                                   "which no energy parity with gco's swap is claimed" % r, RuntimeWarning)
                     self.general_graph_regions.append(r)
             self.blocks[r] = b
+
+        # row tiles of the split blocks: this rank's tiles, and per split block the group of ranks that hold its tiles
+        # (every rank creates every group, in block order: torch.distributed.new_group is collective)
+        self.tile_groups = {}
+        for r in self.split_regions:
+            mine = [(i, u) for i, u in enumerate(units) if u["block"] == r]
+            rows = [(u["r0"], u["r1"]) for _, u in mine]
+            owners = [unit_owner[i] for i, _ in mine]
+            comm = None
+            if self.world > 1:
+                dev_t = None
+                import torch.distributed as dist
+                if dist.get_backend() == "nccl":
+                    import torch
+                    dev_t = torch.device("cuda", torch.cuda.current_device())
+                comm = _tiles.GroupComm(owners, dev_t)
+            if self.rank not in owners:
+                continue
+            lv = self.len_vec[r]
+            s1, H, W, diag = lv[1], geo[r][0], geo[r][1], geo[r][2]
+            e_all = None if device_graph else np.asarray(edge_list_1[r])
+
+            def load(tl, s1=s1, e_all=e_all):
+                tl.b.set_observations(X[s1 + tl.node0:s1 + tl.node0 + tl.n])
+
+            grp = _tiles.make_group(r, (H, W, diag), rows, owners, self.rank, n_features, n_components, factory, load, comm,
+                                    num_neighbor, beta1, edges=e_all)
+            self.tile_groups[r] = grp
+        self.conductor = _tiles.Conductor(list(self.tile_groups.values()))
+
+    def _local_units(self):
+        """(block, slice of the samples its owned nodes are, slice of its own node ids that are owned) of every whole block
+        and every tile this rank holds"""
+        out = []
+        for r in self.my_regions:
+            s1, s2 = self.len_vec[r][1], self.len_vec[r][2]
+            out.append((self.blocks[r], slice(s1, s2), slice(0, s2 - s1), slice(s1, s2)))
+        for r, grp in self.tile_groups.items():
+            s1 = self.len_vec[r][1]
+            for t in sorted(grp.local):
+                tl = grp.local[t]
+                out.append((tl.b, slice(s1 + tl.node0 + tl.own_lo, s1 + tl.node0 + tl.own_hi), tl.owned_local_slice(),
+                            slice(s1 + tl.node0, s1 + tl.node0 + tl.n)))
+        return out
 
     # ---- properties the reference exposes --------------------------------------------------------
     def _get_covars(self):
@@ -197,7 +269,7 @@ class phyloHMRF(_BaseGraph):
         X = np.asarray(X)
         n_samples, n_features = X.shape
         seed = None if self.random_state is None else int(self.random_state)
-        my_blocks = [self.blocks[r] for r in self.my_regions]
+        my_blocks = [u[0] for u in self._local_units()]
         red = self.reducer if self.world > 1 else None
         if self.init_method in ("minibatch", "device"):
             from .kmeans import device_kmeans, device_moments, minibatch_centers
@@ -241,20 +313,18 @@ class phyloHMRF(_BaseGraph):
         self._log("return from initializing parameters...")
 
     def _upload_labels(self, labels):
-        for r in self.my_regions:
-            s1, s2 = self.len_vec[r][1], self.len_vec[r][2]
-            self.blocks[r].set_labels(np.asarray(labels[s1:s2]))
-            self.blocks[r].save_labels(SLOT_LOCAL)
+        for b, _, _, stored in self._local_units():          # (a tile takes its halo rows too)
+            b.set_labels(np.asarray(labels[stored]))
+            b.save_labels(SLOT_LOCAL)
 
     def _snapshot_labels(self, slot):
-        for r in self.my_regions:
-            self.blocks[r].save_labels(slot)
+        for b, _, _, _ in self._local_units():
+            b.save_labels(slot)
 
     def _gather_labels(self, slot):
         out = np.zeros(self.n_samples)
-        for r in self.my_regions:
-            s1, s2 = self.len_vec[r][1], self.len_vec[r][2]
-            out[s1:s2] = self.blocks[r].get_saved_labels(slot)
+        for b, own, own_local, _ in self._local_units():
+            out[own] = b.get_saved_labels(slot)[own_local]
         if self.world > 1:
             out = self.reducer.allreduce(out)
         return out
@@ -273,11 +343,33 @@ class phyloHMRF(_BaseGraph):
     # ---- b2 --------------------------------------------------------------------------------------
     def predict(self, X, region_id):
         """labels and emission log-likelihoods of one region, warm-started from labels_local (:470-484)."""
+        if region_id in self.split_regions:
+            return self._predict_tiled(region_id)
         b = self.blocks[region_id]
         b.restore_labels(SLOT_LOCAL)
         b.emission(self.means_, self._covars_)
         b.solve_fast(self.beta, **self.solver_opts)
         return b.get_labels(), b.get_logprob()
+
+    def _predict_tiled(self, region_id):
+        """predict() of a region that is cut into row tiles: a collective of the ranks that hold its tiles; every one of them
+        returns the whole region's labels and log-likelihoods (the other ranks' rows arrive by all-reduce)"""
+        from .tiles import Conductor
+        n = self.len_vec[region_id][0]
+        labels, logprob = np.zeros(n), np.zeros((n, self.n_components))
+        grp = self.tile_groups.get(region_id)
+        if grp is not None:
+            def prepare(tl):
+                tl.b.restore_labels(SLOT_LOCAL)
+                tl.b.emission(self.means_, self._covars_)
+            Conductor([grp]).solve(self.beta, self.solver_opts, prepare=prepare)
+            for tl in grp.local.values():
+                labels[tl.owned_global_slice()] = tl.b.get_labels()[tl.owned_local_slice()]
+                logprob[tl.owned_global_slice()] = tl.b.get_logprob()[tl.owned_local_slice()]
+        if self.world > 1:
+            labels = self.reducer.allreduce(labels)
+            logprob = self.reducer.allreduce(logprob.ravel()).reshape(n, self.n_components)
+        return labels.astype(np.int32), logprob
 
     def _estimate_state_graphcuts_gco(self, X, init_labels1, edge_idList_undirected, edge_weightList_undirected):
         """Drop-in for the pygco call (:486-507) on an arbitrary graph: GPU label solver, general-graph moves."""
@@ -303,6 +395,24 @@ class phyloHMRF(_BaseGraph):
         b.solve_fast(self.beta, **self.solver_opts)
         stats, costs, _ = b.posterior_stats(self.beta, self.estimate_type)
         return stats, costs
+
+    def _estep_tiles(self):
+        """The E-step of every row tile this rank holds (lockstep rounds with the ranks that hold the other tiles of the same
+        blocks; runs on the calling thread while the whole blocks run on the runner's threads).
+        -> [(stats, cost numerators, owned nodes)] per local tile"""
+        out = []
+
+        def prepare(tl):
+            tl.b.restore_labels(SLOT_LOCAL)                  # init_labels = labels_local[id1:id2]  (:479)
+            tl.b.emission(self.means_, self._covars_)
+
+        def finish(tl):
+            stats, costs, _ = tl.b.posterior_stats(self.beta, self.estimate_type)
+            out.append((stats, costs, tl.own_hi - tl.own_lo))
+
+        if self.conductor.groups:
+            self.conductor.solve(self.beta, self.solver_opts, prepare=prepare, finish=finish)
+        return out
 
     def _predict_posteriors(self, X, len_vec, region_id, m_queue=None):
         """(region_id, stats, labels, pairwise_cost, pairwise_cost_normalize, unary_cost, cost1)  (:297-322)."""
@@ -331,22 +441,24 @@ class phyloHMRF(_BaseGraph):
         return obj.value(np.asarray(params, dtype=np.float64))
 
     def _do_mstep(self, stats):
+        """The K states are DEALT to the ranks (state c to rank c mod world; the reference fits them one after the other in
+        one process, phylo_hmrf.py:1500-1528): every state draws its restarts from a generator of its own, seeded from the
+        fit's generator and the state's index, so what a state's fit returns does not depend on who runs it; one all-reduce
+        (each state's slot is written by exactly one rank, the others add zeros) leaves the full result on every rank."""
         self.stats = {k: np.array(v, copy=True) for k, v in stats.items() if k in ("post", "obs", "obs*obs.T")}
-        if self.world > 1 and self.rank != 0:
-            packed = np.zeros(self.n_components * (self.n_params + self.n_features + self.n_features ** 2))
-        else:
-            params, means, covars, lik = _mstep.do_mstep(
-                self.tree, self.stats, self.params_vec1, self.init_ou_params, self.n_samples, self.lambda_0,
-                self.initial_mode, self.initial_w1, self.initial_w1a, self.initial_w2, self.rng, self.min_covar,
-                workers=self.mstep_workers)
-            self.lik = lik[-1]
-            packed = np.concatenate([params.ravel(), means.ravel(), covars.ravel()])
-        if self.world > 1:      # rank 0 draws the random restarts (:1372-1380); everyone receives its result
-            packed = self.reducer.broadcast(packed, src=0)
         K, P, S = self.n_components, self.n_params, self.n_features
+        mine = [c for c in range(K) if c % self.world == self.rank] if self.world > 1 else None
+        params, means, covars, lik = _mstep.do_mstep(
+            self.tree, self.stats, self.params_vec1, self.init_ou_params, self.n_samples, self.lambda_0,
+            self.initial_mode, self.initial_w1, self.initial_w1a, self.initial_w2, self.rng, self.min_covar,
+            workers=self.mstep_workers, states=mine)
+        packed = np.concatenate([params.ravel(), means.ravel(), covars.ravel(), lik.ravel()])
+        if self.world > 1:
+            packed = self.reducer.allreduce(packed)
         self.params_vec1 = packed[:K * P].reshape(K, P).copy()
         self.means_ = packed[K * P:K * P + K * S].reshape(K, S).copy()
-        self._covars_ = packed[K * P + K * S:].reshape(K, S, S).copy()
+        self._covars_ = packed[K * P + K * S:K * P + K * S + K * S * S].reshape(K, S, S).copy()
+        self.lik = packed[-1]
 
     def close(self):
         # (the M-step's worker pool is process-wide and forked once, before HIP is up: a second fit in the same process
@@ -355,3 +467,7 @@ class phyloHMRF(_BaseGraph):
         for b in self.blocks.values():
             b.close()
         self.blocks = {}
+        for grp in self.tile_groups.values():
+            for tl in grp.local.values():
+                tl.b.close()
+        self.tile_groups = {}

@@ -464,38 +464,57 @@ def close_pool():
         _POOL = None
 
 
+def native_available():
+    """the M-step's native path (all states in one call of libphmrf_host.so on host threads) can be used in this process"""
+    try:
+        return bool(NATIVE_MSTEP[0] and NATIVE_LOOP[0] and slsqp_entry() is not None and host_lib() is not None)
+    except Exception:
+        return False
+
+
 def do_mstep(tree, stats, params_cur, init_ou_params, n_samples, lambda_0, initial_mode, w1, w1a, w2, rng,
-             min_covar=1e-3, workers=None, retries=3):
-    """`_do_mstep` (phylo_hmrf.py:1500-1528) for all K states.
+             min_covar=1e-3, workers=None, retries=3, states=None, base=None):
+    """`_do_mstep` (phylo_hmrf.py:1500-1528) for all K states, or for the states listed in `states` (the others' rows of
+    the result stay zero: with several ranks every rank fits its share and an all-reduce puts the rows together).
+    The reference draws the random parts of all states' start points from one stream in state order (:1371-1380).  Here
+    every state has a generator of its own, seeded from ONE draw of `rng` per call and the state's index: the result of a
+    state does not depend on which other states are fitted in the same call, nor by whom -- as long as every rank calls
+    this once per M-step with generators in the same state, each advances by exactly that one draw.
     -> params[K,3B+2], means[K,S], covars[K,S,S] (= V + min_covar*I as at :1524), lik[K]."""
     K = params_cur.shape[0]
     P = tree.n_params
     N = tree.node_num
+    if base is None:        # (a caller that fits the states in several calls draws it once and hands it to each)
+        base = int(rng.integers(0, 2 ** 62))
+    todo = list(range(K)) if states is None else [int(c) for c in states]
     tasks = []
-    for c in range(K):
+    for c in todo:
+        srng = np.random.default_rng([base, c])
         guesses = []
         for _ in range(retries):
             if initial_mode == 1:                                                     # (:1371-1376)
-                r = 2.0 * rng.random(P) - 1.0
-                r[0:P - N] = rng.random(P - N)
+                r = 2.0 * srng.random(P) - 1.0
+                r[0:P - N] = srng.random(P - N)
                 r = w2 * r
             else:
-                r = w2 * rng.random(P)
+                r = w2 * srng.random(P)
             guesses.append(w1 * init_ou_params[c] + w1a * params_cur[c] + (1.0 - w1 - w1a) * r)   # (:1378-1380)
         tasks.append((tree, stats["post"][c], stats["obs"][c], stats["obs*obs.T"][c], n_samples, lambda_0, guesses,
                       init_ou_params[c]))
     if workers is None:
-        workers = min(K, os.cpu_count() or 1)
-    out = _mstep_native(tree, tasks, n_samples, lambda_0, workers) if (workers > 1 and NATIVE_MSTEP[0]) else None
+        workers = min(max(len(tasks), 1), os.cpu_count() or 1)
+    out = None
+    if tasks and NATIVE_MSTEP[0]:
+        out = _mstep_native(tree, tasks, n_samples, lambda_0, max(1, min(workers, len(tasks))))
     if out is None:
-        pool = _pool(workers)
+        pool = _pool(workers) if len(tasks) > 1 else None
         out = pool.map(_solve_state, tasks) if pool is not None else [_solve_state(t) for t in tasks]
     S = tree.n_features
     params = np.zeros((K, P))
     means = np.zeros((K, S))
     covars = np.zeros((K, S, S))
     lik = np.zeros(K)
-    for c, (p, l, mu, V) in enumerate(out):
+    for c, (p, l, mu, V) in zip(todo, out):
         params[c], lik[c], means[c] = p, l, mu
         covars[c] = V + min_covar * np.eye(S)                                         # (:1524)
     return params, means, covars, lik
