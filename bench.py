@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--no-fit", action="store_true",
                     help="skip the whole-fit measurement after the timed region (the `fit` object of the JSON line)")
+    ap.add_argument("--warm-start", default="best", choices=["best", "local"],
+                    help="start of an E-step's labelling: local = labels_local as the reference (phylo_hmrf.py:479); best = "
+                         "labels_local or the previous E-step's labels, whichever has the lower energy under the new parameters")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
@@ -279,8 +282,11 @@ def main():
     def estep_block(i):
         b = blocks[i]
         tb0 = time.time()
-        b.restore_labels(SLOT_LOCAL)                           # init_labels = labels_local (phylo_hmrf.py:479)
         b.emission(state["means"], state["covars"])
+        if a.warm_start == "best":
+            b.warm_start(a.beta, SLOT_LOCAL)                   # labels_local or the previous E-step's labels: the lower energy
+        else:
+            b.restore_labels(SLOT_LOCAL)                       # init_labels = labels_local (phylo_hmrf.py:479)
         b.solve_fast(a.beta, **solver)
         b.posterior_stats_dev(a.beta, 3, stats_dev[i].data_ptr())
         b.sync()
@@ -288,7 +294,8 @@ def main():
             block_trace.append((i, b.n, tb0, time.time()))
 
     def tile_prepare(tl):
-        tl.b.restore_labels(SLOT_LOCAL)
+        if a.warm_start != "best":
+            tl.b.restore_labels(SLOT_LOCAL)
         tl.b.emission(state["means"], state["covars"])
 
     def tile_finish(tl):
@@ -305,7 +312,8 @@ def main():
         else:
             pending = runner.start(estep_block, order)
         if conductor.groups:
-            conductor.solve(a.beta, solver, prepare=tile_prepare, finish=tile_finish)
+            conductor.solve(a.beta, solver, prepare=tile_prepare, finish=tile_finish,
+                            warm_slot=SLOT_LOCAL if a.warm_start == "best" else None)
             for tl in local_tiles:
                 tl.b.sync()
         if pending is not None:
@@ -570,7 +578,7 @@ def main():
                        "S": S, "K": K, "num_neighbor": nn, "beta": a.beta, "beta1": a.beta1,
                        "step": "full EM iteration: GPU E-step of every block + stats reduction + host M-step (SLSQP; the K states "
                                "dealt to the ranks, %d of them on %d host threads here)" % (len(my_states), workers),
-                       "mrf_solver": solver},
+                       "mrf_solver": dict(solver, warm_start=a.warm_start)},
             "estep_ms": float(np.mean(t_e) * 1e3), "mstep_ms": float(np.mean(t_m) * 1e3),
             "cold_first_iteration_ms": cold_first_ms,
             "fit": fit,

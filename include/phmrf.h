@@ -114,6 +114,14 @@ PHMRF_API int phmrf_block_save_labels(phmrf_block_t b, int slot);
 PHMRF_API int phmrf_block_restore_labels(phmrf_block_t b, int slot);
 PHMRF_API int phmrf_block_get_saved_labels(phmrf_block_t b, int slot, int32_t* labels);
 
+/* The warm start of a labelling under new parameters.  The reference starts from labels_local, the labels of the EM
+ * iteration with the lowest cost so far (phylo_hmrf.py:479, base.py:416-420), however old; the block's current labels are
+ * the previous E-step's result.  Both are scored under the resident logprob (phmrf_emission first) and, with choose != 0,
+ * the one with the lower energy becomes the current labelling: the solve then starts at or below the reference's start.
+ * choose == 0: only the two energies (*e_current, *e_saved; the row tiles of a split block decide on their sums). */
+PHMRF_API int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, double* e_current, double* e_saved,
+                                     int* took_saved);
+
 /* ---- b1: emission ---------------------------------------------------------------------------- */
 /* logprob[i,k] = log N(x_i; means[k], covars[k]) for all nodes of the block, left resident in HBM.
  * means float64 [K,S], covars float64 [K,S,S].  Cholesky (with sklearn's +1e-7*I retry) and

@@ -156,7 +156,8 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
 
     from phylo_hmrf_amd import mstep
     from phylo_hmrf_amd.tree import load_tree_files
-    mstep._pool(min(n_components1, os.cpu_count() or 1))     # fork the M-step workers before the GPU is touched
+    if not mstep.native_available():      # (only the Python fall-back of the M-step uses worker processes: forked before the GPU is touched)
+        mstep._pool(min(n_components1, os.cpu_count() or 1))
 
     start = time.time()
     if synthetic > 0:

@@ -67,6 +67,7 @@ SIGNATURES = {
     "phmrf_block_save_labels": [_vp, _i],
     "phmrf_block_restore_labels": [_vp, _i],
     "phmrf_block_get_saved_labels": [_vp, _i, _ip],
+    "phmrf_block_warm_start": [_vp, _d, _i, _i, _dp, _dp, ctypes.POINTER(_i)],
     "phmrf_emission": [_vp, _dp, _dp],
     "phmrf_block_get_logprob": [_vp, _dp],
     "phmrf_block_set_logprob": [_vp, _dp],

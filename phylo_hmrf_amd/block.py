@@ -85,6 +85,14 @@ class Block(object):
     def restore_labels(self, slot):
         check(self._L.phmrf_block_restore_labels(self._h, slot))
 
+    def warm_start(self, beta, slot, choose=True):
+        """current labels (the previous E-step's) or the snapshot in `slot` (labels_local), whichever has the lower energy
+        under the resident logprob -> (e_current, e_saved, took_saved); choose=False: only the energies"""
+        ec, es, took = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int(0)
+        check(self._L.phmrf_block_warm_start(self._h, float(beta), int(slot), int(bool(choose)), ctypes.byref(ec),
+                                             ctypes.byref(es), ctypes.byref(took)))
+        return ec.value, es.value, bool(took.value)
+
     def get_saved_labels(self, slot):
         out = np.empty(self.n, dtype=np.int32)
         check(self._L.phmrf_block_get_saved_labels(self._h, slot, ptr_i32(out)))

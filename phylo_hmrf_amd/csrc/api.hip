@@ -915,6 +915,55 @@ int phmrf_mrf_energy(phmrf_block_t b, double beta, double* e_total, double* e_un
   return PHMRF_OK;
 }
 
+// The warm start of an E-step.  The reference starts every labelling from labels_local, the labels of the EM iteration with
+// the lowest cost so far (phylo_hmrf.py:479, base.py:416-420) -- which can be many iterations old: the start is then far
+// from any minimum of the energy under the current parameters and the solve pays for a cold start.  The block's CURRENT
+// labels are the previous E-step's result; both candidates are scored under the logprob that is resident now and the lower
+// energy wins.  choose = 0: only score (the tiles of a split block decide on their sums).
+int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, double* e_current, double* e_saved, int* took_saved) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(slot >= 0 && slot < 4 && b->saved[slot], PHMRF_ERR_STATE, "label slot is empty");
+  if (took_saved) *took_saved = 1;
+  if (!b->has_labels) {                                      // nothing to compare with
+    if (choose) PHMRF_TRY(phmrf_block_restore_labels(b, slot));
+    if (e_current) *e_current = std::numeric_limits<double>::infinity();
+    if (e_saved) *e_saved = 0.0;
+    return PHMRF_OK;
+  }
+  double ec[2] = {0, 0}, es[2] = {0, 0};
+  for (int which = 0; which < 2; ++which) {
+    PHMRF_TRY(zero_accum(b, 4, 2));
+    if (which) std::swap(b->labels, b->saved[slot]);          // (score the snapshot in place)
+    tic(b);
+    const int st = launch_energy(b, (float)beta);
+    toc(b, KC_ENERGY, 1);
+    if (which) std::swap(b->labels, b->saved[slot]);
+    PHMRF_TRY(st);
+    PHMRF_HIP(hipMemcpyAsync(b->accum_host + (which ? 6 : 4), b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  }
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  for (int which = 0; which < 2; ++which) {
+    double* dst = which ? es : ec;
+    const double* src = b->accum_host + (which ? 6 : 4);
+    if (b->deterministic) {
+      long long q[2];
+      std::memcpy(q, src, sizeof(q));
+      dst[0] = (double)q[0] / 1048576.0;
+      dst[1] = (double)q[1] / 1048576.0;
+    } else {
+      dst[0] = src[0];
+      dst[1] = src[1];
+    }
+  }
+  const double cur = ec[0] + beta * ec[1], sav = es[0] + beta * es[1];
+  if (e_current) *e_current = cur;
+  if (e_saved) *e_saved = sav;
+  const bool take_saved = !(cur < sav);
+  if (took_saved) *took_saved = take_saved ? 1 : 0;
+  if (choose && take_saved) PHMRF_TRY(phmrf_block_restore_labels(b, slot));
+  return PHMRF_OK;
+}
+
 int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
   PHMRF_TRY(zero_counter(b));

@@ -33,7 +33,7 @@ class phyloHMRF(_BaseGraph):
                  random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
                  learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
                  solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=14,
-                 init_method="minibatch", split_above=1.0, tile_parts=None):
+                 init_method="minibatch", split_above=1.0, tile_parts=None, warm_start="best"):
         _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
                             startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
                             random_state=random_state, n_iter=n_iter, tol=tol, params=params, verbose=verbose,
@@ -93,6 +93,12 @@ class phyloHMRF(_BaseGraph):
                              "over all nodes on the device), 'sklearn' (the reference's initialisation verbatim, on the "
                              "host) or 'device' (Lloyd iterations on the device)")
         self.init_method = init_method
+        # the start of an E-step's labelling: "local" = labels_local, the labels of the iteration with the lowest cost so far,
+        # as the reference does (phylo_hmrf.py:479, base.py:416-420); "best" = that or the previous E-step's labels, whichever
+        # has the lower energy under the new parameters (Block.warm_start) -- labels_local can be dozens of iterations old
+        if warm_start not in ("best", "local"):
+            raise ValueError("warm_start must be 'best' or 'local'")
+        self.warm_start = warm_start
 
         # species tree tables (phylo_hmrf.py:103-143)
         self.tree = PhyloTree(edge_list)
@@ -390,8 +396,11 @@ class phyloHMRF(_BaseGraph):
 
     def _estep_region(self, region_id):
         b = self.blocks[region_id]
-        b.restore_labels(SLOT_LOCAL)                     # init_labels = labels_local[id1:id2]  (:479)
         b.emission(self.means_, self._covars_)
+        if self.warm_start == "best":
+            b.warm_start(self.beta, SLOT_LOCAL)          # labels_local or the previous result, whichever is lower
+        else:
+            b.restore_labels(SLOT_LOCAL)                 # init_labels = labels_local[id1:id2]  (:479)
         b.solve_fast(self.beta, **self.solver_opts)
         stats, costs, _ = b.posterior_stats(self.beta, self.estimate_type)
         return stats, costs
@@ -402,8 +411,11 @@ class phyloHMRF(_BaseGraph):
         -> [(stats, cost numerators, owned nodes)] per local tile"""
         out = []
 
+        best = self.warm_start == "best"
+
         def prepare(tl):
-            tl.b.restore_labels(SLOT_LOCAL)                  # init_labels = labels_local[id1:id2]  (:479)
+            if not best:
+                tl.b.restore_labels(SLOT_LOCAL)              # init_labels = labels_local[id1:id2]  (:479)
             tl.b.emission(self.means_, self._covars_)
 
         def finish(tl):
@@ -411,7 +423,8 @@ class phyloHMRF(_BaseGraph):
             out.append((stats, costs, tl.own_hi - tl.own_lo))
 
         if self.conductor.groups:
-            self.conductor.solve(self.beta, self.solver_opts, prepare=prepare, finish=finish)
+            self.conductor.solve(self.beta, self.solver_opts, prepare=prepare, finish=finish,
+                                 warm_slot=SLOT_LOCAL if best else None)
         return out
 
     def _predict_posteriors(self, X, len_vec, region_id, m_queue=None):

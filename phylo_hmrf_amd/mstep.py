@@ -563,6 +563,23 @@ def _init_state(args):
     return params1, obj.value(params1)
 
 
+def _init_states(tree, tasks, workers):
+    """the per-cluster fits of the initialisation: natively on host threads when libphmrf_host.so's SLSQP loop is available
+    (`_ou_lik_varied_single` is the M-step's objective with N_c = n = 1 and no ridge term, so phmrf_ou_mstep fits it: the
+    start points in turn, `_check_params`, the last guess as the fall-back) -- no worker processes, hence no fork after the
+    GPU runtime is up; otherwise in the fork pool / serially with scipy.optimize.minimize"""
+    if tasks and native_available():
+        nat = []
+        for tree_, Xc, guesses in tasks:
+            obj = OUObjectiveSingle.from_moments(tree_, Xc[0], Xc[1]) if isinstance(Xc, tuple) else OUObjectiveSingle(tree_, Xc)
+            nat.append((tree_, 1.0, obj.obs, obj.oo, 1.0, 0.0, list(guesses[:-1]), guesses[-1]))
+        out = _mstep_native(tree, nat, 1.0, 0.0, max(1, min(workers, len(nat))))
+        if out is not None:
+            return [(p, l) for p, l, _, _ in out]
+    pool = _pool(workers)
+    return pool.map(_init_state, tasks) if pool is not None else [_init_state(t) for t in tasks]
+
+
 def init_ou_params(tree, X, init_label, means, params_default, w2, rng, workers=None, max_per_cluster=200000):
     """`_init_ou_param` (phylo_hmrf.py:184-203): per k-means cluster, fit the OU parameters to that cluster."""
     K = params_default.shape[0]
@@ -579,8 +596,7 @@ def init_ou_params(tree, X, init_label, means, params_default, w2, rng, workers=
         idx.append(c)
     if workers is None:
         workers = min(max(len(tasks), 1), os.cpu_count() or 1)
-    pool = _pool(workers)
-    res = pool.map(_init_state, tasks) if pool is not None else [_init_state(t) for t in tasks]
+    res = _init_states(tree, tasks, workers)
     for c, (p, _) in zip(idx, res):
         out[c] = p
     return out
@@ -602,8 +618,7 @@ def init_ou_params_moments(tree, counts, sums, outer, means, params_default, w2,
         idx.append(c)
     if workers is None:
         workers = min(max(len(tasks), 1), os.cpu_count() or 1)
-    pool = _pool(workers)
-    res = pool.map(_init_state, tasks) if pool is not None else [_init_state(t) for t in tasks]
+    res = _init_states(tree, tasks, workers)
     for c, (p, _) in zip(idx, res):
         out[c] = p
     return out

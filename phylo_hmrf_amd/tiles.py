@@ -176,6 +176,22 @@ class TileGroup(object):
             halo_bot = self._rows(buf, t + 1)[0][:tl.bot_in] if (tl.bottom and (t + 1) not in self.missing) else None
             tl.b.tile_put_halo(halo_top, halo_bot)
 
+    def choose_start(self, beta, slot):
+        """Block.warm_start for the tiles of one block: the current labels (the previous E-step's) or the snapshot in `slot`
+        (labels_local), whichever has the lower energy summed over the tiles' owned rows -- one decision for all of them, so
+        the halo rows stay what the neighbours hold.  -> took the snapshot"""
+        e = np.zeros(2 * self.ntiles, dtype=np.float64)
+        for t in sorted(self.local):
+            e[2 * t], e[2 * t + 1], _ = self.local[t].b.warm_start(beta, slot, choose=False)
+        if self.comm is not None:
+            e = self.comm.allreduce_i64(e.view(np.int64)).view(np.float64)
+        e = e.reshape(self.ntiles, 2)
+        take_saved = not (float(e[:, 0].sum()) < float(e[:, 1].sum()))
+        if take_saved:
+            for t in sorted(self.local):
+                self.local[t].b.restore_labels(slot)
+        return take_saved
+
     def begin(self, beta, opts):
         self.rounds = 0
         self.status = 0
@@ -249,12 +265,15 @@ class Conductor(object):
     def __init__(self, groups):
         self.groups = sorted(groups, key=lambda g: g.block_id)
 
-    def solve(self, beta, opts, prepare=None, finish=None, want_result=False):
-        """prepare(tile) before the solve (restore labels, emission), finish(tile) after it (posteriors / statistics)"""
+    def solve(self, beta, opts, prepare=None, finish=None, want_result=False, warm_slot=None):
+        """prepare(tile) before the solve (restore labels, emission), finish(tile) after it (posteriors / statistics);
+        warm_slot: after prepare, every group starts from its current labels or from that snapshot, whichever is lower"""
         for g in self.groups:
             for t in sorted(g.local):
                 if prepare is not None:
                     prepare(g.local[t])
+            if warm_slot is not None:
+                g.choose_start(beta, warm_slot)
             g.begin(beta, opts)
         active = list(self.groups)
         while active:
@@ -280,7 +299,7 @@ class GroupComm(object):
 
     def __init__(self, ranks, device=None):
         import torch.distributed as dist
-        self.ranks = sorted(int(r) for r in ranks)
+        self.ranks = sorted(set(int(r) for r in ranks))
         self.group = dist.new_group(ranks=self.ranks) if len(self.ranks) > 1 else None       # (every rank must call this)
         self.device = device
         self._buf = None

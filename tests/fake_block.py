@@ -63,6 +63,14 @@ class FakeBlock(object):
     def get_saved_labels(self, slot):
         return self.slots[slot].astype(np.int32)
 
+    def warm_start(self, beta, slot, choose=True):
+        ec = R.mrf_energy(np.int64(self.labels), self.logprob, self.eid, self.w, beta)[0]
+        es = R.mrf_energy(np.int64(self.slots[slot]), self.logprob, self.eid, self.w, beta)[0]
+        took = not (ec < es)
+        if choose and took:
+            self.restore_labels(slot)
+        return ec, es, took
+
     def emission(self, means, covars):
         self.logprob = R.log_multivariate_normal_density_full(self.X, means, covars)
 

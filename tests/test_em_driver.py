@@ -30,7 +30,7 @@ def make_model(g, **kw):
                   edge_list_1=[g["edges0"], g["edges1"]], cons_param=1.0, beta=float(g["beta"]), beta1=float(g["beta1"]),
                   initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, learning_rate=0.001,
                   estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, block_factory=FakeBlock, quiet=True,
-                  random_state=0, **kw)
+                  random_state=0, warm_start="local", **kw)       # (the reference's start: labels_local, phylo_hmrf.py:479)
     sched = g["sched"]
     S = X.shape[1]
     state = {"it": 0}

@@ -27,7 +27,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] in ("strong", "weak") and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
-    assert d["config"]["nodes_per_rank"] == [300 * 301 // 2 + 200 * 260] and d["config"]["blocks_per_rank"] == [2]
+    assert d["config"]["nodes_per_rank"] == [300 * 301 // 2 + 200 * 260] and d["config"]["units_per_rank"] == [2]
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
@@ -59,10 +59,10 @@ def test_bench_rccl_path_single_rank():
     M-step result, barrier, max-over-ranks timing) with one rank; the line must match the plain single-GPU run's shape."""
     d = _run(["--no-cpu-baseline"], env={"PHMRF_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29519",
                                          "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["blocks_per_rank"] == [2]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["units_per_rank"] == [2]
     assert "cpu_baseline" not in d
 
 
 def test_bench_weak_scaling_mode_replicates_the_workload():
     d = _run(["--no-cpu-baseline", "--scaling", "weak"])
-    assert d["scaling"] == "weak" and d["config"]["blocks_per_rank"] == [2]
+    assert d["scaling"] == "weak" and d["config"]["units_per_rank"] == [2]

@@ -155,3 +155,60 @@ def test_tiled_warm_start_under_the_fit_tolerance():
     for tl in g.local.values():
         tl.b.close()
     b.close()
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_tiled_cold_start_at_config_2_size_stays_below_gco(parts):
+    """BASELINE config 2 in full (2000-bin diagonal block, 2,001,000 nodes, K = 10) from uniformly random labels, cut into
+    2 and 3 row tiles: strictly at or below the reference's result (gco swap through pygco's quantisation, recorded in
+    tests/golden/live_gco_energies.json from the reference's own code), within 1e-5 of the unsplit solve, and the whole
+    block's energy (device f64 evaluation of the gathered labels) monotone from round to round."""
+    import json
+    import os
+    from phylo_hmrf_amd import Block, tiles
+    seed, N, K = 13, 2000, 10
+    rec = [c for c in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "live_gco_energies.json")))["cases"]
+           if c["seed"] == seed and c["N"] == N][0]
+    blk = synth.make_block(seed, N, N, 4, K, True)
+    X = blk["X"]
+    n = X.shape[0]
+    w, eid = R.edge_weights_from_distance(blk["edges"], 0.5)
+    lp = R.log_multivariate_normal_density_full(X, blk["means"], blk["covars"])
+    init = np.random.default_rng(seed + 7).integers(0, K, n)
+    np.testing.assert_allclose(R.mrf_energy(init, lp, eid, w, 1.0)[0], rec["e_init"], rtol=1e-12)
+    whole = Block(n, 4, K)
+    whole.set_graph(eid, w)
+    whole.set_grid(N, N, True, 8)
+    whole.set_logprob(lp)
+    whole.set_labels(init)
+    whole.solve_fast(1.0, energy_tol_ppb=1000)
+    e_whole = R.mrf_energy(whole.get_labels(), lp, eid, w, 1.0)[0]
+    rows = tiles.split_rows(N, N, True, parts)
+
+    def load(tl):
+        tl.b.set_observations(X[tl.global_slice()])
+
+    g = tiles.make_group(0, (N, N, True), rows, [0] * parts, 0, 4, K, Block, load, None, 8, 0.5, edges=blk["edges"])
+    for tl in g.local.values():
+        tl.b.set_logprob(lp[tl.global_slice()])
+        tl.b.set_labels(init[tl.global_slice()])
+    g.begin(1.0, dict(energy_tol_ppb=1000))
+    energies = []
+    while True:
+        g.launch()
+        st = g.finish_round()
+        whole.set_labels(_gather(g, n))
+        energies.append(whole.energy(1.0)[0])
+        if st != 0:
+            break
+    g.end()
+    for a, c in zip(energies, energies[1:]):
+        assert c <= a + 1e-9 * abs(a), energies
+    e_tiled = R.mrf_energy(_gather(g, n), lp, eid, w, 1.0)[0]
+    print("2,001,000 nodes, %d tiles: gco via pygco %.2f  unsplit %.2f  tiled %.2f (%+.1e) in %d rounds"
+          % (parts, rec["e_pygco"], e_whole, e_tiled, (e_tiled - e_whole) / abs(e_whole), len(energies)))
+    assert e_tiled <= rec["e_pygco"], (e_tiled, rec)                 # strictly: <= what the reference computes
+    assert abs(e_tiled - e_whole) <= 1e-5 * abs(e_whole), (e_tiled, e_whole)
+    for tl in g.local.values():
+        tl.b.close()
+    whole.close()

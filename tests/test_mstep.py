@@ -227,3 +227,32 @@ def test_native_mstep_flags_an_ill_conditioned_state_and_leaves_the_others_alone
                             0.01, 0.0, guesses.ctypes.data_as(dp), 1, cur.ctypes.data_as(dp), mstep.LOWER, mstep.UPPER, 1e-6,
                             200, 2, params.ctypes.data_as(dp), lik.ctypes.data_as(dp), mean.ctypes.data_as(dp),
                             V.ctypes.data_as(dp), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 1
+
+
+def test_states_dealt_to_ranks_give_the_single_rank_result_bit_for_bit():
+    """do_mstep(states=...): every state draws its restarts from a generator of its own (seeded from one draw of the fit's
+    generator and the state's index), so fitting the states in two shares -- as two ranks do, each adding zeros for the
+    other's rows -- gives exactly the arrays of fitting them all in one call (phyloHMRF._do_mstep, bench.py mstep_all)."""
+    from phylo_hmrf_amd import mstep
+    from phylo_hmrf_amd import synthetic
+    from phylo_hmrf_amd.tree import PhyloTree
+    tree = PhyloTree(synthetic.tree_for(4))
+    K, S = 6, 4
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((K, S, S))
+    post = rng.uniform(500, 3000, K)
+    mu = rng.uniform(0.5, 3.0, (K, S))
+    cov = np.einsum("kij,klj->kil", A, A) * 0.2 + 0.05 * np.eye(S)
+    stats = {"post": post, "obs": post[:, None] * mu,
+             "obs*obs.T": post[:, None, None] * (cov + mu[:, :, None] * mu[:, None, :])}
+    cur = rng.uniform(0.1, 1.5, (K, tree.n_params))
+    init = rng.uniform(0.1, 1.5, (K, tree.n_params))
+    args = (tree, stats, cur, init, float(post.sum()), 1.0, 0, 0.3, 0.1, 1.0)
+    full = mstep.do_mstep(*args, np.random.default_rng(9), workers=3)
+    g0, g1 = np.random.default_rng(9), np.random.default_rng(9)
+    a = mstep.do_mstep(*args, g0, workers=2, states=[0, 2, 4])
+    b = mstep.do_mstep(*args, g1, workers=1, states=[1, 3, 5])
+    for x, y, z in zip(full, a, b):
+        assert np.array_equal(x, y + z)
+    # each call advanced its generator by the one draw: the next M-step is in step on every rank
+    assert g0.integers(0, 2 ** 62) == g1.integers(0, 2 ** 62)
