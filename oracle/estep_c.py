@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libphmrf_oracle.so")
+_PATH = os.environ.get("PHMRF_ORACLE_LIB") or os.path.join(_HERE, "libphmrf_oracle.so")     # (env: the sanitizer build)
 _lib = None
 
 

@@ -42,7 +42,8 @@ def host_lib():
     """libphmrf_host.so (built by csrc/Makefile / __graft_entry__.build()); raises if it is missing."""
     global _HOST_LIB
     if _HOST_LIB is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libphmrf_host.so")
+        # PHMRF_HOST_LIB: a development build, e.g. the AddressSanitizer one (make -C phylo_hmrf_amd/csrc asan)
+        path = os.environ.get("PHMRF_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libphmrf_host.so")
         if not os.path.exists(path):
             raise RuntimeError("libphmrf_host.so is missing: run `make -C phylo_hmrf_amd/csrc` (or __graft_entry__.build())")
         L = ctypes.CDLL(path)
