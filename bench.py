@@ -284,7 +284,7 @@ def main():
         tb0 = time.time()
         b.emission(state["means"], state["covars"])
         if a.warm_start == "best":
-            b.warm_start(a.beta, SLOT_LOCAL)                   # labels_local or the previous E-step's labels: the lower energy
+            b.warm_start(a.beta, SLOT_LOCAL, report=False)     # labels_local or the previous E-step's labels: the lower energy
         else:
             b.restore_labels(SLOT_LOCAL)                       # init_labels = labels_local (phylo_hmrf.py:479)
         b.solve_fast(a.beta, **solver)

@@ -118,7 +118,10 @@ PHMRF_API int phmrf_block_get_saved_labels(phmrf_block_t b, int slot, int32_t* l
  * iteration with the lowest cost so far (phylo_hmrf.py:479, base.py:416-420), however old; the block's current labels are
  * the previous E-step's result.  Both are scored under the resident logprob (phmrf_emission first) and, with choose != 0,
  * the one with the lower energy becomes the current labelling: the solve then starts at or below the reference's start.
- * choose == 0: only the two energies (*e_current, *e_saved; the row tiles of a split block decide on their sums). */
+ * choose == 0: only the two energies (*e_current, *e_saved; the row tiles of a split block decide on their sums).
+ * With all three output pointers NULL the evaluations and the choice (taken on the device) are only queued on the block's
+ * stream: no host synchronisation.  When the snapshot IS the current labelling (saved or restored since the last change)
+ * nothing is evaluated: *e_current = +inf, *e_saved = 0. */
 PHMRF_API int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, double* e_current, double* e_saved,
                                      int* took_saved);
 
@@ -159,10 +162,12 @@ typedef struct phmrf_solve_opts {
                           least 12.5 % of the labels in all (a far-off start); such a solve does not stop on the
                           tolerance before they have had a last say                                                */
   int energy_tol_ppb;  /* > 0: stop as soon as a round lowers the energy by less than this many parts per billion
-                          of |E| (no verification round).  Move types whose LAST RUNS were, taken together, worth at
-                          most a quarter of that are rested meanwhile (a type that did not run in a round keeps the
-                          count of its last run), so what a tolerance stop leaves undone in one round of the types
-                          that have run is bounded by 1.25 x the tolerance.  0: run to the exact fixed point       */
+                          of |E| (no verification round).  Meanwhile the move types whose LAST RUNS changed the fewest
+                          labels are rested (a type that did not run in a round keeps the count of its last run) as long
+                          as, at the round's average gain per changed label, all rested types together were worth at most
+                          a quarter of the tolerance -- a heuristic about labels, not a bound on the energy a stop
+                          leaves behind (what the stops do leave is measured against gco in the parity tests).
+                          0: run to the exact fixed point                                                          */
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {

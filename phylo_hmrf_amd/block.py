@@ -85,9 +85,13 @@ class Block(object):
     def restore_labels(self, slot):
         check(self._L.phmrf_block_restore_labels(self._h, slot))
 
-    def warm_start(self, beta, slot, choose=True):
+    def warm_start(self, beta, slot, choose=True, report=True):
         """current labels (the previous E-step's) or the snapshot in `slot` (labels_local), whichever has the lower energy
-        under the resident logprob -> (e_current, e_saved, took_saved); choose=False: only the energies"""
+        under the resident logprob -> (e_current, e_saved, took_saved); choose=False: only the energies.  report=False: the
+        two evaluations and the choice are queued on the block's stream and the call returns at once (-> None)"""
+        if not report:
+            check(self._L.phmrf_block_warm_start(self._h, float(beta), int(slot), int(bool(choose)), None, None, None))
+            return None
         ec, es, took = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int(0)
         check(self._L.phmrf_block_warm_start(self._h, float(beta), int(slot), int(bool(choose)), ctypes.byref(ec),
                                              ctypes.byref(es), ctypes.byref(took)))

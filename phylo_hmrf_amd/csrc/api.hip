@@ -639,6 +639,7 @@ int phmrf_block_set_labels(phmrf_block_t b, const int32_t* labels) {
   }
   PHMRF_TRY(upload(b->labels, tmp.data(), (size_t)b->n, b->stream));
   b->has_labels = true;
+  b->labels_are_slot = -1;
   return PHMRF_OK;
 }
 
@@ -659,6 +660,7 @@ int phmrf_block_save_labels(phmrf_block_t b, int slot) {
   PHMRF_CHECK(slot >= 0 && slot < 4, PHMRF_ERR_INVALID, "slot must be in [0,4)");
   if (!b->saved[slot]) PHMRF_TRY(dev_alloc(&b->saved[slot], (size_t)b->n));
   PHMRF_HIP(hipMemcpyAsync(b->saved[slot], b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
+  b->labels_are_slot = slot;
   return PHMRF_OK;
 }
 
@@ -667,6 +669,7 @@ int phmrf_block_restore_labels(phmrf_block_t b, int slot) {
   PHMRF_CHECK(slot >= 0 && slot < 4 && b->saved[slot], PHMRF_ERR_STATE, "label slot is empty");
   PHMRF_HIP(hipMemcpyAsync(b->labels, b->saved[slot], (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
   b->has_labels = true;
+  b->labels_are_slot = slot;
   return PHMRF_OK;
 }
 
@@ -924,24 +927,31 @@ int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, d
   PHMRF_TRY(check_solvable(b));
   PHMRF_CHECK(slot >= 0 && slot < 4 && b->saved[slot], PHMRF_ERR_STATE, "label slot is empty");
   if (took_saved) *took_saved = 1;
-  if (!b->has_labels) {                                      // nothing to compare with
-    if (choose) PHMRF_TRY(phmrf_block_restore_labels(b, slot));
+  const bool report = e_current || e_saved || took_saved;
+  if (!b->has_labels || b->labels_are_slot == slot) {        // nothing to compare with / the snapshot IS the current labelling
+    if (choose && !b->has_labels) PHMRF_TRY(phmrf_block_restore_labels(b, slot));
     if (e_current) *e_current = std::numeric_limits<double>::infinity();
     if (e_saved) *e_saved = 0.0;
     return PHMRF_OK;
   }
-  double ec[2] = {0, 0}, es[2] = {0, 0};
-  for (int which = 0; which < 2; ++which) {
-    PHMRF_TRY(zero_accum(b, 4, 2));
-    if (which) std::swap(b->labels, b->saved[slot]);          // (score the snapshot in place)
-    tic(b);
-    const int st = launch_energy(b, (float)beta);
-    toc(b, KC_ENERGY, 1);
-    if (which) std::swap(b->labels, b->saved[slot]);
-    PHMRF_TRY(st);
-    PHMRF_HIP(hipMemcpyAsync(b->accum_host + (which ? 6 : 4), b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  }
+  // the two evaluations and the choice are queued on the block's stream; the host waits only if it wants the numbers
+  double* const extra = b->accum + (ACCUM_DOUBLES - 4);     // (behind every statistic the accum area can hold)
+  PHMRF_TRY(zero_accum(b, 4, 2));
+  PHMRF_TRY(zero_accum(b, ACCUM_DOUBLES - 4, 2));
+  tic(b);
+  PHMRF_TRY(launch_energy(b, (float)beta));
+  std::swap(b->labels, b->saved[slot]);                     // (score the snapshot in place)
+  const int st = launch_energy(b, (float)beta, extra);
+  std::swap(b->labels, b->saved[slot]);
+  PHMRF_TRY(st);
+  if (choose) PHMRF_TRY(launch_choose_labels(b, b->saved[slot], b->accum + 4, extra, beta));
+  toc(b, KC_ENERGY, choose ? 3 : 2);
+  if (choose) b->labels_are_slot = -1;
+  if (!report) return PHMRF_OK;
+  PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  PHMRF_HIP(hipMemcpyAsync(b->accum_host + 6, extra, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   PHMRF_HIP(hipStreamSynchronize(b->stream));
+  double ec[2], es[2];
   for (int which = 0; which < 2; ++which) {
     double* dst = which ? es : ec;
     const double* src = b->accum_host + (which ? 6 : 4);
@@ -958,14 +968,13 @@ int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, d
   const double cur = ec[0] + beta * ec[1], sav = es[0] + beta * es[1];
   if (e_current) *e_current = cur;
   if (e_saved) *e_saved = sav;
-  const bool take_saved = !(cur < sav);
-  if (took_saved) *took_saved = take_saved ? 1 : 0;
-  if (choose && take_saved) PHMRF_TRY(phmrf_block_restore_labels(b, slot));
+  if (took_saved) *took_saved = !(cur < sav) ? 1 : 0;
   return PHMRF_OK;
 }
 
 int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
+  b->labels_are_slot = -1;
   PHMRF_TRY(zero_counter(b));
   PHMRF_TRY(icm_sweep_nocount(b, (float)beta));
   int64_t ch = 0;
@@ -976,6 +985,7 @@ int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed) {
 
 int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
+  b->labels_are_slot = -1;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "chain moves need phmrf_block_set_grid");
   PHMRF_CHECK(family >= 0 && family < (int)b->families.size(), PHMRF_ERR_INVALID, "no such chain family");
   PHMRF_TRY(zero_counter(b));
@@ -989,6 +999,7 @@ int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* cha
 
 int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
+  b->labels_are_slot = -1;
   PHMRF_TRY(zero_counter(b));
   tic(b);
   PHMRF_TRY(launch_component_pass(b, (float)beta));
@@ -1021,6 +1032,7 @@ static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift
 
 int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, int alpha, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
+  b->labels_are_slot = -1;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "strip moves need phmrf_block_set_grid");
   PHMRF_CHECK(b->num_neighbor == 8 || b->num_neighbor == 4, PHMRF_ERR_STATE, "bad grid");
   PHMRF_CHECK(orient == 0 || orient == 1, PHMRF_ERR_INVALID, "orient must be 0 or 1");
@@ -1039,6 +1051,7 @@ int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, 
 int phmrf_mrf_strip_multi_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, uint64_t label_mask,
                                int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
+  b->labels_are_slot = -1;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "strip moves need phmrf_block_set_grid");
   PHMRF_CHECK(b->num_neighbor == 8 || b->num_neighbor == 4, PHMRF_ERR_STATE, "bad grid");
   PHMRF_CHECK(orient == 0 || orient == 1, PHMRF_ERR_INVALID, "orient must be 0 or 1");
@@ -1145,6 +1158,7 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
 int phmrf_mrf_coarse_pass(phmrf_block_t b, double beta, int scale, int offset, int alpha, int shift_r, int shift_c,
                           int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
+  b->labels_are_slot = -1;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "coarse moves need phmrf_block_set_grid");
   PHMRF_CHECK(scale == 2 || scale == 4 || scale == 8, PHMRF_ERR_INVALID, "scale must be 2, 4 or 8");
   PHMRF_CHECK(offset >= 0 && offset < scale, PHMRF_ERR_INVALID, "offset must be in [0, scale)");
@@ -1219,6 +1233,7 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
   s->beta = beta;
   s->bf = (float)beta;
   s->sched_n = b->sched_n > 0 ? b->sched_n : b->n;
+  b->labels_are_slot = -1;                        // (whatever the solve does to the labels)
   struct Abort {                                  // a failure below leaves no half-begun solve behind
     phmrf_block* blk;
     bool armed = true;
@@ -1585,8 +1600,8 @@ int solve_round_decide(phmrf_block_t b, const unsigned long long* counters, cons
   s->verifying = false;
   // A type stays active while it changes labels.  With an energy tolerance the types whose last run changed the
   // fewest labels are rested until the verification round, as long as ALL rested types together were worth at most a
-  // quarter of the stopping tolerance at this round's average gain per changed label (so the moves a tolerance stop
-  // leaves undone in one round of the types that have run are bounded by 1.25 x the tolerance, however many types there are).
+  // quarter of the stopping tolerance at this round's average gain per changed label (a heuristic about label counts, not
+  // a bound on the energy a tolerance stop leaves behind: that is what the parity tests against gco measure).
   int n_act = 0;
   for (int sl : slots) active[sl] = 1;
   if (o.energy_tol_ppb > 0 && ch > 0 && gain > 0) {
@@ -1799,6 +1814,7 @@ int phmrf_block_tile_put_halo(phmrf_block_t b, const uint8_t* top_in, const uint
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   PHMRF_CHECK(b->tile_top || b->tile_bot, PHMRF_ERR_STATE, "the block is not a tile (phmrf_block_set_tile)");
   if (b->tick) ++b->tick;
+  b->labels_are_slot = -1;
   int64_t off = 0;
   if (top_in && b->tile_top) {
     const int64_t c = row_first(b, 1);
@@ -1879,7 +1895,10 @@ int phmrf_kmeans_step(phmrf_block_t b, const double* centers, int write_labels, 
   PHMRF_HIP(hipMemcpyAsync(b->accum_host + 8, b->accum + 8, NP * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   PHMRF_HIP(hipStreamSynchronize(b->stream));
   std::memcpy(out, b->accum_host + 8, NP * sizeof(double));
-  if (write_labels) b->has_labels = true;
+  if (write_labels) {
+    b->has_labels = true;
+    b->labels_are_slot = -1;
+  }
   return PHMRF_OK;
 }
 
@@ -1900,7 +1919,10 @@ int phmrf_kmeans_moments(phmrf_block_t b, const double* centers, int write_label
   PHMRF_HIP(hipMemcpyAsync(b->accum_host + 8, b->accum + 8, NP * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   PHMRF_HIP(hipStreamSynchronize(b->stream));
   std::memcpy(out, b->accum_host + 8, NP * sizeof(double));
-  if (write_labels) b->has_labels = true;
+  if (write_labels) {
+    b->has_labels = true;
+    b->labels_are_slot = -1;
+  }
   return PHMRF_OK;
 }
 

@@ -76,6 +76,7 @@ struct phmrf_block {
   int eval_tick = -1;                       //   ... and the launch tick then (-1: no evaluation in this solve yet)
   float* sgain = nullptr;                   // device [n]: cost of switching a node alone to its fusion proposal (launch_propose)
   uint8_t* saved[4] = {nullptr, nullptr, nullptr, nullptr};
+  int labels_are_slot = -1;                 // the current labels equal this snapshot (set by save / restore; -1 after anything that may write labels)
   bool has_X = false, has_logprob = false, has_labels = false, has_graph = false, has_grid = false;
 
   int D = 0;
@@ -218,7 +219,8 @@ inline int padded_k(int K) { return (K % 2 == 0) ? K + 1 : K; }  // odd LDS row 
 int launch_emission(const float* X, int64_t n, int S, int K, const float* packed, float* logprob, float* uT, hipStream_t st);
 int launch_argmax_labels(const phmrf_block* b);
 int launch_icm_colour(const phmrf_block* b, float beta, int colour);
-int launch_energy(const phmrf_block* b, float beta);  // -> accum[0]=unary, accum[1]=pair (caller zeroes)
+int launch_energy(const phmrf_block* b, float beta, double* accum_at = nullptr);  // -> accum[4]=unary, accum[5]=pair (caller zeroes); accum_at: elsewhere
+int launch_choose_labels(const phmrf_block* b, const uint8_t* saved, const double* acc_cur, const double* acc_sav, double beta);
 bool energy_delta_available(const phmrf_block* b);
 int launch_energy_delta(const phmrf_block* b);        // -> accum[..] += the change since labels_eval / eval_tick
 int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors);

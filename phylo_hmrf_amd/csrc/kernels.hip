@@ -804,8 +804,43 @@ int launch_icm_colour(const phmrf_block* b, float beta, int colour) {
   return PHMRF_OK;
 }
 
-int launch_energy(const phmrf_block* b, float beta) {
+// labels <- saved where the snapshot's energy (acc_sav: unary, pair sums) is not above the current labels' (acc_cur): the
+// choice of phmrf_block_warm_start, taken on the device so that the host does not have to wait for the two evaluations
+__global__ __launch_bounds__(256) void choose_labels_kernel(uint8_t* __restrict__ labels, const uint8_t* __restrict__ saved, int64_t n,
+                                                            const double* __restrict__ acc_cur, const double* __restrict__ acc_sav,
+                                                            double beta, int det) {
+  double cu, cp, su, sp;
+  if (det) {
+    cu = (double)reinterpret_cast<const long long*>(acc_cur)[0] / ENERGY_FIX;
+    cp = (double)reinterpret_cast<const long long*>(acc_cur)[1] / ENERGY_FIX;
+    su = (double)reinterpret_cast<const long long*>(acc_sav)[0] / ENERGY_FIX;
+    sp = (double)reinterpret_cast<const long long*>(acc_sav)[1] / ENERGY_FIX;
+  } else {
+    cu = acc_cur[0]; cp = acc_cur[1]; su = acc_sav[0]; sp = acc_sav[1];
+  }
+  if (cu + beta * cp < su + beta * sp) return;             // the current labels are the better start
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (int64_t)gridDim.x * blockDim.x * 16) {
+    if (i + 16 <= n && ((reinterpret_cast<uintptr_t>(labels + i) | reinterpret_cast<uintptr_t>(saved + i)) & 15) == 0) {
+      *reinterpret_cast<uint4*>(labels + i) = *reinterpret_cast<const uint4*>(saved + i);
+    } else {
+      for (int64_t q = i; q < n && q < i + 16; ++q) labels[q] = saved[q];
+    }
+  }
+}
+
+int launch_choose_labels(const phmrf_block* b, const uint8_t* saved, const double* acc_cur, const double* acc_sav, double beta) {
+  int64_t g64 = (b->n / 16 + 255) / 256 + 1;
+  const int grid = (int)(g64 > 4096 ? 4096 : g64);
+  hipLaunchKernelGGL(choose_labels_kernel, dim3(grid), dim3(256), 0, b->stream, b->labels, saved, b->n, acc_cur, acc_sav, beta,
+                     b->deterministic ? 1 : 0);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+// accum_at: where the two sums go (nullptr: the block's accum area, slots ACC_ENERGY, ACC_ENERGY + 1)
+int launch_energy(const phmrf_block* b, float beta, double* accum_at) {
   (void)beta;
+  double* const acc = accum_at ? accum_at - ACC_ENERGY : b->accum;
   if (b->has_grid && b->fwd_w && b->H > 0 && b->W > 0) {
     const int gx = (b->W + 63) / 64;
     int gy = (b->H + 3) / 4;
@@ -813,14 +848,14 @@ int launch_energy(const phmrf_block* b, float beta) {
     if (gy > cap) gy = cap;
     const int row0 = b->own_r1 >= 0 ? b->own_r0 : 0, row1 = b->own_r1 >= 0 ? b->own_r1 : b->H;
     hipLaunchKernelGGL(energy_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->logprob,
-                       (b->uT && b->uT_valid) ? b->uT : nullptr, b->n, b->K, b->H, b->W, b->diagonal, b->fwd_w, b->labels, b->accum,
+                       (b->uT && b->uT_valid) ? b->uT : nullptr, b->n, b->K, b->H, b->W, b->diagonal, b->fwd_w, b->labels, acc,
                        b->deterministic ? 1 : 0, row0, row1);
     PHMRF_HIP(hipGetLastError());
     return PHMRF_OK;
   }
   const int grid = grid_for(b->n, 256, 256 * 8);
   hipLaunchKernelGGL(energy_kernel, dim3(grid), dim3(256), 0, b->stream, b->logprob, b->n, b->K, b->D, b->nbr, b->wgt,
-                     b->labels, b->accum, b->deterministic ? 1 : 0);
+                     b->labels, acc, b->deterministic ? 1 : 0);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

@@ -1920,9 +1920,10 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
       __builtin_amdgcn_wave_barrier();
 
       // ---- the DP of the flagged labels, lane <-> cell t = 64 p + lane (column-major), cells outside U pinned
+#ifdef PHMRF_COLS_NO_DP            // development: the filter alone (timing / register experiments; the labelling is wrong)
+      const int nbuf = 0;
+#else
       const int nbuf = __builtin_amdgcn_readfirstlane(lds_pool.nbuf);
-#ifdef PHMRF_COLS_NO_DP
-      nbuf = 0;
 #endif
       for (int kb = 0; kb < nbuf; ++kb) {
         const int alpha = __builtin_amdgcn_readfirstlane(abuf[kb]);

@@ -398,7 +398,7 @@ class phyloHMRF(_BaseGraph):
         b = self.blocks[region_id]
         b.emission(self.means_, self._covars_)
         if self.warm_start == "best":
-            b.warm_start(self.beta, SLOT_LOCAL)          # labels_local or the previous result, whichever is lower
+            b.warm_start(self.beta, SLOT_LOCAL, report=False)      # labels_local or the previous result, whichever is lower
         else:
             b.restore_labels(SLOT_LOCAL)                 # init_labels = labels_local[id1:id2]  (:479)
         b.solve_fast(self.beta, **self.solver_opts)

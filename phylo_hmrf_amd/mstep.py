@@ -478,9 +478,9 @@ def do_mstep(tree, stats, params_cur, init_ou_params, n_samples, lambda_0, initi
     """`_do_mstep` (phylo_hmrf.py:1500-1528) for all K states, or for the states listed in `states` (the others' rows of
     the result stay zero: with several ranks every rank fits its share and an all-reduce puts the rows together).
     The reference draws the random parts of all states' start points from one stream in state order (:1371-1380).  Here
-    every state has a generator of its own, seeded from ONE draw of `rng` per call and the state's index: the result of a
-    state does not depend on which other states are fitted in the same call, nor by whom -- as long as every rank calls
-    this once per M-step with generators in the same state, each advances by exactly that one draw.
+    they come, laid out by state, from a generator seeded with ONE draw of `rng` per call: the result of a state does not
+    depend on which other states are fitted in the same call, nor by whom -- as long as every rank calls this once per
+    M-step with generators in the same state, each advances by exactly that one draw.
     -> params[K,3B+2], means[K,S], covars[K,S,S] (= V + min_covar*I as at :1524), lik[K]."""
     K = params_cur.shape[0]
     P = tree.n_params
@@ -488,17 +488,22 @@ def do_mstep(tree, stats, params_cur, init_ou_params, n_samples, lambda_0, initi
     if base is None:        # (a caller that fits the states in several calls draws it once and hands it to each)
         base = int(rng.integers(0, 2 ** 62))
     todo = list(range(K)) if states is None else [int(c) for c in states]
+    # the random parts of ALL states' start points from one generator seeded by `base`, laid out by state: what state c
+    # gets does not depend on which states this call fits (every rank draws the same K x retries x P block: 1,380 doubles
+    # at K = 20 -- cheaper than a generator per state)
+    block = np.random.default_rng(base)
+    ra = block.random((K, retries, P))
+    rb = block.random((K, retries, P - N)) if initial_mode == 1 else None
     tasks = []
     for c in todo:
-        srng = np.random.default_rng([base, c])
         guesses = []
-        for _ in range(retries):
+        for q in range(retries):
             if initial_mode == 1:                                                     # (:1371-1376)
-                r = 2.0 * srng.random(P) - 1.0
-                r[0:P - N] = srng.random(P - N)
+                r = 2.0 * ra[c, q] - 1.0
+                r[0:P - N] = rb[c, q]
                 r = w2 * r
             else:
-                r = w2 * srng.random(P)
+                r = w2 * ra[c, q]
             guesses.append(w1 * init_ou_params[c] + w1a * params_cur[c] + (1.0 - w1 - w1a) * r)   # (:1378-1380)
         tasks.append((tree, stats["post"][c], stats["obs"][c], stats["obs*obs.T"][c], n_samples, lambda_0, guesses,
                       init_ou_params[c]))

@@ -63,7 +63,7 @@ class FakeBlock(object):
     def get_saved_labels(self, slot):
         return self.slots[slot].astype(np.int32)
 
-    def warm_start(self, beta, slot, choose=True):
+    def warm_start(self, beta, slot, choose=True, report=True):
         ec = R.mrf_energy(np.int64(self.labels), self.logprob, self.eid, self.w, beta)[0]
         es = R.mrf_energy(np.int64(self.slots[slot]), self.logprob, self.eid, self.w, beta)[0]
         took = not (ec < es)

@@ -481,7 +481,8 @@ def test_posterior_stats_golden(et):
     b.close()
 
 
-@pytest.mark.parametrize("S,K,N", [(4, 20, 120), (8, 30, 60), (4, 10, 200)])
+# (the last two: the kernel's corner -- K = 64, S = 8 takes 158 KB of the CU's 160 KB of LDS at 64-node tiles; K = 56 the size below)
+@pytest.mark.parametrize("S,K,N", [(4, 20, 120), (8, 30, 60), (4, 10, 200), (8, 64, 50), (8, 56, 50)])
 def test_posterior_stats_oracle(S, K, N):
     blk = synth.make_block(5, N, N, S, K, True)
     X = blk["X"]

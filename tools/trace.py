@@ -30,3 +30,4 @@ print("warm solve:", res)
 stats, costs, _ = b.posterior_stats(1.0, 3)
 print("costs/n:", (costs / n).round(5))
 print("work:", b.work())
+print("timing:", {k: (round(v[0], 3), v[1]) for k, v in b.timing().items() if v[1]})
