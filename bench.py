@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--split-above", type=float, default=1.0,
                     help="N > 1: a block that holds more than this many times a rank's share of the nodes is cut into row "
                          "tiles that different ranks hold (phylo_hmrf_amd/tiles.py)")
+    ap.add_argument("--tile-parts", type=int, default=0,
+                    help="cut EVERY block into this many row tiles whatever its size (measurement of the lockstep rounds' "
+                         "overhead on one GPU: the tiles of a block are then all local)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one process, one GPU: build and time only what rank --emulate-rank of a run on this many GPUs holds")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -205,7 +208,8 @@ def main():
     # units of work -> ranks: whole blocks, and ROW TILES of the blocks that hold more than --split-above x a rank's share
     # (phylo_hmrf_amd/tiles.py), dealt longest first; this rank builds and keeps only its own
     all_blocks = list(blocks_def) * (world if a.scaling == "weak" else 1)
-    units = tiles.plan(all_blocks, eworld, a.split_above)
+    units = tiles.plan(all_blocks, eworld, a.split_above,
+                       force_parts={bi: a.tile_parts for bi in range(len(all_blocks))} if a.tile_parts > 1 else None)
     owner = tiles.assign(units, eworld)
     sizes = [workloads.block_nodes(*bd) for bd in all_blocks]
     n_global = int(sum(sizes))

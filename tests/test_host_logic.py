@@ -68,3 +68,84 @@ def test_shard_deals_every_block_once_and_balances(world, scaling):
         assert loads.max() == sizes.max()                              # the chr1 block alone bounds the speed-up: 7.16x
     # deterministic: every rank computes the same deal
     assert np.array_equal(owner, W.shard(blocks, world, scaling)[1])
+
+
+# ---- row tiles: the planner and the tile geometry (phylo_hmrf_amd/tiles.py; the solves themselves: tests/test_gpu_tiles.py) ----
+@pytest.mark.parametrize("H,W,diag,parts", [(4980, 4980, True, 2), (4980, 4980, True, 3), (4980, 4980, True, 7), (1806, 2090, False, 3),
+                                            (100, 100, True, 5), (64, 40, False, 2), (17, 17, True, 9)])
+def test_split_rows_partitions_the_rows_into_balanced_tiles(H, W, diag, parts):
+    from phylo_hmrf_amd import tiles
+    rows = tiles.split_rows(H, W, diag, parts)
+    assert rows[0][0] == 0 and rows[-1][1] == H
+    for (a0, a1), (b0, b1) in zip(rows, rows[1:]):
+        assert a1 == b0
+    assert all(r1 - r0 >= tiles.MIN_TILE_ROWS for r0, r1 in rows) or len(rows) == 1
+    assert len(rows) == min(parts, max(1, H // tiles.MIN_TILE_ROWS))
+    n = [tiles.rows_nodes(r0, r1, W, diag) for r0, r1 in rows]
+    assert sum(n) == (H * W - H * (H - 1) // 2 if diag else H * W)
+    if H >= 20 * len(rows):          # equal shares up to a row or two of the longest row
+        assert max(n) - min(n) <= 2 * W + 2 * tiles.MIN_TILE_ROWS * W * (H < 200)
+
+
+def test_plan_cuts_the_blocks_above_a_ranks_share_and_balances_eight_ranks():
+    from phylo_hmrf_amd import tiles, workloads
+    blocks = workloads.genome_blocks(50000)
+    total = sum(workloads.block_nodes(*b) for b in blocks)
+    for world in (1, 2, 4):
+        units = tiles.plan(blocks, world)
+        assert len(units) == len(blocks) and all(u["ntiles"] == 1 for u in units)       # nothing above a rank's share
+    units = tiles.plan(blocks, 8)
+    split = sorted(set(u["block"] for u in units if u["ntiles"] > 1))
+    assert split == [0, 1]                                                               # chr1 and chr2 (12.4 M, 11.7 M > 11.1 M)
+    assert sum(u["nodes"] for u in units) == total
+    owner = tiles.assign(units, 8)
+    load = [sum(u["nodes"] for u, o in zip(units, owner) if o == r) for r in range(8)]
+    assert max(load) <= 1.03 * total / 8.0, load                                         # whole blocks alone: 1.12 (chr1)
+    # every unit of a split block names its rows; together they cover the block
+    for b in split:
+        us = [u for u in units if u["block"] == b]
+        assert [u["tile"] for u in us] == list(range(len(us))) and us[0]["r0"] == 0 and us[-1]["r1"] == blocks[b][0]
+
+
+@pytest.mark.parametrize("diag", [True, False])
+def test_tile_geometry_is_the_blocks_rows(diag):
+    from phylo_hmrf_amd import tiles
+    H, W = (60, 60) if diag else (50, 70)
+
+    class NoBlock(object):
+        def __init__(self, n, S, K):
+            self.n = n
+
+    rows = tiles.split_rows(H, W, diag, 3)
+    covered = 0
+    for t, (r0, r1) in enumerate(rows):
+        tl = tiles.Tile(H, W, diag, r0, r1, t, 3, 4, 5, NoBlock)
+        assert (tl.top, tl.bottom) == (t > 0, t < 2)
+        assert tl.Hl == (r1 - r0) + int(tl.top) + int(tl.bottom)
+        assert tl.Wl == (W - tl.s0 if diag else W)
+        assert tl.b.n == tl.n == (tl.Hl * tl.Wl - tl.Hl * (tl.Hl - 1) // 2 if diag else tl.Hl * tl.Wl)       # rows of a triangle are a smaller triangle's first rows
+        assert tl.node0 == tiles.row_first(tl.s0, W, diag)
+        assert tl.own_hi - tl.own_lo == tiles.rows_nodes(r0, r1, W, diag)
+        g = tl.owned_global_slice()
+        assert g.start == covered
+        covered = g.stop
+        # the rows that travel: what I send up is what the tile above receives from below, and so on
+        if t > 0:
+            up = tiles.Tile(H, W, diag, rows[t - 1][0], rows[t - 1][1], t - 1, 3, 4, 5, NoBlock)
+            assert tl.top_out == up.bot_in and tl.top_in == up.bot_out
+    assert covered == tiles.rows_nodes(0, H, W, diag)
+
+
+def test_tile_group_payload_round_trip():
+    from phylo_hmrf_amd import tiles
+    g = tiles.TileGroup(0, (100, 100, True), 3, {}, None)
+    buf = np.zeros(3 * g.slot, dtype=np.int64)
+    c = np.arange(128, dtype=np.uint64) * 3 + (1 << 40)
+    top, bot = np.arange(97, dtype=np.uint8) % 20, (np.arange(60, dtype=np.uint8) * 7) % 20
+    g._pack(buf, 1, c, [1.5, -2.25e9], top, bot)
+    o = g.slot
+    assert np.array_equal(buf[o:o + 128].view(np.uint64), c)
+    assert buf[o + 128:o + 130].view(np.float64).tolist() == [1.5, -2.25e9]
+    rt, rb = g._rows(buf, 1)
+    assert np.array_equal(rt[:97], top) and np.array_equal(rb[:60], bot)
+    assert not buf[:o].any() and not buf[2 * o:].any()                # the other tiles' slots stay zero: an all-reduce is a gather
