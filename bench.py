@@ -648,6 +648,79 @@ def pmc_traffic(workload, kernel_names):
     return int(tot_b / tot_l), "profiles/pmc_by_kernel.json: %s (git %s)" % (d.get("command"), d.get("git_rev"))
 
 
+def _cpu_sample_main():
+    """child process of cpu_baseline's parallel leg: `python bench.py --cpu-sample-child N S K nn seed beta beta1` runs the
+    faithful warm-start E-step of one N x N diagonal block (no GPU, no torch) and prints its seconds"""
+    N, S, K, nn, seed = (int(x) for x in sys.argv[2:7])
+    beta, beta1 = float(sys.argv[7]), float(sys.argv[8])
+    from oracle import gco_ref, ref_numpy as R, synth
+    blk = synth.make_block(seed, N, N, S, K, True, nn)
+    X = blk["X"]
+    w, eid = R.edge_weights_from_distance(blk["edges"], beta1)
+    V = R.potts_matrix(K, beta)
+    have_ref = gco_ref.available()
+
+    def label(lp, init):
+        if have_ref:
+            return gco_ref.cut_general_graph(eid, w, -lp, V, n_iter=5000, algorithm="swap", init_labels=init)
+        from oracle import estep_c
+        u_i, w_i, v_i = gco_ref.quantise(w, -lp, V, "pygco")
+        return estep_c.swap_int(eid, w_i, u_i, v_i, init)[0]
+
+    rng = np.random.default_rng(seed + 99)
+    lp_prev = R.log_multivariate_normal_density_full(X, blk["means"] * (1.0 + 0.03 * rng.standard_normal(blk["means"].shape)),
+                                                     blk["covars"])
+    labels_prev = label(lp_prev, np.argmax(lp_prev, axis=1))
+    print("READY", flush=True)
+    sys.stdin.readline()                                   # all children start the timed part together
+    t0 = time.time()
+    lp = R.log_multivariate_normal_density_full(X, blk["means"], blk["covars"])
+    labels = label(lp, labels_prev)
+    pp = R.pairwise_compare_loops(labels, eid, w, V, 3)
+    wp = np.exp(lp - pp)
+    post = wp / wp.sum(axis=1, keepdims=True)
+    R.pairwise_cost_ensemble_loops(labels, eid, w, V, 3)
+    R.sufficient_statistics(post, X)
+    print("SECONDS %.4f %d" % (time.time() - t0, X.shape[0]), flush=True)
+
+
+def cpu_parallel(a, S, K, nn, procs):
+    """the faithful sample of cpu_baseline in `procs` fresh processes at once (one block each, as the reference runs one process
+    per block, base.py:357-362): a MEASURED multi-core figure next to the extrapolated bound.  -> dict or None"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-sample-child", str(a.cpu_sample), str(S), str(K), str(nn), str(a.seed),
+           str(a.beta), str(a.beta1)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    ch = []
+    try:
+        ch = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
+              for _ in range(procs)]
+        for p in ch:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("child did not start")
+        t0 = time.time()
+        for p in ch:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        secs, n = [], 0
+        for p in ch:
+            parts = p.stdout.readline().split()
+            secs.append(float(parts[1]))
+            n = int(parts[2])
+            p.wait(timeout=60)
+        wall = time.time() - t0
+        return {"processes": procs, "value": procs * n / wall, "unit": "node-iterations/s", "wall_s": round(wall, 2),
+                "per_process_s": [round(x, 2) for x in secs],
+                "note": "MEASURED: %d processes at once, one %d-node block each (ref-faithful variant, OMP/BLAS threads 1)" % (procs, n)}
+    except Exception as err:          # a baseline leg must never take the bench line down
+        for p in ch:
+            try:
+                p.kill()
+            except Exception:
+                pass
+        return {"processes": procs, "value": None, "error": "%s: %s" % (type(err).__name__, err)}
+
+
 def cpu_baseline(a, S, K, nn, n_blocks=1, n_total=0, n_max=0):
     """The reference's CPU E-step, timed on this box's host cores on ONE bounded block of the workload's shape: a
     652-bin diagonal block (212,878 nodes: the size of config 1's chr21 block), S species, K states.
@@ -662,7 +735,8 @@ def cpu_baseline(a, S, K, nn, n_blocks=1, n_total=0, n_max=0):
          ref-vectorised  the same arithmetic in vectorised NumPy -- a fair CPU ceiling for that part
     One core = one reference block process (base.py:357-362).  The reference runs one process per block, so on C cores
     its whole-workload rate is at most min(#blocks, C, N_tot / n_largest_block) times the single-core figure
-    (`all_cores_upper_bound`, extrapolated, not measured).  The reference's M-step (K SLSQP runs, ~0.6 s each) is NOT
+    (`all_cores_upper_bound`, extrapolated, not measured); `measured_parallel` is the same faithful sample run in up to 8
+    fresh processes at once on this box's cores (one block each): measured, for that many cores.  The reference's M-step (K SLSQP runs, ~0.6 s each) is NOT
     included although `value` includes the build's M-step.  A stated baseline, never the target."""
     from oracle import gco_ref, ref_numpy as R, synth
     N = a.cpu_sample
@@ -711,6 +785,7 @@ def cpu_baseline(a, S, K, nn, n_blocks=1, n_total=0, n_max=0):
             "variant": "ref-faithful (Python posterior loops)",
             "vectorised": {"value": n / (t_em + t_cut + t_vec), "unit": "node-iterations/s", "cores": 1,
                            "variant": "ref-vectorised (same arithmetic in NumPy)"},
+            "measured_parallel": cpu_parallel(a, S, K, nn, int(max(1, min(8, cores // 2, n_blocks or 1)))),
             "all_cores_upper_bound": {"faithful": faithful * par, "vectorised": n / (t_em + t_cut + t_vec) * par,
                                       "processes": "one per block as in base.py:357-362: at most min(%d blocks, %d cores, "
                                                    "N_tot / largest block = %.1f) = %.1f x one core; extrapolated, not measured"
@@ -725,4 +800,7 @@ def cpu_baseline(a, S, K, nn, n_blocks=1, n_total=0, n_max=0):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-sample-child":
+        _cpu_sample_main()
+    else:
+        main()

@@ -1213,6 +1213,28 @@ void solve_scope_exit(phmrf_block* b) {
   b->ss = nullptr;
 }
 
+// first node of grid row i (i == H: n)
+int64_t tile_row_first(const phmrf_block* b, int i) {
+  return b->diagonal ? (int64_t)i * b->W - ((int64_t)i * (i - 1)) / 2 : (int64_t)i * b->W;
+}
+
+// queue the copy of a tile's first and last owned rows into the pinned staging buffer (top row first); whoever
+// synchronises the stream next finds them there (phmrf_block_tile_get_boundary then copies without touching the device)
+int tile_queue_boundary(phmrf_block* b) {
+  int64_t off = 0;
+  if (b->tile_top) {
+    const int64_t tf = tile_row_first(b, 1), tc = tile_row_first(b, 2) - tf;
+    PHMRF_HIP(hipMemcpyAsync(b->xfer_host, b->labels + tf, (size_t)tc, hipMemcpyDeviceToHost, b->stream));
+    off = tc;
+  }
+  if (b->tile_bot) {
+    const int64_t bf = tile_row_first(b, b->H - 2), bc = tile_row_first(b, b->H - 1) - bf;
+    PHMRF_HIP(hipMemcpyAsync(b->xfer_host + off, b->labels + bf, (size_t)bc, hipMemcpyDeviceToHost, b->stream));
+  }
+  b->boundary_queued = true;
+  return PHMRF_OK;
+}
+
 int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool want_init_energy) {
   PHMRF_TRY(check_solvable(b));
   if (b->ss) solve_scope_exit(b);                 // (an abandoned solve)
@@ -1456,6 +1478,7 @@ int solve_round_launch(phmrf_block_t b) {
   PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            b->stream));
   PHMRF_TRY(energy_round_launch(b, &s->incremental, &s->snapshot));
+  if (b->tile_top || b->tile_bot) PHMRF_TRY(tile_queue_boundary(b));      // the rows the neighbours need travel with the counters
   s->launched = true;
   s->collected = false;
   return PHMRF_OK;
@@ -1747,7 +1770,7 @@ int phmrf_block_set_tile(phmrf_block_t b, int top, int bottom, int64_t sched_n) 
     if (b->xfer_host) (void)hipHostFree(b->xfer_host);
     b->xfer_host = nullptr;
     PHMRF_TRY(dev_alloc(&b->xfer, (size_t)cap));
-    PHMRF_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->xfer_host), (size_t)cap));
+    PHMRF_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->xfer_host), (size_t)2 * cap));     // outgoing | incoming rows
     b->xfer_cap = cap;
   }
   return PHMRF_OK;
@@ -1791,21 +1814,24 @@ int phmrf_block_tile_pins(phmrf_block_t b, int n_top, int n_bottom) {
 int phmrf_block_tile_get_boundary(phmrf_block_t b, uint8_t* top_out, uint8_t* bottom_out) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   PHMRF_CHECK(b->tile_top || b->tile_bot, PHMRF_ERR_STATE, "the block is not a tile (phmrf_block_set_tile)");
-  int64_t off = 0, tf = 0, tc = 0, bf = 0, bc = 0;
-  if (top_out && b->tile_top) {
-    tf = row_first(b, 1);
-    tc = row_first(b, 2) - tf;
-    PHMRF_HIP(hipMemcpyAsync(b->xfer_host, b->labels + tf, (size_t)tc, hipMemcpyDeviceToHost, b->stream));
+  // inside a solve the rows were queued behind the round's moves (solve_round_launch) and have arrived with the round's
+  // counters (solve_round_collect): no device traffic, no wait
+  const bool have = b->boundary_queued && b->ss && b->ss->collected;
+  if (!have) {
+    PHMRF_TRY(tile_queue_boundary(b));
+    PHMRF_HIP(hipStreamSynchronize(b->stream));
+  }
+  b->boundary_queued = false;
+  int64_t off = 0;
+  if (b->tile_top) {
+    const int64_t tc = row_first(b, 2) - row_first(b, 1);
+    if (top_out) std::memcpy(top_out, b->xfer_host, (size_t)tc);
     off = tc;
   }
-  if (bottom_out && b->tile_bot) {
-    bf = row_first(b, b->H - 2);
-    bc = row_first(b, b->H - 1) - bf;
-    PHMRF_HIP(hipMemcpyAsync(b->xfer_host + off, b->labels + bf, (size_t)bc, hipMemcpyDeviceToHost, b->stream));
+  if (b->tile_bot && bottom_out) {
+    const int64_t bc = row_first(b, b->H - 1) - row_first(b, b->H - 2);
+    std::memcpy(bottom_out, b->xfer_host + off, (size_t)bc);
   }
-  PHMRF_HIP(hipStreamSynchronize(b->stream));
-  if (tc) std::memcpy(top_out, b->xfer_host, (size_t)tc);
-  if (bc) std::memcpy(bottom_out, b->xfer_host + off, (size_t)bc);
   return PHMRF_OK;
 }
 
@@ -1815,24 +1841,26 @@ int phmrf_block_tile_put_halo(phmrf_block_t b, const uint8_t* top_in, const uint
   PHMRF_CHECK(b->tile_top || b->tile_bot, PHMRF_ERR_STATE, "the block is not a tile (phmrf_block_set_tile)");
   if (b->tick) ++b->tick;
   b->labels_are_slot = -1;
+  uint8_t* const in_host = b->xfer_host + b->xfer_cap;      // (the second half of the pinned buffer: the first holds the outgoing rows)
   int64_t off = 0;
   if (top_in && b->tile_top) {
     const int64_t c = row_first(b, 1);
     for (int64_t q = 0; q < c; ++q) PHMRF_CHECK(top_in[q] < b->K, PHMRF_ERR_INVALID, "label out of range [0,K)");
-    std::memcpy(b->xfer_host, top_in, (size_t)c);
-    PHMRF_HIP(hipMemcpyAsync(b->xfer, b->xfer_host, (size_t)c, hipMemcpyHostToDevice, b->stream));
+    std::memcpy(in_host, top_in, (size_t)c);
+    PHMRF_HIP(hipMemcpyAsync(b->xfer, in_host, (size_t)c, hipMemcpyHostToDevice, b->stream));
     PHMRF_TRY(launch_put_labels(b, 0, c, b->xfer));
     off = c;
   }
   if (bottom_in && b->tile_bot) {
     const int64_t f = row_first(b, b->H - 1), c = b->n - f;
     for (int64_t q = 0; q < c; ++q) PHMRF_CHECK(bottom_in[q] < b->K, PHMRF_ERR_INVALID, "label out of range [0,K)");
-    std::memcpy(b->xfer_host + off, bottom_in, (size_t)c);
-    PHMRF_HIP(hipMemcpyAsync(b->xfer + off, b->xfer_host + off, (size_t)c, hipMemcpyHostToDevice, b->stream));
+    std::memcpy(in_host + off, bottom_in, (size_t)c);
+    PHMRF_HIP(hipMemcpyAsync(b->xfer + off, in_host + off, (size_t)c, hipMemcpyHostToDevice, b->stream));
     PHMRF_TRY(launch_put_labels(b, f, c, b->xfer + off));
   }
-  // (the staging buffers are reused by the next call: the copies must have left the host buffer)
-  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  // (no wait: inside a solve the next call comes after the next round has been collected -- a stream synchronisation --,
+  //  so the copies have left the staging buffers by then; outside a solve the caller's next synchronising call does it)
+  if (!b->ss) PHMRF_HIP(hipStreamSynchronize(b->stream));
   return PHMRF_OK;
 }
 

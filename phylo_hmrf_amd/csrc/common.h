@@ -159,6 +159,7 @@ struct phmrf_block {
   uint8_t* xfer = nullptr;                  // device staging for the halo rows (2 rows)
   uint8_t* xfer_host = nullptr;             // pinned mirror
   int64_t xfer_cap = 0;
+  bool boundary_queued = false;             // the outgoing rows' copy into xfer_host is queued / has arrived (tile_queue_boundary)
   int64_t pin_first[2] = {0, 0}, pin_count[2] = {0, 0};   // node range of the two top / two bottom rows
   int64_t pin_split[2] = {0, 0};            // nodes of the FIRST of the two rows (top region) / of the first of the two bottom rows
   int pin_rows[2] = {0, 0};                 // how many rows of each region are pinned right now (top: counted from the top, bottom: from the bottom)

@@ -10,7 +10,6 @@ from phylo_hmrf_amd.tree import PhyloTree
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 blocks_def, S, K, nn, desc = workloads.workload(wl)
-mstep._pool(min(K, os.cpu_count()))
 dev = torch.device("cuda", 0)
 tree = PhyloTree(synthetic.tree_for(S)); rng = np.random.default_rng(0)
 P = synthetic.sample_ou_params(rng, tree, K); mu, cv = tree.mean_cov(P); cv = cv + 1e-3 * np.eye(S)
@@ -27,10 +26,14 @@ for b in blocks:
     b.save_labels(SLOT_LOCAL); b.sync()
 ns = K * (1 + S + S * S); min_cost = 1e30
 for it in range(iters):
-    tot = np.zeros(ns + 4); ch = 0; rounds = 0; t0 = time.time()
+    tot = np.zeros(ns + 4); ch = 0; rounds = 0; t0 = time.time(); took_local = 0; hist = [0] * 10
     for b in blocks:
-        b.restore_labels(SLOT_LOCAL); b.emission(means, covars)
-        r = b.solve(1.0, energy_tol_ppb=1000); ch += r["changed"]; rounds += r["rounds"]
+        b.emission(means, covars)
+        if os.environ.get("PHMRF_DIAG_WARM", "best") == "best":
+            ec, es, took = b.warm_start(1.0, SLOT_LOCAL); took_local += int(took)
+        else:
+            b.restore_labels(SLOT_LOCAL)
+        r = b.solve(1.0, energy_tol_ppb=1000); ch += r["changed"]; rounds += r["rounds"]; hist[min(r["rounds"], 9)] += 1
         st, costs, _ = b.posterior_stats(1.0, 3)
         tot[:K] += st["post"]; tot[K:K + K * S] += st["obs"].ravel(); tot[K + K * S:ns] += st["obs*obs.T"].ravel(); tot[ns:] += costs
     cost1 = tot[ns + 3] / N; renewed = cost1 < min_cost
@@ -39,5 +42,5 @@ for it in range(iters):
         for b in blocks: b.save_labels(SLOT_LOCAL)
     p, means, covars, _ = mstep.do_mstep(tree, unpack_stats(tot[:ns], K, S), cur, init_ou, N, 1.0, 0, 0.3, 0.1, 1.0, rng, workers=min(K, os.cpu_count()))
     dpar = float(np.max(np.abs(p - cur) / (np.abs(cur) + 1e-3))); cur = p
-    print("it %2d cost1 %.6f %s changed %.2f%% rounds/solve %.1f  max rel param change %.3f  (%.2fs sequential)" % (it, cost1, "renewed" if renewed else "kept   ", 100.0 * ch / N, rounds / len(blocks), dpar, time.time() - t0), flush=True)
+    print("it %2d cost1 %.6f %s changed %.2f%% rounds/solve %.1f %s started from labels_local in %d of %d blocks  max rel param change %.3f  (%.2fs sequential)" % (it, cost1, "renewed" if renewed else "kept   ", 100.0 * ch / N, rounds / len(blocks), hist[1:8], took_local, len(blocks), dpar, time.time() - t0), flush=True)
 mstep.close_pool()
