@@ -292,6 +292,10 @@ PHMRF_API int phmrf_kmeans_moments(phmrf_block_t b, const double* centers /* [K,
  * of a solve: fusion_cols_kernel; the single-label strip passes of the API: strip_kernel). */
 #define PHMRF_NUM_KERNEL_CLASSES 10
 PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
+/* Which classes get event pairs while timing is on (bit k = class k; default all).  Two event records per launch group
+ * cost host time and queue slots: a measurement that wants one kernel's durations without perturbing the rest of the run
+ * times that class only (bench.py's timed region).  Launch counts and the device-counted work cover every class always. */
+PHMRF_API int phmrf_block_set_timing_classes(phmrf_block_t b, uint32_t class_mask);
 /* capacity = the length of the caller's arrays; min(capacity, PHMRF_NUM_KERNEL_CLASSES) entries are written */
 PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, int capacity, double* ms /*[capacity]*/, int64_t* launches /*[capacity]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);

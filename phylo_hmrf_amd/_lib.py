@@ -97,6 +97,7 @@ SIGNATURES = {
     "phmrf_kmeans_step": [_vp, _dp, _i, _dp],
     "phmrf_kmeans_moments": [_vp, _dp, _i, _dp],
     "phmrf_block_enable_timing": [_vp, _i],
+    "phmrf_block_set_timing_classes": [_vp, ctypes.c_uint32],
     "phmrf_block_get_timing": [_vp, _i, _dp, _lp],
     "phmrf_block_reset_timing": [_vp],
     "phmrf_block_get_work": [_vp, _lp],

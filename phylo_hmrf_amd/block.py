@@ -285,7 +285,14 @@ class Block(object):
         return (out[:KS].reshape(K, S), out[KS:KS + K], float(out[KS + K]), out[KS + K + 1:].reshape(K, S, S))
 
     # -- timing -----------------------------------------------------------------------------------
-    def enable_timing(self, on=True):
+    def enable_timing(self, on=True, classes=None):
+        """classes: names of the kernel classes that get event pairs (None: all)"""
+        mask = 0xFFFFFFFF
+        if classes is not None:
+            mask = 0
+            for c in classes:
+                mask |= 1 << _lib.KERNEL_CLASSES.index(c)
+        check(self._L.phmrf_block_set_timing_classes(self._h, ctypes.c_uint32(mask)))
         check(self._L.phmrf_block_enable_timing(self._h, int(on)))
 
     def reset_timing(self):

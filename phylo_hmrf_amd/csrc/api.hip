@@ -32,8 +32,8 @@ static hipEvent_t take_event(phmrf_block* b) {
   return e;
 }
 
-void tic(phmrf_block* b) {
-  if (!b->timing) return;
+void tic(phmrf_block* b, int kclass) {
+  if (!b->timing || !((b->timing_mask >> kclass) & 1u)) return;
   b->cur_start = take_event(b);
   if (b->cur_start && hipEventRecord(b->cur_start, b->stream) != hipSuccess) {
     b->free_events.push_back(b->cur_start);
@@ -745,7 +745,7 @@ int phmrf_emission(phmrf_block_t b, const double* means, const double* covars) {
   std::vector<float> packed((size_t)b->K * PS);
   PHMRF_TRY(phmrf_emission_pack(b->S, b->K, means, covars, packed.data()));
   PHMRF_TRY(upload(b->emis_params, packed.data(), packed.size() * sizeof(float), b->stream));
-  tic(b);
+  tic(b, KC_EMISSION);
   // (a block that has run strip moves before owns its unary planes: the kernel writes them along with logprob)
   PHMRF_TRY(launch_emission(b->X, b->n, b->S, b->K, b->emis_params, b->logprob, b->uT, b->stream));
   toc(b, KC_EMISSION, 1);
@@ -814,7 +814,7 @@ static int check_solvable(phmrf_block_t b) {
 
 static int icm_sweep_nocount(phmrf_block_t b, float beta) {
   if (b->tick) ++b->tick;
-  tic(b);
+  tic(b, KC_ICM);
   for (int c = 0; c < b->n_colours; ++c) PHMRF_TRY(launch_icm_colour(b, beta, c));
   toc(b, KC_ICM, b->n_colours);
   return PHMRF_OK;
@@ -823,7 +823,7 @@ static int icm_sweep_nocount(phmrf_block_t b, float beta) {
 static int chain_sweep_nocount(phmrf_block_t b, float beta, int family, int phase, bool timed = true) {
   const ChainFamily& f = b->families[family];
   if (b->tick) ++b->tick;
-  if (timed) tic(b);
+  if (timed) tic(b, KC_CHAIN);
   for (int c = 0; c < f.n_colours; ++c) PHMRF_TRY(launch_chain_colour(b, beta, family, c, phase));
   if (timed) toc(b, KC_CHAIN, f.n_colours);
   return PHMRF_OK;
@@ -831,7 +831,7 @@ static int chain_sweep_nocount(phmrf_block_t b, float beta, int family, int phas
 
 static int energy_now(phmrf_block_t b, double beta, double* eu, double* ep) {
   PHMRF_TRY(zero_accum(b, 4, 2));
-  tic(b);
+  tic(b, KC_ENERGY);
   PHMRF_TRY(launch_energy(b, (float)beta));
   toc(b, KC_ENERGY, 1);
   PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
@@ -860,7 +860,7 @@ static int energy_round_launch(phmrf_block_t b, bool* incremental_out, bool* sna
   const bool snapshot = grid && !always_full;
   const bool incremental = snapshot && energy_delta_available(b);
   PHMRF_TRY(zero_accum(b, 4, 2));
-  tic(b);
+  tic(b, KC_ENERGY);
   if (incremental) PHMRF_TRY(launch_energy_delta(b));
   else PHMRF_TRY(launch_energy(b, 0.f));
   toc(b, KC_ENERGY, 1);
@@ -938,7 +938,7 @@ int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, d
   double* const extra = b->accum + (ACCUM_DOUBLES - 4);     // (behind every statistic the accum area can hold)
   PHMRF_TRY(zero_accum(b, 4, 2));
   PHMRF_TRY(zero_accum(b, ACCUM_DOUBLES - 4, 2));
-  tic(b);
+  tic(b, KC_ENERGY);
   PHMRF_TRY(launch_energy(b, (float)beta));
   std::swap(b->labels, b->saved[slot]);                     // (score the snapshot in place)
   const int st = launch_energy(b, (float)beta, extra);
@@ -1001,7 +1001,7 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
   b->labels_are_slot = -1;
   PHMRF_TRY(zero_counter(b));
-  tic(b);
+  tic(b, KC_COMPONENT);
   PHMRF_TRY(launch_component_pass(b, (float)beta));
   toc(b, KC_COMPONENT, 1);
   int64_t ch = 0;
@@ -1013,16 +1013,16 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
 static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, int geom = -1,
                               bool timed = true) {
   if (!b->uT_valid) {                       // (before the proposals: on a grid they are formed from the planes)
-    tic(b);
+    tic(b, KC_PROPOSE);
     PHMRF_TRY(launch_unary_planes(b));
     toc(b, KC_PROPOSE, 1);
   }
   if (alpha < 0) {
-    tic(b);
+    tic(b, KC_PROPOSE);
     PHMRF_TRY(launch_propose(b, beta));
     toc(b, KC_PROPOSE, 1);
   }
-  if (timed) tic(b);
+  if (timed) tic(b, KC_FUSION);
   if (b->tick) ++b->tick;
   PHMRF_TRY(launch_strip_pass(b, beta, orient, shift_r, shift_c, alpha, geom));
   b->work[4] += 1;
@@ -1059,7 +1059,7 @@ int phmrf_mrf_strip_multi_pass(phmrf_block_t b, double beta, int orient, int shi
   PHMRF_CHECK(b->K >= 64 || (label_mask >> b->K) == 0, PHMRF_ERR_INVALID, "label_mask names a label >= K");
   PHMRF_HIP(hipMemsetAsync(b->counters, 0, 128 * sizeof(unsigned long long), b->stream));
   if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
-  tic(b);
+  tic(b, KC_STRIP);
   PHMRF_TRY(launch_strip_multi(b, (float)beta, orient, shift_r, shift_c, label_mask, -1));
   b->work[4] += 1;
   toc(b, KC_STRIP, 1);
@@ -1122,7 +1122,7 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   phmrf_block* ch[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int q = 0; q < batch; ++q) PHMRF_TRY(coarse_child(b, level * 4 + q, &ch[q]));
   if (!b->coarse_flag) PHMRF_TRY(dev_alloc(&b->coarse_flag, (size_t)1));
-  tic(b);
+  tic(b, KC_COARSE);
   int n_launch = 0;
   for (int a0 = alpha_lo; a0 < alpha_hi; a0 += batch) {
     const int nl = std::min(batch, alpha_hi - a0);
@@ -1381,7 +1381,7 @@ int solve_round_launch(phmrf_block_t b) {
     for (int f = 0; f < s->n_fam; ++f)
       if (active[72 + f] && (f < n_ord_fams || verifying)) n_chain += b->families[f].n_colours;
     if (n_chain > 0) {
-      tic(b);
+      tic(b, KC_CHAIN);
       for (int f = 0; f < s->n_fam; ++f)
         if (active[72 + f] && (f < n_ord_fams || verifying)) {
           b->counter_slot = 72 + f;
@@ -1410,7 +1410,7 @@ int solve_round_launch(phmrf_block_t b) {
     b->counter_slot = 77;
     ran[77] = 1;
     if (b->tick) ++b->tick;
-    tic(b);
+    tic(b, KC_COMPONENT);
     PHMRF_TRY(launch_component_pass(b, bf));
     toc(b, KC_COMPONENT, 1);
   }
@@ -1435,11 +1435,11 @@ int solve_round_launch(phmrf_block_t b) {
           }
         if (lmask) {
           if (!b->uT_valid) {
-            tic(b);
+            tic(b, KC_PROPOSE);
             PHMRF_TRY(launch_unary_planes(b));
             toc(b, KC_PROPOSE, 1);
           }
-          tic(b);
+          tic(b, KC_STRIP);
           ++b->tick;
           PHMRF_TRY(launch_strip_multi(b, bf, orient, GEOM_R[geom], GEOM_C[geom], lmask, geom));
           b->tick += K;                           // one tick per label inside the launch
@@ -1873,7 +1873,7 @@ static int posterior_launch(phmrf_block_t b, double beta, int estimate_type, boo
   if (write_post && !b->posteriors) PHMRF_TRY(dev_alloc(&b->posteriors, (size_t)b->n * b->K));
   PHMRF_TRY(zero_accum(b, 0, 4));
   PHMRF_TRY(zero_accum(b, 8, ns));
-  tic(b);
+  tic(b, KC_POSTERIOR);
   PHMRF_TRY(launch_posterior_stats(b, (float)beta, estimate_type, write_post));
   toc(b, KC_POSTERIOR, 1);
   return PHMRF_OK;
@@ -1958,6 +1958,12 @@ int phmrf_kmeans_moments(phmrf_block_t b, const double* centers, int write_label
 int phmrf_block_enable_timing(phmrf_block_t b, int enable) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   b->timing = enable != 0;
+  return PHMRF_OK;
+}
+
+int phmrf_block_set_timing_classes(phmrf_block_t b, uint32_t class_mask) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  b->timing_mask = class_mask;
   return PHMRF_OK;
 }
 

@@ -134,6 +134,7 @@ struct phmrf_block {
 
   // timing: event pairs recorded on the block's stream, resolved lazily (no host sync inside the measured loop)
   bool timing = false;
+  unsigned int timing_mask = ~0u;           // which kernel classes get event pairs while timing is on (launch counts: all)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   struct Pending { int kclass; hipEvent_t a, b; };
   std::vector<Pending> pending;
@@ -210,7 +211,7 @@ constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every (K,S) the po
                                      // (K <= 64, S <= 8: 4,688); phmrf_posterior_stats rejects anything larger
 
 // RAII-free helpers for the timers: call tic before the launches of one class, toc after.
-void tic(phmrf_block* b);
+void tic(phmrf_block* b, int kclass);
 void toc(phmrf_block* b, int kclass, int n_launches);
 
 inline int tile_threads(int K) { return K <= 40 ? 256 : 128; }
