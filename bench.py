@@ -380,7 +380,9 @@ def main():
     cold_first_ms = None
     dominant = None                                            # the kernel class whose launches the timed region times
     for w_it in range(a.warmup):
-        last = w_it == a.warmup - 1
+        # (which class leads is asked of a WARM iteration: with fewer than two warm-up steps the only candidate is the cold
+        #  first iteration, whose coarse rounds say nothing about the timed region -- every class is timed then, as before)
+        last = w_it == a.warmup - 1 and a.warmup >= 2
         if last and not a.no_kernel_timing:                    # the last warm-up iteration with every class timed: which one leads?
             for b in unit_blocks:
                 b.enable_timing(True)
@@ -396,8 +398,6 @@ def main():
                     if name in KERNELS_OF_CLASS:
                         tot[name] = tot.get(name, 0.0) + ms
             dominant = max(tot.items(), key=lambda kv: kv[1])[0]
-    if dominant is None and not a.no_kernel_timing:
-        dominant = "strip"
     # HIP events around EVERY launch group cost 4 - 5 ms of a 75 ms EM iteration (tools/job_ab_timing.sh): in the timed region
     # only the dominant class is timed (its launch durations are what `roofline` needs); the per-class breakdown (`kernels`)
     # comes from an instrumented pass after the timed region, which is not part of `value`
@@ -462,7 +462,7 @@ def main():
                 for name in agg_dom} if not a.no_kernel_timing and unit_blocks else {}
     # ---- the instrumented pass: a few more EM iterations with every class timed (after the timed region, not part of `value`)
     agg, busy, inst_steps, work_inst = agg_dom, busy_dom, 0, work
-    if not a.no_kernel_timing and unit_blocks:
+    if not a.no_kernel_timing and unit_blocks and dominant:
         inst_steps = min(a.steps, 5)
         for b in unit_blocks:
             b.enable_timing(True)
@@ -600,9 +600,12 @@ def main():
     kernels = {k: {"ms": round(v[0], 3), "launches": int(v[1]), "busy_ms": round(busy.get(k, 0.0), 3),
                    "GBps": (round(v[2] / (busy[k] * 1e-3) / 1e9, 1) if busy.get(k, 0) > 0 and v[2] > 0 else None)}
                for k, v in agg.items()}
-    kernels_from = ("an instrumented pass of %d EM iterations right after the timed region with every kernel class timed (not part "
-                    "of `value`); in the timed region only the dominant class (%s) carries HIP events -- the timers of all "
-                    "classes cost 4 - 5 ms per EM iteration" % (inst_steps, dominant)) if inst_steps else "the timed region"
+    if dominant:
+        kernels_from = ("an instrumented pass of %d EM iterations right after the timed region with every kernel class timed (not "
+                        "part of `value`); in the timed region only the dominant class of the last warm-up iteration (%s) carries "
+                        "HIP events -- the timers of all classes cost 4 - 5 ms per EM iteration" % (inst_steps, dominant))
+    else:
+        kernels_from = "the timed region (every class timed: fewer than two warm-up steps to choose the dominant class from)"
 
     if rank == 0:
         value = n_norm * a.steps / elapsed
