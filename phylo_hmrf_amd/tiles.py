@@ -298,9 +298,15 @@ class GroupComm(object):
     nccl backend (RCCL) the vector travels through a device tensor, with gloo through host memory."""
 
     def __init__(self, ranks, device=None):
+        import os
         import torch.distributed as dist
         self.ranks = sorted(set(int(r) for r in ranks))
-        self.group = dist.new_group(ranks=self.ranks) if len(self.ranks) > 1 else None       # (every rank must call this)
+        # PHMRF_TILE_BACKEND=gloo: the tiles' control messages (<= 11 KB per tile and round, host-resident on both ends)
+        # over a gloo group next to an RCCL world -- an operator's escape hatch; the default is the world's backend
+        backend = os.environ.get("PHMRF_TILE_BACKEND") or None
+        if backend == "gloo":
+            device = None
+        self.group = dist.new_group(ranks=self.ranks, backend=backend) if len(self.ranks) > 1 else None   # (every rank must call this)
         self.device = device
         self._buf = None
 
