@@ -639,7 +639,7 @@ int phmrf_block_set_labels(phmrf_block_t b, const int32_t* labels) {
   }
   PHMRF_TRY(upload(b->labels, tmp.data(), (size_t)b->n, b->stream));
   b->has_labels = true;
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   return PHMRF_OK;
 }
 
@@ -660,7 +660,7 @@ int phmrf_block_save_labels(phmrf_block_t b, int slot) {
   PHMRF_CHECK(slot >= 0 && slot < 4, PHMRF_ERR_INVALID, "slot must be in [0,4)");
   if (!b->saved[slot]) PHMRF_TRY(dev_alloc(&b->saved[slot], (size_t)b->n));
   PHMRF_HIP(hipMemcpyAsync(b->saved[slot], b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
-  b->labels_are_slot = slot;
+  b->labels_are_slot |= 1 << slot;
   return PHMRF_OK;
 }
 
@@ -669,7 +669,7 @@ int phmrf_block_restore_labels(phmrf_block_t b, int slot) {
   PHMRF_CHECK(slot >= 0 && slot < 4 && b->saved[slot], PHMRF_ERR_STATE, "label slot is empty");
   PHMRF_HIP(hipMemcpyAsync(b->labels, b->saved[slot], (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
   b->has_labels = true;
-  b->labels_are_slot = slot;
+  b->labels_are_slot = 1 << slot;
   return PHMRF_OK;
 }
 
@@ -928,7 +928,7 @@ int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, d
   PHMRF_CHECK(slot >= 0 && slot < 4 && b->saved[slot], PHMRF_ERR_STATE, "label slot is empty");
   if (took_saved) *took_saved = 1;
   const bool report = e_current || e_saved || took_saved;
-  if (!b->has_labels || b->labels_are_slot == slot) {        // nothing to compare with / the snapshot IS the current labelling
+  if (!b->has_labels || ((b->labels_are_slot >> slot) & 1)) {        // nothing to compare with / the snapshot IS the current labelling
     if (choose && !b->has_labels) PHMRF_TRY(phmrf_block_restore_labels(b, slot));
     if (e_current) *e_current = std::numeric_limits<double>::infinity();
     if (e_saved) *e_saved = 0.0;
@@ -946,7 +946,7 @@ int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, d
   PHMRF_TRY(st);
   if (choose) PHMRF_TRY(launch_choose_labels(b, b->saved[slot], b->accum + 4, extra, beta));
   toc(b, KC_ENERGY, choose ? 3 : 2);
-  if (choose) b->labels_are_slot = -1;
+  if (choose) b->labels_are_slot = 0;
   if (!report) return PHMRF_OK;
   PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   PHMRF_HIP(hipMemcpyAsync(b->accum_host + 6, extra, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
@@ -974,7 +974,7 @@ int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, d
 
 int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   PHMRF_TRY(zero_counter(b));
   PHMRF_TRY(icm_sweep_nocount(b, (float)beta));
   int64_t ch = 0;
@@ -985,7 +985,7 @@ int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed) {
 
 int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "chain moves need phmrf_block_set_grid");
   PHMRF_CHECK(family >= 0 && family < (int)b->families.size(), PHMRF_ERR_INVALID, "no such chain family");
   PHMRF_TRY(zero_counter(b));
@@ -999,7 +999,7 @@ int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* cha
 
 int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   PHMRF_TRY(zero_counter(b));
   tic(b, KC_COMPONENT);
   PHMRF_TRY(launch_component_pass(b, (float)beta));
@@ -1032,7 +1032,7 @@ static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift
 
 int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, int alpha, int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "strip moves need phmrf_block_set_grid");
   PHMRF_CHECK(b->num_neighbor == 8 || b->num_neighbor == 4, PHMRF_ERR_STATE, "bad grid");
   PHMRF_CHECK(orient == 0 || orient == 1, PHMRF_ERR_INVALID, "orient must be 0 or 1");
@@ -1051,7 +1051,7 @@ int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, 
 int phmrf_mrf_strip_multi_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, uint64_t label_mask,
                                int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "strip moves need phmrf_block_set_grid");
   PHMRF_CHECK(b->num_neighbor == 8 || b->num_neighbor == 4, PHMRF_ERR_STATE, "bad grid");
   PHMRF_CHECK(orient == 0 || orient == 1, PHMRF_ERR_INVALID, "orient must be 0 or 1");
@@ -1158,7 +1158,7 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
 int phmrf_mrf_coarse_pass(phmrf_block_t b, double beta, int scale, int offset, int alpha, int shift_r, int shift_c,
                           int64_t* changed) {
   PHMRF_TRY(check_solvable(b));
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   PHMRF_CHECK(b->has_grid, PHMRF_ERR_STATE, "coarse moves need phmrf_block_set_grid");
   PHMRF_CHECK(scale == 2 || scale == 4 || scale == 8, PHMRF_ERR_INVALID, "scale must be 2, 4 or 8");
   PHMRF_CHECK(offset >= 0 && offset < scale, PHMRF_ERR_INVALID, "offset must be in [0, scale)");
@@ -1255,7 +1255,7 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
   s->beta = beta;
   s->bf = (float)beta;
   s->sched_n = b->sched_n > 0 ? b->sched_n : b->n;
-  b->labels_are_slot = -1;                        // (whatever the solve does to the labels)
+  b->labels_are_slot = 0;                        // (whatever the solve does to the labels)
   struct Abort {                                  // a failure below leaves no half-begun solve behind
     phmrf_block* blk;
     bool armed = true;
@@ -1840,7 +1840,7 @@ int phmrf_block_tile_put_halo(phmrf_block_t b, const uint8_t* top_in, const uint
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   PHMRF_CHECK(b->tile_top || b->tile_bot, PHMRF_ERR_STATE, "the block is not a tile (phmrf_block_set_tile)");
   if (b->tick) ++b->tick;
-  b->labels_are_slot = -1;
+  b->labels_are_slot = 0;
   uint8_t* const in_host = b->xfer_host + b->xfer_cap;      // (the second half of the pinned buffer: the first holds the outgoing rows)
   int64_t off = 0;
   if (top_in && b->tile_top) {
@@ -1925,7 +1925,7 @@ int phmrf_kmeans_step(phmrf_block_t b, const double* centers, int write_labels, 
   std::memcpy(out, b->accum_host + 8, NP * sizeof(double));
   if (write_labels) {
     b->has_labels = true;
-    b->labels_are_slot = -1;
+    b->labels_are_slot = 0;
   }
   return PHMRF_OK;
 }
@@ -1949,7 +1949,7 @@ int phmrf_kmeans_moments(phmrf_block_t b, const double* centers, int write_label
   std::memcpy(out, b->accum_host + 8, NP * sizeof(double));
   if (write_labels) {
     b->has_labels = true;
-    b->labels_are_slot = -1;
+    b->labels_are_slot = 0;
   }
   return PHMRF_OK;
 }

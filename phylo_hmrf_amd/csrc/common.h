@@ -76,7 +76,7 @@ struct phmrf_block {
   int eval_tick = -1;                       //   ... and the launch tick then (-1: no evaluation in this solve yet)
   float* sgain = nullptr;                   // device [n]: cost of switching a node alone to its fusion proposal (launch_propose)
   uint8_t* saved[4] = {nullptr, nullptr, nullptr, nullptr};
-  int labels_are_slot = -1;                 // the current labels equal this snapshot (set by save / restore; -1 after anything that may write labels)
+  int labels_are_slot = 0;                  // bit k: the current labels equal snapshot k (set by save / restore; 0 after anything that may write labels)
   bool has_X = false, has_logprob = false, has_labels = false, has_graph = false, has_grid = false;
 
   int D = 0;

@@ -387,6 +387,10 @@ class phyloHMRF(_BaseGraph):
 
     # ---- b3 --------------------------------------------------------------------------------------
     def _compute_posteriors_graph(self, X, label, logprob, region_id):
+        if region_id in self.split_regions:
+            raise NotImplementedError("region %d is cut into row tiles held by several ranks: its posteriors come out of the "
+                                      "fit's E-step (fit_accumulate_test); construct the model with split_above=float('inf') "
+                                      "to keep every block whole" % region_id)
         b = self.blocks[region_id]
         b.set_logprob(logprob)
         b.set_labels(label)
