@@ -75,7 +75,8 @@ def slsqp_entry():
             sig = (slsqp.__doc__ or "").split("\n")[0].replace(" ", "")
             want = ("slsqp(m,meq,x,xl,xu,f,c,g,a,acc,iter,mode,w,jw,alpha,f0,gs,h1,h2,h3,h4,t,t0,tol,iexact,incons,ireset,"
                     "itermx,line,n1,n2,n3,[la,n,l_w,l_jw])")
-            if sig == want:
+            ver = tuple(int(x) for x in _scipy_version().split(".")[:2] if x.isdigit())
+            if sig == want and (1, 12) <= ver <= (1, 15):        # (the calling sequence this was written and tested for)
                 api = ctypes.pythonapi
                 api.PyCapsule_GetName.restype = ctypes.c_char_p
                 api.PyCapsule_GetName.argtypes = [ctypes.py_object]
@@ -384,7 +385,7 @@ def _mstep_native(tree, tasks, n_samples, lambda_0, n_threads, min_covar=1e-3):
     covariance turns ill-conditioned comes back flagged and is repeated by `_solve_state` (pseudo-inverse path).
     -> the list `_solve_state` would return, or None when the native loop is unavailable."""
     entry = slsqp_entry() if NATIVE_LOOP[0] else None
-    if entry is None:
+    if entry is None or not _native_self_check():
         return None
     nt = NativeTree(tree)
     K, P, S = len(tasks), tree.n_params, tree.n_features
@@ -465,10 +466,54 @@ def close_pool():
         _POOL = None
 
 
+_NATIVE_CHECKED = [None]      # None: not checked yet; True / False: the self-check's verdict
+
+
+def _native_self_check():
+    """Once per process: one small fixed state fitted by the native loop (SciPy's Fortran SLSQP core called through its raw
+    address from libphmrf_host.so) and by the Python loop over the same routine (`_slsqp_lean`).  The f2py signature string
+    and the SciPy version gate in `slsqp_entry` say the calling sequence SHOULD match; this says it DOES in this build of
+    SciPy (integer width, argument order, no hidden state): the iterates must agree to the last bit, otherwise the native
+    path is switched off for the process and the M-step runs the Python loop."""
+    if _NATIVE_CHECKED[0] is None:
+        ok = False
+        try:
+            from .tree import PhyloTree
+            tree = PhyloTree([[0, 1], [1, 2], [1, 3], [3, 4], [4, 5], [4, 6], [3, 7]])
+            rng = np.random.default_rng(12345)
+            S = tree.n_features
+            A = rng.standard_normal((S, S))
+            mu = rng.uniform(0.5, 3.0, S)
+            post = 1000.0
+            obj = OUObjective(tree, post, post * mu, post * (A @ A.T * 0.2 + 0.05 * np.eye(S) + np.outer(mu, mu)), 5000.0, 1.0)
+            x0 = np.clip(rng.uniform(0.1, 1.5, tree.n_params), LOWER, UPPER)
+            nat = _slsqp_native(obj, x0, LOWER, UPPER, acc=1e-6, maxiter=200)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = _slsqp_lean(obj.value_and_grad, x0, LOWER, UPPER, acc=1e-6, maxiter=200)
+            ok = nat is not None and ref is not None and nat[1] == ref[1] and np.array_equal(nat[0], ref[0])
+            if nat is not None and ref is not None and not ok:
+                warnings.warn("the native SLSQP loop does not reproduce scipy.optimize._slsqp.slsqp on the self-check problem "
+                              "(SciPy %s): the M-step uses the Python loop" % _scipy_version(), RuntimeWarning)
+        except Exception:
+            ok = False
+        _NATIVE_CHECKED[0] = ok
+    return _NATIVE_CHECKED[0]
+
+
+def _scipy_version():
+    try:
+        import scipy
+        return scipy.__version__
+    except Exception:
+        return "?"
+
+
 def native_available():
     """the M-step's native path (all states in one call of libphmrf_host.so on host threads) can be used in this process"""
     try:
-        return bool(NATIVE_MSTEP[0] and NATIVE_LOOP[0] and slsqp_entry() is not None and host_lib() is not None)
+        return bool(NATIVE_MSTEP[0] and NATIVE_LOOP[0] and slsqp_entry() is not None and host_lib() is not None
+                    and _native_self_check())
     except Exception:
         return False
 
