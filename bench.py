@@ -6,23 +6,28 @@
            bench.py --gpus N --steps K --warmup W
 
 A STEP is one full EM iteration over every syntenic block of the workload, exactly as fit_accumulate_test drives it
-(base.py:347-442): per block  labels <- labels_local, emission log-likelihoods, MRF labelling, posteriors + costs +
-sufficient statistics;  then the reduction of the statistics (one RCCL all-reduce when N > 1), the cost
-bookkeeping, and the host M-step (SciPy SLSQP over the OU parameters of every state; rank 0 + broadcast).
+(base.py:347-442): per block  emission log-likelihoods, labels <- labels_local or the previous labelling, whichever has
+the lower energy (--warm-start local: labels_local as the reference), MRF labelling, posteriors + costs + sufficient
+statistics;  then the reduction of the statistics (one RCCL all-reduce when N > 1), the cost bookkeeping, and the host
+M-step (SciPy's SLSQP over the OU parameters of every state; the states dealt to the ranks, one all-reduce of their rows).
 Inputs (X, graph) are resident in HBM before the timed region.  Metric (BASELINE.json):
 EM-iterations/sec x nodes = N_tot * steps / wall.
 
-Multi-GPU: the syntenic blocks are independent MRFs and are DEALT to the ranks, longest block first
-(phylo_hmrf_amd.dist.lpt_assign; the reference forks one process per block, base.py:357-362); a block lives on exactly
-one GPU, there is no data-path collective.  --scaling strong (default): the workload's blocks are shared out, total work
-fixed -- north_star's "whole-genome run ... at 8 GPUs" (bound by the largest block: 88.8 M / 12.4 M = 7.2x at 8 GPUs on
-cfg3).  --scaling weak: N copies of the workload (an N-genome cohort) are shared out the same way, work per GPU fixed.
+Multi-GPU: the syntenic blocks are independent MRFs and are DEALT to the ranks, longest first (the reference forks one
+process per block, base.py:357-362); a block that holds more than --split-above x a rank's share is cut into row tiles
+first (see the end of this text).  --scaling strong (default): the workload's units are shared out, total work fixed --
+north_star's "whole-genome run ... at 8 GPUs".  --scaling weak: N copies of the workload (an N-genome cohort) are shared
+out the same way, work per GPU fixed.
 
 Extra objects on the JSON line:
   "roofline"          the kernel class with the largest device time: algorithmic bytes (SURVEY.md 8d accounting x the
                       units the launches actually processed, COUNTED ON THE DEVICE) / the time during which at least one
                       kernel of the class was running (HIP events on the blocks' streams, merged on one time line, so the
-                      class's time per step can never exceed ms_per_step), against the 8 TB/s HBM peak.
+                      class's time per step can never exceed ms_per_step), against the 8 TB/s HBM peak.  In the timed region
+                      only this class carries events (the timers of all ten cost 4 - 5 ms per EM iteration); `kernels` is
+                      filled by an instrumented pass after it.  `kernel_frac_isolated`: the same bytes over a launch's OWN
+                      duration (one block at a time, after the timed region) -- the kernel's fraction, where `frac` is
+                      the class's throughput with up to fourteen launches overlapping.
   "roofline_limiter"  what actually bounds that kernel, from this run's device counters only (LDS bytes, pairs, cells, DP
                       steps); the explanation -- instruction issue of in-order waves at 4 waves per SIMD -- and the
                       measurements behind it are in DESIGN.md 3.3 and profiles/README.md.
