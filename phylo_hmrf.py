@@ -88,6 +88,8 @@ def cache_names(output_path, resolution, run_id, annot1="observed"):
 
 
 def write_cache(output_path, resolution, run_id, samples, edge_list_vec, len_vec):
+    if int(os.environ.get("RANK", "0")) != 0:      # (several ranks: every one builds the same data, rank 0 writes the cache)
+        return
     f1, f2, f3 = cache_names(output_path, resolution, run_id)
     np.save(f1, samples)
     arr = np.empty(len(edge_list_vec), dtype=object)
@@ -201,6 +203,25 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
 
     if method_mode == 1:
         from phylo_hmrf_amd.hmrf import phyloHMRF
+        # several GPUs: `python -m torch.distributed.run --nproc-per-node N phylo_hmrf.py ...` -- one process per GPU; the
+        # blocks (and row tiles of the ones larger than a GPU's share) are dealt to the ranks, every rank loads the data,
+        # rank 0 writes the result.  The process group is set up here, before anything touches the GPU.
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29519")
+                backend = os.environ.get("PHMRF_DIST_BACKEND", "nccl")
+                if backend == "nccl":
+                    local = 0 if os.environ.get("PHMRF_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+                    torch.cuda.set_device(local)
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+                else:
+                    dist.init_process_group(backend, rank=rank, world_size=world)
         tree1 = phyloHMRF(n_components=n_components1, run_id=run_id, n_samples=samples.shape[0],
                           n_features=samples[0].shape[-1], observation=samples, edge_list=edge_list, len_vec=len_vec,
                           type_id=version, branch_list=branch_list, edge_list_1=edge_list_vec, cons_param=cons_param,
@@ -218,10 +239,15 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
         mdict = {"state_vec": state_vec, "len_vec": np.asarray(len_vec), "params_vec1": params_vec1,
                  "params_vec2": params_vec2, "iter_id1": iter_id1, "iter_id2": iter_id2, "cost_vec": cost_vec}
         filename3 = "%s/estimate_ou_%d_%.2f_%d.mat" % (output_path, run_id, lambda_0, n_components1)
-        scipy.io.savemat(filename3, mdict)
+        if rank == 0:                                   # (every rank holds the same result: state_vec is all-reduced)
+            scipy.io.savemat(filename3, mdict)
         print(params_vecList.shape)
         tree1.close()
         mstep.close_pool()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
         return filename3
     mstep.close_pool()
     return None

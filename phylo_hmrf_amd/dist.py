@@ -13,7 +13,10 @@ import numpy as np
 
 
 def env_rank_world():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    """(rank, world size, this rank's device) from the launcher's environment.  PHMRF_ONE_GPU=1 (tests): every rank on
+    device 0 -- the sharded path on one card, over gloo (RCCL refuses two ranks on one device)"""
+    local = 0 if os.environ.get("PHMRF_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), local
 
 
 def lpt_assign(sizes, world):

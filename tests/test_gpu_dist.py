@@ -205,3 +205,24 @@ def test_bench_two_ranks_on_one_gpu_shards_the_blocks(tmp_path):
     #  chaotic afterwards, see the fit tests)
     np.testing.assert_allclose(d2["cost1"], d1["cost1"], rtol=6e-2, atol=5e-3)
     assert d2["fit"]["iterations"] >= 6 and d1["fit"]["iterations"] >= 6
+
+
+def test_cli_under_torchrun_two_ranks_one_block_in_two_tiles(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 phylo_hmrf.py --synthetic 64 ...`: the reference's command line on
+    two ranks (both on GPU 0, over gloo).  The one synthetic block (2,080 nodes) is more than a rank's share, so it is cut
+    into two row tiles, one per rank, built from the host edge list; rank 0 writes the reference's .mat."""
+    import scipy.io
+    out = str(tmp_path)
+    env = dict(os.environ, PHMRF_ONE_GPU="1", PHMRF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29771", os.path.join(ROOT, "phylo_hmrf.py"), "-n", "5", "-r", "3", "--miter", "6", "--output", out,
+           "--synthetic", "64", "--seed", "7", "-g", "3", "--quiet", "1"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    d = scipy.io.loadmat(os.path.join(out, "estimate_ou_3_1.00_5.mat"))
+    n = 64 * 65 // 2
+    assert d["state_vec"].size == n and d["params_vec1"].shape == (5, 23)
+    cv = d["cost_vec"]
+    assert cv.shape[1] == 4 and 1 <= cv.shape[0] <= 6 and np.all(np.isfinite(cv))
+    lab = d["state_vec"].ravel()
+    assert lab.min() >= 0 and lab.max() < 5 and len(np.unique(lab)) >= 2
