@@ -631,6 +631,9 @@ def main():
                                "dealt to the ranks, %d of them on %d host threads here)" % (len(my_states), workers),
                        "mrf_solver": dict(solver, warm_start=a.warm_start)},
             "estep_ms": float(np.mean(t_e_timed) * 1e3), "mstep_ms": float(np.mean(t_m_timed) * 1e3),
+            # the E-step of every timed step (ms, this rank): warm-started label solves make the steps unequal -- an
+            # iteration that renews labels_local or restarts from it moves more labels than the one after it
+            "estep_ms_by_step": [round(x * 1e3, 1) for x in t_e_timed],
             "cold_first_iteration_ms": cold_first_ms,
             "fit": fit,
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)

@@ -1097,6 +1097,7 @@ static int coarse_child(phmrf_block_t b, int level_slot, phmrf_block** out) {   
     c->has_graph = true;
     c->has_logprob = true;
     c->D = 0;
+    c->unary_pins = true;
     b->coarse[level_slot] = c;
   }
   b->coarse[level_slot]->stream = b->stream;
@@ -1119,6 +1120,7 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   static const int batch_env = getenv("PHMRF_COARSE_BATCH") ? atoi(getenv("PHMRF_COARSE_BATCH")) : 4;
   const int batch = (batch_env == 1 || batch_env == 2) ? batch_env : 4;
   static const bool no_gate = getenv("PHMRF_COARSE_NO_GATE") != nullptr;      // development: A/B timing
+  static const bool no_stamp_gate = getenv("PHMRF_COARSE_NO_STAMP_GATE") != nullptr;
   phmrf_block* ch[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int q = 0; q < batch; ++q) PHMRF_TRY(coarse_child(b, level * 4 + q, &ch[q]));
   if (!b->coarse_flag) PHMRF_TRY(dev_alloc(&b->coarse_flag, (size_t)1));
@@ -1134,13 +1136,16 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
       ch[q]->counter_slot = 0;
       PHMRF_HIP(hipMemsetAsync(ch[q]->counters, 0, sizeof(unsigned long long), b->stream));
     }
-    PHMRF_TRY(launch_coarsen_batch(b, ch, alphas, nl == 3 ? 3 : nl, s, off, beta, nullptr));
+    PHMRF_TRY(launch_coarsen_batch(b, ch, alphas, nl == 3 ? 3 : nl, s, off, beta, nullptr, -1));
+    // (inside a solve the change stamps say WHERE the labels before a label in the batch have moved: its rebuild touches
+    //  those wavefronts only -- every apply pass below stamps with a tick later than this one)
+    const int since = (b->tick && !no_stamp_gate) ? b->tick : -1;
     ++n_launch;
     for (int q = 0; q < nl; ++q) {
       phmrf_block* c = ch[q];
       if (q > 0) {        // rebuilt only if a label before it in the batch has moved (b->coarse_flag, read on the device)
         phmrf_block* one[1] = {c};
-        PHMRF_TRY(launch_coarsen_batch(b, one, &alphas[q], 1, s, off, beta, b->coarse_flag));
+        PHMRF_TRY(launch_coarsen_batch(b, one, &alphas[q], 1, s, off, beta, b->coarse_flag, since));
         ++n_launch;
       }
       // (measured: the filtered multi-label kernel is 15-20 % slower than the plain one on these one-label problems)
@@ -1668,6 +1673,22 @@ int solve_end(phmrf_block_t b, phmrf_solve_result* res) {
     res->rounds = s->rounds;
     res->converged = s->converged;
     res->changed = s->total;
+  }
+  static const bool child_count = getenv("PHMRF_CHILD_COUNT") != nullptr;     // development (with PHMRF_SOLVE_TRACE)
+  if (child_count) {
+    (void)hipStreamSynchronize(b->stream);
+    for (int lv = 0; lv < 3; ++lv) {
+      unsigned long long tot[5] = {0, 0, 0, 0, 0};
+      for (int q = 0; q < 4; ++q) {
+        if (!b->coarse[lv * 4 + q]) continue;
+        unsigned long long c[5];
+        // (a child's passes run with alpha = 1, counter slot 0: strip_kernel's counters 100.. land at 91..)
+        if (hipMemcpy(c, b->coarse[lv * 4 + q]->counters + 91, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) continue;
+        for (int x = 0; x < 5; ++x) tot[x] += c[x];
+      }
+      fprintf(stderr, "[phmrf solve] coarse scale %d child strips: seen %llu, past the memo and the pin look %llu, into the DP %llu, DP steps %llu, with a move %llu\n",
+              lv == 0 ? 2 : (lv == 1 ? 4 : 8), tot[0], tot[1], tot[2], tot[3], tot[4]);
+    }
   }
   solve_scope_exit(b);
   return st;

@@ -21,6 +21,8 @@
 // super-cells = 10..20 rows x 126..252 columns of nodes.  Its energy never goes above 0 = "nobody switches", so the
 // fine labelling's energy never goes up.  (Model: oracle/mrf_moves.coarse_problem / coarse_expansion.)
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace phmrf {
@@ -67,16 +69,20 @@ struct CoarseOut {
   int nl;
 };
 
+// Loads first (round 4): the labels of the node and of its eight neighbours, its own forward-edge record, the ONE weight
+// of each backward neighbour's record that belongs to the shared edge and the unary terms are all requested before the
+// first of them is used -- an absent neighbour reads the node itself and gets weight 0, which adds exact zeros where the
+// first version of this kernel skipped the edge behind a branch (and waited for one load after the other: 373 - 423 us
+// per pass on the 12.4 M-node block for ~0.5 GB, a quarter of what HBM allows).  The sums are formed in the same order.
 template <int SCALE, int NL>
-__global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, int64_t nc, const uint8_t* __restrict__ labels,
-                                                      const float* __restrict__ uT, const float4* __restrict__ fwd_w,
-                                                      CoarseOut out, float beta, const unsigned int* __restrict__ rebuild) {
-  if (rebuild && *rebuild == 0u) return;        // nothing has moved since the batch built this label's problem
-  const int I = blockIdx.y;
+__device__ __forceinline__ void coarsen_row(const CoarseGeom& g, int I, int64_t n, int64_t nc, const uint8_t* __restrict__ labels,
+                                            const float* __restrict__ uT, const float4* __restrict__ fwd_w, const CoarseOut& out,
+                                            float beta) {
   const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x) - g.off;      // (j + off) % SCALE == lane % SCALE
   const int J = (int)(blockIdx.x * blockDim.x + threadIdx.x) / SCALE;
   constexpr int FI[4] = {0, 1, 1, 1};
   constexpr int FJ[4] = {1, -1, 0, 1};
+  const float* __restrict__ fwd_s = reinterpret_cast<const float*>(fwd_w);
   float D[NL], lam[NL][4];
 #pragma unroll
   for (int q = 0; q < NL; ++q) {
@@ -90,21 +96,42 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
     const int i = I * SCALE - g.off + di;
     const int node = fine_node(g, i, j);
     if (node < 0) continue;
+    // ---- addresses, then every load of this node ----
+    int fnn[4], bnn[4], fdI[4], fdJ[4], bdI[4], bdJ[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ni = i + FI[e], nj = j + FJ[e];
+      fnn[e] = fine_node(g, ni, nj);
+      fdI[e] = (ni + g.off) / SCALE - I;
+      fdJ[e] = (nj + g.off) / SCALE - J;
+      const int mi = i - FI[e], mj = j - FJ[e];
+      bdI[e] = (mi + g.off) / SCALE - I;
+      bdJ[e] = (mj + g.off) / SCALE - J;
+      // (a backward neighbour inside this super-cell is counted from the holder, not here)
+      bnn[e] = (mi < 0 || mj < 0 || (bdI[e] == 0 && bdJ[e] == 0)) ? -1 : fine_node(g, mi, mj);
+    }
     const int li = labels[node];
+    const float4 fw = fwd_w[node];
+    int lf[4], lb[4];
+    float wb[4], ua[NL];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lf[e] = labels[fnn[e] >= 0 ? fnn[e] : node];
+      lb[e] = labels[bnn[e] >= 0 ? bnn[e] : node];
+      wb[e] = fwd_s[4 * (int64_t)(bnn[e] >= 0 ? bnn[e] : node) + e];
+    }
+#pragma unroll
+    for (int q = 0; q < NL; ++q) ua[q] = uT[(int64_t)out.alpha[q] * n + node];
     const float ucur = uT[(int64_t)li * n + node];
+    // ---- the sums, in the order of the first version ----
 #pragma unroll
     for (int q = 0; q < NL; ++q)
-      if (li != out.alpha[q]) D[q] += uT[(int64_t)out.alpha[q] * n + node] - ucur;
-    const float4 fw = fwd_w[node];
+      if (li != out.alpha[q]) D[q] += ua[q] - ucur;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {           // edges this node holds
-      const float w = comp4(fw, e);
-      if (w == 0.f) continue;
-      const int ni = i + FI[e], nj = j + FJ[e];
-      const int nn = fine_node(g, ni, nj);
-      if (nn < 0) continue;
-      const int lj = labels[nn];
-      const int dI = (ni + g.off) / SCALE - I, dJ = (nj + g.off) / SCALE - J;
+      const float w = fnn[e] >= 0 ? comp4(fw, e) : 0.f;
+      const int lj = lf[e];
+      const int dI = fdI[e], dJ = fdJ[e];
       const bool inside = dI == 0 && dJ == 0;
       if (!inside) wcross += w;
 #pragma unroll
@@ -124,15 +151,9 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {           // edges held by the four backward neighbours
-      const int ni = i - FI[e], nj = j - FJ[e];
-      if (ni < 0 || nj < 0) continue;
-      const int dI = (ni + g.off) / SCALE - I, dJ = (nj + g.off) / SCALE - J;
-      if (dI == 0 && dJ == 0) continue;               // inside this super-cell: counted from the holder
-      const int nn = fine_node(g, ni, nj);
-      if (nn < 0) continue;
-      const float w = comp4(fwd_w[nn], e);
-      if (w == 0.f) continue;
-      const int lj = labels[nn];                      // holder nn = "i" of the table, this node = "j"
+      const float w = bnn[e] >= 0 ? wb[e] : 0.f;
+      const int lj = lb[e];                           // holder = "i" of the table, this node = "j"
+      const int dI = bdI[e], dJ = bdJ[e];
       wcross += w;
 #pragma unroll
       for (int q = 0; q < NL; ++q) {
@@ -163,10 +184,37 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
     out.c_uT[q][c] = 0.f;
     // A super-cell whose switch cost exceeds everything its pairs could give back (lambda <= w on every cross edge) is in
     // no optimal switch set: taking it out of any set lowers the energy.  It is pinned (strip.hip: unary >= 1e29 = no
-    // proposal), and a strip of pinned super-cells costs the strip kernel its staging only.
+    // proposal), and a strip of pinned super-cells costs the strip kernel one look at the unary plane.
     out.c_uT[q][nc + c] = (D[q] > beta * wcross * 1.0001f + 1e-6f) ? 1.0e30f : D[q];
     out.c_fwd[q][c] = make_float4(lam[q][0], lam[q][1], lam[q][2], lam[q][3]);
     out.c_labels[q][c] = 0;
+  }
+}
+
+// rebuild != nullptr: the problem of ONE label of a batch, built again after a label before it in the batch has moved
+// (*rebuild, raised by coarse_apply_kernel) -- and then only where the labelling has changed: a wavefront whose nodes carry
+// no change stamp later than `since` (the tick of the batch's pass; the stamps are dilated, so a change next to a super-cell
+// marks nodes inside it) would write the numbers that are there already, and returns after reading its stamps
+// (2 bytes per node instead of ~40).  The rows of the coarse grid are strided over the launch's gridDim.y, so that a pass
+// that has nothing to do is a small launch.
+template <int SCALE, int NL>
+__global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, int64_t nc, const uint8_t* __restrict__ labels,
+                                                      const float* __restrict__ uT, const float4* __restrict__ fwd_w,
+                                                      CoarseOut out, float beta, const unsigned int* __restrict__ rebuild,
+                                                      const uint16_t* __restrict__ stamp, int since) {
+  if (rebuild && *rebuild == 0u) return;        // nothing has moved since the batch built this label's problem
+  for (int I = blockIdx.y; I < g.Hc; I += gridDim.y) {
+    if (stamp) {
+      const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x) - g.off;
+      bool dirty = false;
+#pragma unroll
+      for (int di = 0; di < SCALE; ++di) {
+        const int node = fine_node(g, I * SCALE - g.off + di, j);
+        if (node >= 0) dirty = dirty || (int)stamp[node] > since;
+      }
+      if (!__ballot(dirty)) continue;           // (wave-uniform: the butterfly below stays inside the wave)
+    }
+    coarsen_row<SCALE, NL>(g, I, n, nc, labels, uT, fwd_w, out, beta);
   }
 }
 
@@ -179,26 +227,28 @@ __global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const u
                                                            unsigned int* __restrict__ moved_flag) {
   if (gate && *gate == 0ull) return;            // the child's passes switched no super-cell: nothing to take over
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y * blockDim.y + threadIdx.y;
-  bool moved = false;
-  const int node = fine_node(g, i, j);
-  if (node >= 0) {
-    const int c = coarse_node(g, (i + g.off) / g.s, (j + g.off) / g.s);
-    if (c_labels[c] && labels[node] != alpha) {
-      labels[node] = (uint8_t)alpha;
-      if (stamp) {
-        stamp[node] = (uint16_t)tick;
-        const int32_t* nb = nbr + (int64_t)node * D;
-        for (int x = 0; x < D; ++x)
-          if (nb[x] >= 0) stamp[nb[x]] = (uint16_t)tick;
+  // (row groups strided over gridDim.y: the launch that finds the gate down -- most of them -- is a small one)
+  for (int i = blockIdx.y * blockDim.y + threadIdx.y; i < g.H; i += gridDim.y * blockDim.y) {
+    bool moved = false;
+    const int node = fine_node(g, i, j);
+    if (node >= 0) {
+      const int c = coarse_node(g, (i + g.off) / g.s, (j + g.off) / g.s);
+      if (c_labels[c] && labels[node] != alpha) {
+        labels[node] = (uint8_t)alpha;
+        if (stamp) {
+          stamp[node] = (uint16_t)tick;
+          const int32_t* nb = nbr + (int64_t)node * D;
+          for (int x = 0; x < D; ++x)
+            if (nb[x] >= 0) stamp[nb[x]] = (uint16_t)tick;
+        }
+        moved = true;
       }
-      moved = true;
     }
-  }
-  const unsigned long long m = __ballot(moved);
-  if ((threadIdx.x & 63) == 0 && m) {
-    atomicAdd(changed, (unsigned long long)__popcll(m));
-    if (moved_flag) *moved_flag = 1u;           // the labelling has changed: later labels of the batch rebuild their problems
+    const unsigned long long m = __ballot(moved);
+    if ((threadIdx.x & 63) == 0 && m) {
+      atomicAdd(changed, (unsigned long long)__popcll(m));
+      if (moved_flag) *moved_flag = 1u;         // the labelling has changed: later labels of the batch rebuild their problems
+    }
   }
 }
 
@@ -225,7 +275,7 @@ int64_t coarse_nodes(const phmrf_block* b, int s, int off) {
 // Point the child blocks at the coarse grid of (s, off) and fill their unary planes / forward weights / labels for up to
 // four labels in one pass (alphas[q] < 0: unused).  rebuild != nullptr: the pass runs only if *rebuild != 0 (device).
 int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, const int* alphas, int nl, int s, int off, float beta,
-                         const unsigned int* rebuild) {
+                         const unsigned int* rebuild, int since) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
   CoarseOut out;
   for (int q = 0; q < 4; ++q) {
@@ -243,9 +293,15 @@ int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, con
   }
   out.nl = nl;
   const int64_t nc = children[0]->n;
-  const dim3 blk(256), grd((g.Wc * s + 255) / 256, g.Hc);
+  // a rebuild (one label, gated on the device) strides the coarse rows over <= ~2048 workgroups; `since` >= 0 with change
+  // stamps at hand (inside a solve): only the wavefronts whose nodes changed after that tick do the work
+  const int gx = (g.Wc * s + 255) / 256;
+  const int gy = rebuild ? std::max(1, std::min(g.Hc, 2048 / gx)) : g.Hc;
+  const dim3 blk(256), grd(gx, gy);
+  const uint16_t* stamp = (rebuild && since >= 0 && b->tick && b->stamp) ? b->stamp : nullptr;
 #define PHMRF_LAUNCH_COARSEN(S_, NL_)                                                                                     \
-  hipLaunchKernelGGL((coarsen_kernel<S_, NL_>), grd, blk, 0, b->stream, g, b->n, nc, b->labels, b->uT, b->fwd_w, out, beta, rebuild)
+  hipLaunchKernelGGL((coarsen_kernel<S_, NL_>), grd, blk, 0, b->stream, g, b->n, nc, b->labels, b->uT, b->fwd_w, out, beta, \
+                     rebuild, stamp, since)
 #define PHMRF_LAUNCH_COARSEN_S(S_)                                                                                        \
   {                                                                                                                       \
     if (nl == 1) PHMRF_LAUNCH_COARSEN(S_, 1);                                                                             \
@@ -263,13 +319,14 @@ int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, con
 
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta) {
   phmrf_block* one[1] = {child};
-  return launch_coarsen_batch(b, one, &alpha, 1, s, off, beta, nullptr);
+  return launch_coarsen_batch(b, one, &alpha, 1, s, off, beta, nullptr, -1);
 }
 
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate,
                         unsigned int* moved_flag) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
-  const dim3 blk(64, 4), grd((g.W + 63) / 64, (g.H + 3) / 4);
+  const int gx = (g.W + 63) / 64;
+  const dim3 blk(64, 4), grd(gx, std::max(1, std::min((g.H + 3) / 4, (gate ? 2048 : (1 << 20)) / gx)));
   hipLaunchKernelGGL(coarse_apply_kernel, grd, blk, 0, b->stream, g, child->labels, alpha, b->labels,
                      b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot, gate, moved_flag);
   PHMRF_HIP(hipGetLastError());

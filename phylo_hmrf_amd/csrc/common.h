@@ -106,6 +106,7 @@ struct phmrf_block {
   float4* fwd_w = nullptr;                  // device [n]: weights of the four forward grid edges (E, SW, S, SE)
   float* uT = nullptr;                      // device [K][n]: unary planes, uT[k][i] = -logprob[i][k]
   bool uT_valid = false;                    //   ... current with logprob
+  bool unary_pins = false;                  // a coarse child problem: unary terms >= 1e29 pin a cell (strip_kernel looks first)
   // coarse alpha-expansions (coarse.hip): child blocks holding the two-label problem of the super-cells, side 2, 4, 8
   phmrf_block* coarse[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [level * 4 + slot in a batch of labels]
   unsigned int* coarse_flag = nullptr;      // device: set by coarse_apply_kernel when a label of the batch has moved
@@ -239,7 +240,7 @@ int launch_fwd_weights(phmrf_block* b);                                         
 int64_t coarse_nodes(const phmrf_block* b, int s, int off);                        // nodes of the coarse grid (s, off)
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta);
 int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, const int* alphas, int nl, int s, int off, float beta,
-                         const unsigned int* rebuild);
+                         const unsigned int* rebuild, int since);
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr,
                         unsigned int* moved_flag = nullptr);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT

@@ -354,8 +354,30 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
       }
     }
 
-    if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
     if (debug == 16) continue;           // timing experiments: launch + memo + mask only
+    // ---- the coarse child problems (debug & 32: two labels, keep = 0 with unary term 0 everywhere, switch = alpha with the
+    //      super-cell's switch cost D, which coarsen_kernel sets to >= 1e29 where a switch can never pay): step B's test
+    //      "does any cell of the strip propose a switch" made on the unary plane alone, before the strip is staged.  And
+    //      while no super-cell of the problem has switched yet (*changed == 0: the first pass, and the second after a quiet
+    //      first -- 3,599 strips in 3,600), every cell in and around the strip is at "keep", every pair term is >= 0, and a
+    //      switch set costs the sum of its D's plus its cut: with no D < 0 in the strip nothing beats all-keep (cost 0,
+    //      which the DP's own tie rule prefers), so only strips that hold a NEGATIVE switch cost go on -- measured on the
+    //      cold solve of the 12.4 M-node block: half of all child strips went through the DP over 276 of their 315 cells,
+    //      one in 3,600 found a move.
+    if ((debug & 32) && alpha >= 0 && !prop) {
+      const float below = (*changed == 0ull) ? 0.f : 1.0e29f;
+      bool any = false;
+      for (int e = lane; e < ncell; e += 64) {
+        const int cc = e / SH, rr = e - cc * SH;
+        const int node = strip_node(g, rs0 + rr, ca + cc);
+        if (node >= 0) any = any || (labels[node] != alpha && uT[(int64_t)alpha * n + node] < below);
+      }
+      if (!__ballot(any)) {
+        if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+        continue;
+      }
+    }
+    if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1
     if (lane == 0) {
       atomicAdd(&wk[0], 1u);
       atomicAdd(&wk[1], (unsigned int)ncell);                  // nodes this unit re-decides
@@ -2424,10 +2446,13 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
     PHMRF_HIP(hipGetLastError());
     return PHMRF_OK;
   }
+  static const bool no_pin_look = getenv("PHMRF_NO_PIN_LOOK") != nullptr;      // development: A/B timing
+  static const bool child_count = getenv("PHMRF_CHILD_COUNT") != nullptr;     // development: strips seen / staged / into the DP
+  const int pin_look = b->unary_pins ? ((no_pin_look ? 0 : 32) | (child_count ? 4 : 0)) : 0;   // (coarse child problems)
 #define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
   hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
                      b->labels, alpha < 0 ? b->labels_tmp : nullptr, alpha, beta, b->counters + b->counter_slot,       \
-                     (alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3),               \
+                     ((alpha >= 0 && b->counter_slot == 8 + alpha) ? strip_debug() : (strip_debug() & 3)) | pin_look,  \
                      b->tick ? b->stamp : nullptr,                                                                     \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
                      b->tick, b->work_acc)

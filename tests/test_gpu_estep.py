@@ -829,6 +829,27 @@ def test_coarse_labels_in_batches_give_the_one_by_one_sequence():
     assert runs[0][1] >= 3                       # (several rounds: the coarse scales did run)
 
 
+def test_coarse_shortcuts_leave_the_labellings_alone():
+    """Round 4: a label's problem is rebuilt only in the wavefronts whose nodes carry a change stamp later than the batch's
+    pass (coarsen_kernel; PHMRF_COARSE_NO_STAMP_GATE=1: everywhere), and a child strip is staged only if it holds a
+    super-cell that proposes a switch -- a NEGATIVE switch cost while nothing has switched yet (strip_kernel, debug & 32;
+    PHMRF_NO_PIN_LOOK=1: every strip is staged and walked).  Both are exact: with PHMRF_DETERMINISTIC=1 the cold-start script
+    gives the same label hash, round count and energy with and without them, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for extra in ({}, {"PHMRF_COARSE_NO_STAMP_GATE": "1"}, {"PHMRF_NO_PIN_LOOK": "1"}):
+        env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", **extra)
+        out = subprocess.run([sys.executable, "-c", DET_SCRIPT.replace("range(3)", "range(1)")], capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        runs.append(eval(line[len("RESULT"):])[0])
+    assert runs[0] == runs[1] == runs[2], runs
+    assert runs[0][1] >= 3
+
+
 @pytest.mark.parametrize("H,W,diagonal", [(520, 610, False), (800, 800, True)])
 def test_energy_of_later_rounds_from_the_touched_nodes_equals_the_full_pass(H, W, diagonal):
     """From its second round on a solve of a large grid block adds the CHANGE of the energy on the nodes the round's moves
