@@ -1129,14 +1129,11 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   for (int a0 = alpha_lo; a0 < alpha_hi; a0 += batch) {
     const int nl = std::min(batch, alpha_hi - a0);
     int alphas[4] = {a0, a0 + 1, a0 + 2, a0 + 3};
-    PHMRF_HIP(hipMemsetAsync(b->coarse_flag, 0, sizeof(unsigned int), b->stream));
     // The apply pass (a thread per fine node) returns at once when the child's two passes switched no super-cell: the
-    // child counts its switches in its own counter slot 0, and the apply kernel reads it on the device.
-    for (int q = 0; q < nl; ++q) {
-      ch[q]->counter_slot = 0;
-      PHMRF_HIP(hipMemsetAsync(ch[q]->counters, 0, sizeof(unsigned long long), b->stream));
-    }
-    PHMRF_TRY(launch_coarsen_batch(b, ch, alphas, nl == 3 ? 3 : nl, s, off, beta, nullptr, -1));
+    // child counts its switches in its own counter slot 0, and the apply kernel reads it on the device.  (The batch's pass
+    // zeroes those counters and the block's moved-flag itself.)
+    for (int q = 0; q < nl; ++q) ch[q]->counter_slot = 0;
+    PHMRF_TRY(launch_coarsen_batch(b, ch, alphas, nl == 3 ? 3 : nl, s, off, beta, nullptr, -1, true));
     // (inside a solve the change stamps say WHERE the labels before a label in the batch have moved: its rebuild touches
     //  those wavefronts only -- every apply pass below stamps with a tick later than this one)
     const int since = (b->tick && !no_stamp_gate) ? b->tick : -1;
@@ -1145,7 +1142,7 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
       phmrf_block* c = ch[q];
       if (q > 0) {        // rebuilt only if a label before it in the batch has moved (b->coarse_flag, read on the device)
         phmrf_block* one[1] = {c};
-        PHMRF_TRY(launch_coarsen_batch(b, one, &alphas[q], 1, s, off, beta, b->coarse_flag, since));
+        PHMRF_TRY(launch_coarsen_batch(b, one, &alphas[q], 1, s, off, beta, b->coarse_flag, since, false));
         ++n_launch;
       }
       // (measured: the filtered multi-label kernel is 15-20 % slower than the plain one on these one-label problems)

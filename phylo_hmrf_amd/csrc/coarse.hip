@@ -67,6 +67,11 @@ struct CoarseOut {
   uint8_t* c_labels[4];
   int alpha[4];      // (slots past nl repeat the first label: computed, not written)
   int nl;
+  // the batch's pass also resets what its labels count with: each child's switch counter (the gate of its apply pass and
+  // of strip_kernel's look) and the block's "a label of this batch has moved" flag -- five 8-byte memsets per batch were
+  // five launches per batch, 9,000 of the 42,000 launches of a cold EM iteration of the whole-genome workload
+  unsigned long long* c_counter[4];
+  unsigned int* moved_flag;
 };
 
 // Loads first (round 4): the labels of the node and of its eight neighbours, its own forward-edge record, the ONE weight
@@ -203,6 +208,11 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
                                                       CoarseOut out, float beta, const unsigned int* __restrict__ rebuild,
                                                       const uint16_t* __restrict__ stamp, int since) {
   if (rebuild && *rebuild == 0u) return;        // nothing has moved since the batch built this label's problem
+  if (!rebuild && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (out.moved_flag) *out.moved_flag = 0u;
+    for (int q = 0; q < out.nl; ++q)
+      if (out.c_counter[q]) *out.c_counter[q] = 0ull;
+  }
   for (int I = blockIdx.y; I < g.Hc; I += gridDim.y) {
     if (stamp) {
       const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x) - g.off;
@@ -275,7 +285,7 @@ int64_t coarse_nodes(const phmrf_block* b, int s, int off) {
 // Point the child blocks at the coarse grid of (s, off) and fill their unary planes / forward weights / labels for up to
 // four labels in one pass (alphas[q] < 0: unused).  rebuild != nullptr: the pass runs only if *rebuild != 0 (device).
 int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, const int* alphas, int nl, int s, int off, float beta,
-                         const unsigned int* rebuild, int since) {
+                         const unsigned int* rebuild, int since, bool reset) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
   CoarseOut out;
   for (int q = 0; q < 4; ++q) {
@@ -290,7 +300,9 @@ int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, con
     out.c_fwd[q] = child->fwd_w;
     out.c_labels[q] = child->labels;
     out.alpha[q] = q < nl ? alphas[q] : alphas[0];
+    out.c_counter[q] = (q < nl && reset) ? child->counters : nullptr;
   }
+  out.moved_flag = reset ? b->coarse_flag : nullptr;
   out.nl = nl;
   const int64_t nc = children[0]->n;
   // a rebuild (one label, gated on the device) strides the coarse rows over <= ~2048 workgroups; `since` >= 0 with change
@@ -319,7 +331,7 @@ int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, con
 
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta) {
   phmrf_block* one[1] = {child};
-  return launch_coarsen_batch(b, one, &alpha, 1, s, off, beta, nullptr, -1);
+  return launch_coarsen_batch(b, one, &alpha, 1, s, off, beta, nullptr, -1, false);
 }
 
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate,

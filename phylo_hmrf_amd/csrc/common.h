@@ -240,7 +240,7 @@ int launch_fwd_weights(phmrf_block* b);                                         
 int64_t coarse_nodes(const phmrf_block* b, int s, int off);                        // nodes of the coarse grid (s, off)
 int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int alpha, float beta);
 int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, const int* alphas, int nl, int s, int off, float beta,
-                         const unsigned int* rebuild, int since);
+                         const unsigned int* rebuild, int since, bool reset);
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr,
                         unsigned int* moved_flag = nullptr);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
