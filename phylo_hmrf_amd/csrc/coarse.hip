@@ -107,10 +107,11 @@ __device__ __forceinline__ void coarsen_row(const CoarseGeom& g, int I, int64_t 
     for (int e = 0; e < 4; ++e) {
       const int ni = i + FI[e], nj = j + FJ[e];
       fnn[e] = fine_node(g, ni, nj);
-      fdI[e] = (ni + g.off) / SCALE - I;
+      // (row offsets of the neighbours' super-cells are known per unrolled trip: i + off = I * SCALE + di)
+      fdI[e] = (di + FI[e]) / SCALE;
       fdJ[e] = (nj + g.off) / SCALE - J;
       const int mi = i - FI[e], mj = j - FJ[e];
-      bdI[e] = (mi + g.off) / SCALE - I;
+      bdI[e] = (di - FI[e] < 0) ? -1 : 0;
       bdJ[e] = (mj + g.off) / SCALE - J;
       // (a backward neighbour inside this super-cell is counted from the holder, not here)
       bnn[e] = (mi < 0 || mj < 0 || (bdI[e] == 0 && bdJ[e] == 0)) ? -1 : fine_node(g, mi, mj);
