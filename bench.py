@@ -634,6 +634,9 @@ def main():
             # the E-step of every timed step (ms, this rank): warm-started label solves make the steps unequal -- an
             # iteration that renews labels_local or restarts from it moves more labels than the one after it
             "estep_ms_by_step": [round(x * 1e3, 1) for x in t_e_timed],
+            # (not the metric: `value` is units / the whole timed region; the median step tells a window that caught a far-off
+            #  iteration from one that did not)
+            "ms_per_step_median": float(np.median(np.asarray(t_e_timed) + np.asarray(t_m_timed)) * 1e3),
             "cold_first_iteration_ms": cold_first_ms,
             "fit": fit,
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
