@@ -207,6 +207,26 @@ def test_bench_two_ranks_on_one_gpu_shards_the_blocks(tmp_path):
     assert d2["fit"]["iterations"] >= 6 and d1["fit"]["iterations"] >= 6
 
 
+def test_bench_four_ranks_on_one_gpu_two_split_blocks_on_disjoint_rank_pairs(tmp_path):
+    """bench.py --gpus 4 under torch.distributed.run, all four ranks on device 0 over gloo, the small workload: each of its
+    two blocks holds more than a rank's share and is cut into row tiles (2 and 3), dealt longest first so that block 0 sits
+    on ranks 0 and 1 and block 1 on ranks 2 and 3 -- the shape of the 8-GPU deal of the whole-genome workload: every rank
+    creates both tile groups and is a bystander of one of them, the tiles' lockstep rounds run inside each pair, the
+    statistics and the dealt M-step (5 states on 4 ranks) go through the world."""
+    env = dict(os.environ, PHMRF_ONE_GPU="1", PHMRF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29757", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "small", "--steps", "2",
+           "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    n0, n1 = 300 * 301 // 2, 200 * 260
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong"
+    assert sorted(d["config"]["units_per_rank"]) == [1, 1, 1, 2] and sum(d["config"]["nodes_per_rank"]) == n0 + n1
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["fit"]["iterations"] >= 6
+    assert all(np.isfinite(c) for c in d["cost1"])
+
+
 def test_cli_under_torchrun_two_ranks_one_block_in_two_tiles(tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 phylo_hmrf.py --synthetic 64 ...`: the reference's command line on
     two ranks (both on GPU 0, over gloo).  The one synthetic block (2,080 nodes) is more than a rank's share, so it is cut

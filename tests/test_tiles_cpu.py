@@ -130,3 +130,76 @@ def test_tiles_of_one_block_on_two_ranks_over_gloo(tmp_path):
     assert sorted(got) == [0, 1, 2]
     for t in range(3):
         assert np.array_equal(got[t], want[t])
+
+
+WORKER4 = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from phylo_hmrf_amd import tiles
+from tests.test_tiles_cpu import _problem, _make_group, _solve
+H, W, diag, K, parts = 48, 48, True, 5, 2
+OWNERS = {0: [2, 3], 1: [1, 0]}                      # block 0 on ranks 2 and 3, block 1 on ranks 1 and 0 (top tile on rank 1)
+out, groups = {}, []
+for bi in (0, 1):                                    # every rank creates every group, in block order (new_group is collective)
+    comm = tiles.GroupComm(OWNERS[bi], None)
+    if rank not in OWNERS[bi]:
+        continue
+    blk, lp, w, eid, init = _problem(H, W, diag, K, seed=3 + bi)
+    groups.append((bi, _make_group(blk, lp, init, H, W, diag, K, parts, OWNERS[bi], rank, comm)))
+for bi, g in groups:
+    res, energies = _solve(g)
+    out[str(bi)] = dict(labels={str(t): tl.b.get_labels()[tl.owned_local_slice()].tolist() for t, tl in g.local.items()},
+                        energy=res["energy"], rounds=res["rounds"])
+# what follows the tiles' rounds in an EM iteration: a collective of the whole world (the statistics)
+t = torch.tensor([float(sum(v["energy"] for v in out.values()))], dtype=torch.float64)
+dist.all_reduce(t)
+out["world_sum"] = float(t.item())
+json.dump(out, open(%(out)r + ".%%d" %% rank, "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_two_split_blocks_on_disjoint_rank_pairs_of_a_world_of_four(tmp_path):
+    """The 8-GPU deal in small: two split blocks, each on its own pair of ranks, every rank a bystander of the other block's
+    group (it creates the group -- torch.distributed.new_group is collective -- and takes no part in its rounds), then a
+    collective of the whole world.  Labels, energies and round counts equal those of the same tiles in one process."""
+    import json
+    H, W, diag, K, parts = 48, 48, True, 5, 2
+    want = {}
+    for bi in (0, 1):
+        blk, lp, w, eid, init = _problem(H, W, diag, K, seed=3 + bi)
+        g = _make_group(blk, lp, init, H, W, diag, K, parts, [0] * parts, 0, None)
+        res1, _ = _solve(g)
+        want[bi] = (res1, {t: tl.b.get_labels()[tl.owned_local_slice()] for t, tl in g.local.items()})
+    out = str(tmp_path / "tiles4")
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER4 % {"root": ROOT, "out": out})
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29783", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o.decode()[-3000:]
+    got = {0: {}, 1: {}}
+    sums = []
+    for r in range(4):
+        d = json.load(open(out + ".%d" % r))
+        sums.append(d.pop("world_sum"))
+        assert sorted(d) == [str(bi) for bi in (0, 1) if r in {0: [2, 3], 1: [1, 0]}[bi]]        # a rank ran its own block only
+        for bi, v in d.items():
+            assert v["rounds"] == want[int(bi)][0]["rounds"]
+            np.testing.assert_allclose(v["energy"], want[int(bi)][0]["energy"], rtol=1e-12)
+            for t, lab in v["labels"].items():
+                got[int(bi)][int(t)] = np.array(lab)
+    for bi in (0, 1):
+        assert sorted(got[bi]) == [0, 1]
+        for t in range(2):
+            assert np.array_equal(got[bi][t], want[bi][1][t])
+    # every member reported its block's energy: each block twice
+    np.testing.assert_allclose(sums, [2 * (want[0][0]["energy"] + want[1][0]["energy"])] * 4, rtol=1e-12)
