@@ -20,6 +20,8 @@ for bi, (H, W, diag) in enumerate(blocks_def):
     Xd = synthetic.device_observations(torch, dev, seed * 1000 + bi, H, W, diag, K, mu, cv); torch.cuda.synchronize()
     b.set_observations_dev(Xd.data_ptr()); b.sync(); del Xd; b.build_grid_graph(H, W, diag, nn, 0.5); blocks.append(b)
 N = sum(b.n for b in blocks)
+if os.environ.get("PHMRF_SOLVE_TRACE"):
+    for b in blocks: b.enable_timing(True)         # (the trace prints the labels changed per move type with the timers on)
 cur = np.clip(P * (1 + 0.15 * rng.standard_normal(P.shape)), 1e-3, 50); init_ou = cur.copy()
 means, covars = tree.mean_cov(cur); covars = covars + 1e-3 * np.eye(S)
 for b in blocks:
