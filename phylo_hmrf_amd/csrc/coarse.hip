@@ -140,15 +140,23 @@ __device__ __forceinline__ void coarsen_row(const CoarseGeom& g, int I, int64_t 
       const int dI = fdI[e], dJ = fdJ[e];
       const bool inside = dI == 0 && dJ == 0;
       if (!inside) wcross += w;
+      // The pair table of label alpha, t00 = w [l_i != l_j], t01 = w [l_i != alpha], t10 = w [alpha != l_j], is the same for
+      // every alpha that neither end carries: lambda = (w + w - t00) / 2 and the D term w - t00 - lambda are formed once per
+      // edge; with alpha at this end both are exactly 0, with alpha at the other end lambda is 0 and the term is -w --
+      // the values the per-label expressions give, bit for bit, for a third fewer instructions per label.
+      const float t00 = (li != lj) ? w : 0.f;
+      const float lvG = 0.5f * (w + w - t00);
+      const float dG = w - t00 - lvG;
 #pragma unroll
       for (int q = 0; q < NL; ++q) {
         const int alpha = out.alpha[q];
-        const float t00 = (li != lj) ? w : 0.f, t01 = (li != alpha) ? w : 0.f, t10 = (alpha != lj) ? w : 0.f;
         if (inside) {
           D[q] -= beta * t00;
         } else {
-          const float lv = 0.5f * (t10 + t01 - t00);
-          D[q] += beta * (t10 - t00 - lv);
+          const bool mine = li == alpha, other = lj == alpha;
+          const float lv = (mine || other) ? 0.f : lvG;
+          const float dt = mine ? 0.f : (other ? -w : dG);
+          D[q] += beta * dt;
           if (dI == 0 && dJ == 1) lam[q][0] += lv;
           else if (dI == 1) lam[q][2 + dJ] += lv;           // SW (dJ -1) -> 1, S -> 2, SE -> 3
           // (dI == 0, dJ == -1): the pair's slot is the E slot of the other super-cell, which adds it below
@@ -161,12 +169,16 @@ __device__ __forceinline__ void coarsen_row(const CoarseGeom& g, int I, int64_t 
       const int lj = lb[e];                           // holder = "i" of the table, this node = "j"
       const int dI = bdI[e], dJ = bdJ[e];
       wcross += w;
+      const float t00 = (lj != li) ? w : 0.f;               // (as above; here t01 belongs to the holder, t10 to this node)
+      const float lvG = 0.5f * (w + w - t00);
+      const float dG = w - t00 - lvG;
 #pragma unroll
       for (int q = 0; q < NL; ++q) {
         const int alpha = out.alpha[q];
-        const float t00 = (lj != li) ? w : 0.f, t01 = (lj != alpha) ? w : 0.f, t10 = (alpha != li) ? w : 0.f;
-        const float lv = 0.5f * (t10 + t01 - t00);
-        D[q] += beta * (t01 - t00 - lv);
+        const bool mine = li == alpha, other = lj == alpha;
+        const float lv = (mine || other) ? 0.f : lvG;
+        const float dt = mine ? 0.f : (other ? -w : dG);
+        D[q] += beta * dt;
         if (dI == 0 && dJ == 1) lam[q][0] += lv;            // the holder sits in my E neighbour (a fine SW edge)
       }
     }

@@ -41,6 +41,8 @@ __device__ __forceinline__ int strip_node(const StripGeom& g, int sr, int sc) {
   return i * g.W + j;
 }
 
+__device__ __forceinline__ float comp4f(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
 // lane of the wavefront (workgroups are whole waves here), without threadIdx: inside an out-of-line device function the
 // work-item id is a library call
 __device__ __forceinline__ int wave_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -365,16 +367,114 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
     //      cold solve of the 12.4 M-node block: half of all child strips went through the DP over 276 of their 315 cells,
     //      one in 3,600 found a move.
     if ((debug & 32) && alpha >= 0 && !prop) {
-      const float below = (*changed == 0ull) ? 0.f : 1.0e29f;
-      bool any = false;
-      for (int e = lane; e < ncell; e += 64) {
-        const int cc = e / SH, rr = e - cc * SH;
-        const int node = strip_node(g, rs0 + rr, ca + cc);
-        if (node >= 0) any = any || (labels[node] != alpha && uT[(int64_t)alpha * n + node] < below);
-      }
-      if (!__ballot(any)) {
-        if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
-        continue;
+      const bool fresh = *changed == 0ull;
+      if (!fresh) {
+        bool any = false;
+        for (int e = lane; e < ncell; e += 64) {
+          const int cc = e / SH, rr = e - cc * SH;
+          const int node = strip_node(g, rs0 + rr, ca + cc);
+          if (node >= 0) any = any || (labels[node] != alpha && uT[(int64_t)alpha * n + node] < 1.0e29f);
+        }
+        if (!__ballot(any)) {
+          if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+          continue;
+        }
+      } else {
+        // the strip's cells with a negative switch cost, gathered one per lane (the slab is free until the strip is staged)
+        const float* __restrict__ ua = uT + (int64_t)alpha * n;
+        int total = 0;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          const int e = p * 64 + lane;
+          bool neg = false;
+          if (e < ncell) {
+            const int cc = e / SH, rr = e - cc * SH;
+            const int node = strip_node(g, rs0 + rr, ca + cc);
+            if (node >= 0) neg = labels[node] != alpha && ua[node] < 0.f;
+          }
+          const unsigned long long m = __ballot(neg);
+          const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+          if (neg && slot < 64) tab[slot] = __builtin_bit_cast(float, e);
+          total += __popcll(m);
+        }
+        if (total == 0) {
+          if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+          continue;
+        }
+        // ---- a one-hop flow certificate for those cells.  With every cell at "keep", a switch set S costs
+        //      sum_S D + cut(S).  Let every cell A with D_A < 0 ship f_AB <= lambda_AB to neighbours B with D_B > 0, each B
+        //      taking in at most D_B in all.  If A can ship its whole deficit (sum_B f_AB >= -D_A) it is SETTLED, and a set S
+        //      whose negative cells are all settled costs sum_S D + cut(S) >= -sum_{A in S, B not in S} f_AB + cut(S) >= 0 (what
+        //      A ships to a B inside S is paid for by D_B; what it ships out of S is at most the cut).  The split: a cell with
+        //      D_B > 0 offers each of its n_B neighbours with a negative cost min(lambda_AB, D_B / n_B) -- whichever strip those
+        //      neighbours lie in; a pinned cell (D >= 1e29: its true cost exceeds all its pair weights) offers lambda_AB.  So a
+        //      strip whose negative cells are all settled has nothing better than all-keep, which the DP's tie rule prefers:
+        //      it stops here, and only the others -- one strip in seven at 2 x 2, one in thirty at 4 x 4 on the whole-genome
+        //      blocks where three in four hold a negative cost -- are staged and walked.
+        if (total <= 64) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          bool open_cell = false;
+          if (lane < total) {
+            const int e = __builtin_bit_cast(int, tab[lane]);
+            const int cc = e / SH, rr = e - cc * SH;
+            const int R = rs0 + rr, C = ca + cc;
+            const int node = strip_node(g, R, C);
+            const float4 fw = fwd_w[node];
+            const float* __restrict__ fws = reinterpret_cast<const float*>(fwd_w);
+            // switch costs of the 5 x 5 window around the cell: which are negative, and the eight inner ones themselves
+            unsigned int negw = 0u;
+            float dn[8];
+            int nb[8];
+#pragma unroll
+            for (int dr = -2; dr <= 2; ++dr)
+#pragma unroll
+              for (int dc = -2; dc <= 2; ++dc) {
+                if (dr == 0 && dc == 0) {
+                  negw |= 1u << 12;
+                  continue;
+                }
+                const int nw = strip_node(g, R + dr, C + dc);
+                const float dv = nw >= 0 ? ua[nw] : 0.f;
+                if (nw >= 0 && dv < 0.f) negw |= 1u << ((dr + 2) * 5 + (dc + 2));
+                if (dr >= -1 && dr <= 1 && dc >= -1 && dc <= 1) {
+                  constexpr int dummy = 0;
+                  (void)dummy;
+                  const int k = (dr + 1) * 3 + (dc + 1);
+                  const int k8 = k > 4 ? k - 1 : k;
+                  dn[k8] = dv;
+                  nb[k8] = nw;
+                }
+              }
+            float recv = 0.f;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+              const int k = k8 >= 4 ? k8 + 1 : k8;
+              const int dr = k / 3 - 1, dc = k % 3 - 1;
+              const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;       // grid direction of the edge (as in step B)
+              const bool fwd = di > 0 || (di == 0 && dj > 0);
+              const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
+              if (nb[k8] < 0) continue;
+              const float w = beta * (fwd ? comp4f(fw, comp) : fws[4 * (int64_t)nb[k8] + comp]);
+              // negative cells among B's eight neighbours (this cell is one of them)
+              int nneg = 0;
+#pragma unroll
+              for (int er = -1; er <= 1; ++er)
+#pragma unroll
+                for (int ec = -1; ec <= 1; ++ec)
+                  if (er != 0 || ec != 0) nneg += (int)((negw >> ((dr + er + 2) * 5 + (dc + ec + 2))) & 1u);
+              const float capb = dn[k8] > 0.f ? dn[k8] : 0.f;
+              recv += __builtin_fminf(w, capb / (float)nneg);
+            }
+            open_cell = !(recv >= -ua[node] * 1.0001f + 1.0e-6f);
+          }
+          const bool any_open = __ballot(open_cell) != 0ull;
+          __builtin_amdgcn_wave_barrier();      // (the slab is about to be staged)
+          if (!any_open) {
+            if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
+            continue;
+          }
+        }
       }
     }
     if ((debug & 4) && lane == 0) atomicAdd(changed - alpha - 8 + 101, 1ull);   // strips reaching phase 1

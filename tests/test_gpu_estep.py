@@ -832,8 +832,9 @@ def test_coarse_labels_in_batches_give_the_one_by_one_sequence():
 def test_coarse_shortcuts_leave_the_labellings_alone():
     """Round 4: a label's problem is rebuilt only in the wavefronts whose nodes carry a change stamp later than the batch's
     pass (coarsen_kernel; PHMRF_COARSE_NO_STAMP_GATE=1: everywhere), and a child strip is staged only if it holds a
-    super-cell that proposes a switch -- a NEGATIVE switch cost while nothing has switched yet (strip_kernel, debug & 32;
-    PHMRF_NO_PIN_LOOK=1: every strip is staged and walked).  Both are exact: with PHMRF_DETERMINISTIC=1 the cold-start script
+    super-cell that proposes a switch -- while nothing has switched yet: a NEGATIVE switch cost that the one-hop flow
+    certificate cannot settle (strip_kernel, debug & 32; PHMRF_NO_PIN_LOOK=1: every strip is staged and walked).  Both are
+    exact: with PHMRF_DETERMINISTIC=1 the cold-start script
     gives the same label hash, round count and energy with and without them, bit for bit."""
     import subprocess
     import sys
