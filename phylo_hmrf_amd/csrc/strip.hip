@@ -383,15 +383,23 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
         // the strip's cells with a negative switch cost, gathered one per lane (the slab is free until the strip is staged)
         const float* __restrict__ ua = uT + (int64_t)alpha * n;
         int total = 0;
+        int lnode[NPASS], llab[NPASS];
+        float lcost[NPASS];
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {            // every load of the look in flight at once (an absent cell reads node 0)
+          const int e = p * 64 + lane;
+          const int cc = e / SH, rr = e - cc * SH;
+          lnode[p] = e < ncell ? strip_node(g, rs0 + rr, ca + cc) : -1;
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          llab[p] = labels[lnode[p] >= 0 ? lnode[p] : 0];
+          lcost[p] = ua[lnode[p] >= 0 ? lnode[p] : 0];
+        }
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
           const int e = p * 64 + lane;
-          bool neg = false;
-          if (e < ncell) {
-            const int cc = e / SH, rr = e - cc * SH;
-            const int node = strip_node(g, rs0 + rr, ca + cc);
-            if (node >= 0) neg = labels[node] != alpha && ua[node] < 0.f;
-          }
+          const bool neg = lnode[p] >= 0 && llab[p] != alpha && lcost[p] < 0.f;
           const unsigned long long m = __ballot(neg);
           const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
           if (neg && slot < 64) tab[slot] = __builtin_bit_cast(float, e);
@@ -435,14 +443,14 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
                   continue;
                 }
                 const int nw = strip_node(g, R + dr, C + dc);
-                const float dv = nw >= 0 ? ua[nw] : 0.f;
+                const float dv = ua[nw >= 0 ? nw : node];       // (an absent cell reads this one: no load waits behind a branch)
                 if (nw >= 0 && dv < 0.f) negw |= 1u << ((dr + 2) * 5 + (dc + 2));
                 if (dr >= -1 && dr <= 1 && dc >= -1 && dc <= 1) {
                   constexpr int dummy = 0;
                   (void)dummy;
                   const int k = (dr + 1) * 3 + (dc + 1);
                   const int k8 = k > 4 ? k - 1 : k;
-                  dn[k8] = dv;
+                  dn[k8] = nw >= 0 ? dv : 0.f;
                   nb[k8] = nw;
                 }
               }
@@ -454,8 +462,8 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
               const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;       // grid direction of the edge (as in step B)
               const bool fwd = di > 0 || (di == 0 && dj > 0);
               const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
-              if (nb[k8] < 0) continue;
-              const float w = beta * (fwd ? comp4f(fw, comp) : fws[4 * (int64_t)nb[k8] + comp]);
+              const float wraw = fwd ? comp4f(fw, comp) : fws[4 * (int64_t)(nb[k8] >= 0 ? nb[k8] : node) + comp];
+              const float w = nb[k8] >= 0 ? beta * wraw : 0.f;
               // negative cells among B's eight neighbours (this cell is one of them)
               int nneg = 0;
 #pragma unroll
