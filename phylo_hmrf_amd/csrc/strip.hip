@@ -1657,7 +1657,11 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
         const int cc = t / SH, rr = t - cc * SH;
         const int node = strip_node(g, rs0 + rr, ca + cc);
         if (node >= 0) {
-          labels[node] = FUSION ? slabp[(cc + 1) * EH + (rr + 1)] : (uint8_t)alpha;
+          const unsigned char nl = FUSION ? slabp[(cc + 1) * EH + (rr + 1)] : (unsigned char)alpha;
+          labels[node] = nl;
+          // (the staged labels follow: only this wave changes the cells of its strip during a pass, the rim belongs to
+          //  nobody's strip -- after a move the slab is what a restaging would load, and the caller does not restage)
+          const_cast<unsigned char*>(slabl)[(cc + 1) * EH + (rr + 1)] = nl;
           if (stamp) {
             stamp[node] = (uint16_t)tick_a;
             const global_ptr<const int32_t> nb2 = nbr + (int64_t)node * D;
@@ -2061,9 +2065,12 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
                                                                   uT, labels, stamp, mrow ? mrow + alpha : nullptr, changed + alpha);
         PH(4)
         if (my_changed) {
-          // the labels of this strip have changed: everything later is filtered again on the new labelling
+          // the labels of this strip have changed: everything later is filtered again on the new labelling (the slab's
+          // labels were patched by the DP's apply step; its weights do not depend on the labels: no restaging)
           __threadfence();
+#ifdef PHMRF_COLS_RESTAGE
           staged = false;
+#endif
           todo = todo_in & ~((2ull << alpha) - 1ull);
           break;
         }
