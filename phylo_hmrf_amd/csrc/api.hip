@@ -366,15 +366,12 @@ int phmrf_block_create(int64_t n, int S, int K, phmrf_block_t* out) {
   return PHMRF_OK;
 }
 
+static void coarse_children_destroy(phmrf_block_t b);
+
 int phmrf_block_destroy(phmrf_block_t b) {
   if (!b) return PHMRF_OK;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  for (int lv = 0; lv < 12; ++lv)
-    if (b->coarse[lv]) {
-      b->coarse[lv]->stream = b->coarse[lv]->own_stream;
-      phmrf_block_destroy(b->coarse[lv]);
-      b->coarse[lv] = nullptr;
-    }
+  coarse_children_destroy(b);
   dev_free(b->X);
   dev_free(b->logprob);
   dev_free(b->labels);
@@ -1079,27 +1076,61 @@ static const int COARSE_SCALE[N_COARSE] = {2, 4, 8};
 static const int64_t COARSE_ON_DIV = 8;       // "moved at large": a solve changed >= 1/8 of the labels so far
 static const int64_t COARSE_ROUND_DIV = 4;    // "moving at large": a round changed >= 1/4 of the labels (a cold start)
 
-static int coarse_child(phmrf_block_t b, int level_slot, phmrf_block** out) {       // level_slot = level * 4 + slot in a batch
-  const int level = level_slot / 4;
-  if (!b->coarse[level_slot]) {
-    const int s = COARSE_SCALE[level];
-    const int64_t nmax = coarse_nodes(b, s, s - 1);
-    phmrf_block* c = nullptr;
-    PHMRF_TRY(phmrf_block_create(nmax, 1, 2, &c));
-    int st = dev_alloc(&c->fwd_w, (size_t)nmax);
-    if (st == PHMRF_OK) st = dev_alloc(&c->uT, (size_t)2 * nmax);
-    if (st != PHMRF_OK) {
-      phmrf_block_destroy(c);
-      return st;
-    }
+// The twelve child problems of a block (three scales x four labels of a batch) are lean: a child holds what coarsen_kernel
+// writes and strip_kernel / coarse_apply_kernel read -- labels, two unary planes, the forward weights, a counter bank -- and
+// all twelve come out of ONE device allocation made at the first coarse sweep.  (They used to be full blocks: a stream, three
+// pinned host buffers, two events and eleven device buffers each -- some two hundred runtime calls per block, 50 - 60 ms of
+// the first cold solve of EVERY block, whatever its size.)
+static int coarse_children_create(phmrf_block_t b) {
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off_lab[12], off_uT[12], off_fwd[12], total = up((size_t)12 * 128 * sizeof(unsigned long long));   // the counter banks first
+  int64_t nm[12];
+  for (int ls = 0; ls < 12; ++ls) {
+    const int s = COARSE_SCALE[ls / 4];
+    nm[ls] = coarse_nodes(b, s, s - 1);
+    off_lab[ls] = total;
+    total += up((size_t)nm[ls]);
+    off_uT[ls] = total;
+    total += up((size_t)2 * nm[ls] * sizeof(float));
+    off_fwd[ls] = total;
+    total += up((size_t)nm[ls] * sizeof(float4));
+  }
+  PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->coarse_arena), total));
+  PHMRF_HIP(hipMemsetAsync(b->coarse_arena, 0, (size_t)12 * 128 * sizeof(unsigned long long), b->stream));
+  for (int ls = 0; ls < 12; ++ls) {
+    phmrf_block* c = new phmrf_block();
+    c->n = nm[ls];
+    c->S = 1;
+    c->K = 2;
+    c->device = b->device;
+    c->deterministic = b->deterministic;
+    c->counters = reinterpret_cast<unsigned long long*>(b->coarse_arena) + (size_t)ls * 128;
+    c->labels = reinterpret_cast<uint8_t*>(b->coarse_arena + off_lab[ls]);
+    c->uT = reinterpret_cast<float*>(b->coarse_arena + off_uT[ls]);
+    c->fwd_w = reinterpret_cast<float4*>(b->coarse_arena + off_fwd[ls]);
     c->uT_valid = true;
     c->has_grid = true;
     c->has_graph = true;
     c->has_logprob = true;
     c->D = 0;
     c->unary_pins = true;
-    b->coarse[level_slot] = c;
+    c->stream = b->stream;
+    b->coarse[ls] = c;
   }
+  return PHMRF_OK;
+}
+
+static void coarse_children_destroy(phmrf_block_t b) {
+  for (int ls = 0; ls < 12; ++ls) {
+    delete b->coarse[ls];             // (a child owns nothing: its buffers are slices of the arena)
+    b->coarse[ls] = nullptr;
+  }
+  if (b->coarse_arena) (void)hipFree(b->coarse_arena);
+  b->coarse_arena = nullptr;
+}
+
+static int coarse_child(phmrf_block_t b, int level_slot, phmrf_block** out) {       // level_slot = level * 4 + slot in a batch
+  if (!b->coarse_arena) PHMRF_TRY(coarse_children_create(b));
   b->coarse[level_slot]->stream = b->stream;
   b->coarse[level_slot]->num_neighbor = b->num_neighbor;
   *out = b->coarse[level_slot];

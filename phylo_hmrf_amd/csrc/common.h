@@ -110,6 +110,7 @@ struct phmrf_block {
   // coarse alpha-expansions (coarse.hip): child blocks holding the two-label problem of the super-cells, side 2, 4, 8
   phmrf_block* coarse[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [level * 4 + slot in a batch of labels]
   unsigned int* coarse_flag = nullptr;      // device: set by coarse_apply_kernel when a label of the batch has moved
+  char* coarse_arena = nullptr;             // ONE allocation behind the twelve child problems (labels, unary planes, weights, counters)
   int prop_tick = -1;                       // tick of the last proposal launch of this solve (-1: none)
   int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
   // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS

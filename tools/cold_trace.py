@@ -28,5 +28,12 @@ r = b.solve(1.0, energy_tol_ppb=int(os.environ.get("TOL_PPB", "1000")))
 b.sync()
 print("block %d of %s: %d nodes, cold solve %.1f ms, %s" % (bi, wl, n, (time.time() - t0) * 1e3, {k: r[k] for k in ("rounds", "changed", "energy", "converged") if k in r}))
 print({k: (round(v[0], 1), v[1]) for k, v in b.timing().items()})
+if os.environ.get("COLD_TWICE"):          # the same cold solve again: the coarse child blocks exist now (allocated by the first)
+    b.solve_fast(1.0, max_rounds=1, use_chains=False, use_components=False, use_strips=False, use_expansion=False, init_mode=1)
+    b.sync(); b.reset_timing()
+    t0 = time.time()
+    r = b.solve(1.0, energy_tol_ppb=int(os.environ.get("TOL_PPB", "1000")))
+    b.sync()
+    print("again: cold solve %.1f ms, rounds %d" % ((time.time() - t0) * 1e3, r["rounds"]))
 import hashlib
 print("labels sha1 %s energy %.9f rounds %d" % (hashlib.sha1(b.get_labels().tobytes()).hexdigest()[:16], r["energy"], r["rounds"]))
