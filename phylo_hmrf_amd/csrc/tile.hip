@@ -106,7 +106,11 @@ int launch_tile_pins(phmrf_block* b, int region, int64_t first, int64_t count, i
   const int grid = (int)(g64 > 4096 ? 4096 : g64);
   hipLaunchKernelGGL(tile_pins_kernel, dim3(grid), dim3(256), 0, b->stream, b->logprob, (b->uT && b->uT_valid) ? b->uT : nullptr, b->n,
                      b->K, b->labels, b->pin_save[region], b->pin_label[region], first, count, pinned_first, pinned_count, was_first,
-                     was_count, save_first ? 1 : 0, b->tick ? b->stamp : nullptr, b->tick, b->counters + 120);
+                     was_count, save_first ? 1 : 0, b->tick ? b->stamp : nullptr, b->tick,
+                     // (the violation count lives in accum slot 6: solve_begin zeroes it, every round's read-back carries
+                     //  it -- energy_round_launch --, solve_round_collect tests it; the counter bank would not do: it is
+                     //  zeroed at the start of every round, after the pins of that round have been set)
+                     reinterpret_cast<unsigned long long*>(b->accum + 6));
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

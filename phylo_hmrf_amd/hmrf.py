@@ -135,6 +135,12 @@ class phyloHMRF(_BaseGraph):
                     parts = force[r]
                 elif self.world > 1 and self.len_vec[r][0] > split_above * share:
                     parts = int(np.ceil(self.len_vec[r][0] / (split_above * share)))
+                # a block with a host edge list is only cut if that list IS the grid stencil -- every rank asks the same
+                # question of the same list and gets the same answer; a block that fails stays whole and takes the
+                # general-graph fallback below (a RuntimeWarning) instead of aborting in make_group on its holders only
+                if parts > 1 and not device_graph and not _tiles.edges_fit_grid(
+                        np.asarray(edge_list_1[r])[:, 0:2], H, W, diag, num_neighbor):
+                    parts = 1
             rows = _tiles.split_rows(H, W, diag, parts) if parts > 1 else [(0, H)]
             if len(rows) == 1:
                 units.append(dict(block=r, tile=0, ntiles=1, r0=0, r1=H, nodes=self.len_vec[r][0]))
@@ -351,31 +357,47 @@ class phyloHMRF(_BaseGraph):
         """labels and emission log-likelihoods of one region, warm-started from labels_local (:470-484)."""
         if region_id in self.split_regions:
             return self._predict_tiled(region_id)
-        b = self.blocks[region_id]
+        b = self._whole_block(region_id, "predict")
         b.restore_labels(SLOT_LOCAL)
         b.emission(self.means_, self._covars_)
         b.solve_fast(self.beta, **self.solver_opts)
         return b.get_labels(), b.get_logprob()
 
     def _predict_tiled(self, region_id):
-        """predict() of a region that is cut into row tiles: a collective of the ranks that hold its tiles; every one of them
-        returns the whole region's labels and log-likelihoods (the other ranks' rows arrive by all-reduce)"""
+        """predict() of a region that is cut into row tiles: a collective of THE RANKS THAT HOLD ITS TILES (the tile group's
+        communicator -- a rank that holds none of them returns zeros at once and takes part in nothing, so the holders may
+        call it on their own); every holder returns the whole region's labels and log-likelihoods, the other holders' rows
+        arrive by an all-reduce over the group"""
         from .tiles import Conductor
         n = self.len_vec[region_id][0]
-        labels, logprob = np.zeros(n), np.zeros((n, self.n_components))
+        labels, logprob = np.zeros(n, dtype=np.int64), np.zeros((n, self.n_components))
         grp = self.tile_groups.get(region_id)
-        if grp is not None:
-            def prepare(tl):
-                tl.b.restore_labels(SLOT_LOCAL)
-                tl.b.emission(self.means_, self._covars_)
-            Conductor([grp]).solve(self.beta, self.solver_opts, prepare=prepare)
-            for tl in grp.local.values():
-                labels[tl.owned_global_slice()] = tl.b.get_labels()[tl.owned_local_slice()]
-                logprob[tl.owned_global_slice()] = tl.b.get_logprob()[tl.owned_local_slice()]
-        if self.world > 1:
-            labels = self.reducer.allreduce(labels)
-            logprob = self.reducer.allreduce(logprob.ravel()).reshape(n, self.n_components)
+        if grp is None:
+            return labels.astype(np.int32), logprob
+
+        def prepare(tl):
+            tl.b.restore_labels(SLOT_LOCAL)
+            tl.b.emission(self.means_, self._covars_)
+
+        Conductor([grp]).solve(self.beta, self.solver_opts, prepare=prepare)
+        for tl in grp.local.values():
+            labels[tl.owned_global_slice()] = tl.b.get_labels()[tl.owned_local_slice()]
+            logprob[tl.owned_global_slice()] = tl.b.get_logprob()[tl.owned_local_slice()]
+        if grp.comm is not None:                          # (each row is written by exactly one rank: the sum is a gather)
+            labels = grp.comm.allreduce_i64(labels)
+            logprob = grp.comm.allreduce_i64(logprob.ravel().view(np.int64)).view(np.float64).reshape(n, self.n_components)
         return labels.astype(np.int32), logprob
+
+    def _whole_block(self, region_id, what):
+        """the resident block of a region this rank holds whole -- or the reason why there is none"""
+        if region_id in self.split_regions:
+            raise NotImplementedError("region %d is cut into row tiles held by several ranks: %s comes out of the fit's E-step "
+                                      "(fit_accumulate_test); construct the model with split_above=float('inf') to keep "
+                                      "every block whole" % (region_id, what))
+        if region_id not in self.blocks:
+            raise KeyError("region %d is held by rank %d, not by this rank (%d of %d)"
+                           % (region_id, self.owner[region_id], self.rank, self.world))
+        return self.blocks[region_id]
 
     def _estimate_state_graphcuts_gco(self, X, init_labels1, edge_idList_undirected, edge_weightList_undirected):
         """Drop-in for the pygco call (:486-507) on an arbitrary graph: GPU label solver, general-graph moves."""
@@ -387,11 +409,7 @@ class phyloHMRF(_BaseGraph):
 
     # ---- b3 --------------------------------------------------------------------------------------
     def _compute_posteriors_graph(self, X, label, logprob, region_id):
-        if region_id in self.split_regions:
-            raise NotImplementedError("region %d is cut into row tiles held by several ranks: its posteriors come out of the "
-                                      "fit's E-step (fit_accumulate_test); construct the model with split_above=float('inf') "
-                                      "to keep every block whole" % region_id)
-        b = self.blocks[region_id]
+        b = self._whole_block(region_id, "its posteriors")
         b.set_logprob(logprob)
         b.set_labels(label)
         _, costs, post = b.posterior_stats(self.beta, self.estimate_type, want_posteriors=True)
@@ -399,7 +417,7 @@ class phyloHMRF(_BaseGraph):
         return post, costs[0] / n, costs[1] / n, costs[2] / n, costs[3] / n
 
     def _estep_region(self, region_id):
-        b = self.blocks[region_id]
+        b = self._whole_block(region_id, "its E-step")
         b.emission(self.means_, self._covars_)
         if self.warm_start == "best":
             b.warm_start(self.beta, SLOT_LOCAL, report=False)      # labels_local or the previous result, whichever is lower
@@ -433,7 +451,7 @@ class phyloHMRF(_BaseGraph):
 
     def _predict_posteriors(self, X, len_vec, region_id, m_queue=None):
         """(region_id, stats, labels, pairwise_cost, pairwise_cost_normalize, unary_cost, cost1)  (:297-322)."""
-        stats, costs = self._estep_region(region_id)
+        stats, costs = self._estep_region(region_id)          # (raises for a region cut into row tiles, like b3)
         n = float(len_vec[region_id][0])
         out = (region_id, stats, self.blocks[region_id].get_labels(), costs[0] / n, costs[1] / n, costs[2] / n, costs[3] / n)
         if m_queue is not None:

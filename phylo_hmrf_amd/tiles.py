@@ -35,6 +35,39 @@ def row_len(i, W, diag):
     return W - i if diag else W
 
 
+def node_coords(ids, W, diag):
+    """grid (row, column) of node ids of a block with W columns (diag: the W x W upper triangle, row-major)"""
+    ids = np.asarray(ids, dtype=np.int64)
+    if not diag:
+        return np.divmod(ids, W)
+    # row i starts at i W - i (i - 1) / 2: the largest i whose start is <= id
+    i = np.floor(((2 * W + 1) - np.sqrt(np.maximum((2.0 * W + 1) ** 2 - 8.0 * ids, 0.0))) / 2.0).astype(np.int64)
+    for _ in range(2):                                   # (the float root can be one off either way)
+        i = np.where(i * W - (i * (i - 1)) // 2 > ids, i - 1, i)
+        i = np.where((i + 1) * W - ((i + 1) * i) // 2 <= ids, i + 1, i)
+    return i, ids - (i * W - (i * (i - 1)) // 2) + i
+
+
+def edges_fit_grid(ids, H, W, diag, num_neighbor=8):
+    """Does every edge of the list [E, 2] join two grid neighbours of the block (H, W, diag)?  The host-side form of what
+    phmrf_block_set_grid checks on the device copy (status 1, 'edge list joins nodes that are not grid neighbours'): asked
+    BEFORE a block is cut into row tiles, so that a block whose edge list is not the stencil stays whole and takes the
+    whole-block path's general-graph fallback instead of failing inside make_group on some ranks only."""
+    ids = np.asarray(ids, dtype=np.int64)
+    if ids.ndim != 2 or ids.shape[1] < 2:
+        return False
+    n = rows_nodes(0, H, W, diag)
+    if ids.size and (ids[:, :2].min() < 0 or ids[:, :2].max() >= n):
+        return False
+    i1, j1 = node_coords(ids[:, 0], W, diag)
+    i2, j2 = node_coords(ids[:, 1], W, diag)
+    di, dj = np.abs(i1 - i2), np.abs(j1 - j2)
+    ok = (di <= 1) & (dj <= 1) & (di + dj > 0)
+    if num_neighbor == 4:
+        ok &= (di + dj) == 1
+    return bool(ok.all())
+
+
 MIN_TILE_ROWS = 8
 
 
@@ -139,25 +172,27 @@ class TileGroup(object):
         self.local = dict(local)
         self.comm = comm
         self.row_words = (row_len(0, self.W, self.diag) + 7) // 8          # int64 words that hold the longest row
-        self.slot = N_COUNTERS + 2 + 2 * self.row_words
+        self.slot = N_COUNTERS + 3 + 2 * self.row_words
         self.rounds = 0
         self.status = 0
         self.missing = set(range(self.ntiles)) - set(self.local) if comm is None else set()
         self.result = None
 
-    # the payload of tile t: [counters 128 | energy 2 (float64 bits) | first owned row | last owned row], int64 words
+    # the payload of tile t: [counters 128 | energy 2 (float64 bits) | 1 + the status its holder decided last round |
+    # first owned row | last owned row], int64 words
     def _pack(self, buf, t, counters, energy, top, bot):
         o = t * self.slot
         buf[o:o + N_COUNTERS] = counters.view(np.int64)
         buf[o + N_COUNTERS:o + N_COUNTERS + 2] = np.asarray(energy, dtype=np.float64).view(np.int64)
-        rows = buf[o + N_COUNTERS + 2:o + self.slot].view(np.uint8)
+        buf[o + N_COUNTERS + 2] = 1 + self.status
+        rows = buf[o + N_COUNTERS + 3:o + self.slot].view(np.uint8)
         if top is not None:
             rows[:top.size] = top
         if bot is not None:
             rows[8 * self.row_words:8 * self.row_words + bot.size] = bot
 
     def _rows(self, buf, t):
-        o = t * self.slot + N_COUNTERS + 2
+        o = t * self.slot + N_COUNTERS + 3
         rows = buf[o:o + 2 * self.row_words].view(np.uint8)
         return rows[:8 * self.row_words], rows[8 * self.row_words:]
 
@@ -219,10 +254,18 @@ class TileGroup(object):
             buf = self.comm.allreduce_i64(buf)
         tot_c = np.zeros(N_COUNTERS, dtype=np.uint64)
         tot_e = np.zeros(2, dtype=np.float64)
+        seen = set()
         for t in range(self.ntiles):                       # fixed order: every rank forms the same sums
             o = t * self.slot
             tot_c += buf[o:o + N_COUNTERS].view(np.uint64)
             tot_e += buf[o + N_COUNTERS:o + N_COUNTERS + 2].view(np.float64)
+            if t not in self.missing:
+                seen.add(int(buf[o + N_COUNTERS + 2]) - 1)
+        # every holder decides on the same sums and so reaches the same status; one that did not (a failed tile, a rank on
+        # another code path) would otherwise hang its partners in the next all-reduce -- fail here instead, on every rank
+        if len(seen) > 1:
+            raise RuntimeError("block %d: the ranks that hold its row tiles disagree on the schedule (status of the previous "
+                               "round: %s)" % (self.block_id, sorted(seen)))
         status = None
         for t in sorted(self.local):
             tl = self.local[t]

@@ -81,13 +81,33 @@ if os.environ.get("TEST_FIXED_SCHEDULE") == "1":
     m._init = fake_init
     m._do_mstep = fake_mstep
 res = m.fit_accumulate_test(X, len_vec, 1e-3, "t", 5)        # t_labels are kept from iteration 3 on (base.py:422-426)
+pred = {}
+if os.environ.get("TEST_PREDICT_TILED") == "1":
+    # predict() of the split regions, called by the ranks that hold tiles of them ONLY (a collective of the tile group, not
+    # of the world: a rank without a tile of the region must not be needed)
+    import hashlib
+    for r in sorted(m.tile_groups):
+        st, lp = m.predict(X, r)
+        pred[str(r)] = [hashlib.sha1(np.ascontiguousarray(st, dtype=np.int32).tobytes()).hexdigest(), float(lp.sum()),
+                        int(st.shape[0]), list(lp.shape)]
+    for r in m.split_regions:
+        try:
+            m._compute_posteriors_graph(X, None, None, r)
+            raise SystemExit("no error for a split region")
+        except NotImplementedError:
+            pass
+        try:
+            m._predict_posteriors(X, len_vec, r)
+            raise SystemExit("no error for a split region")
+        except NotImplementedError:
+            pass
 out = dict(rank=m.rank, owned=owned, tiles=tiles_held, cost_vec=res[5].tolist(), labels=res[6].astype(int).tolist(),
-           means=m.means_.tolist())
+           means=m.means_.tolist(), predict=pred)
 m.close()
 if m.rank == 0:
     json.dump(out, open(%(out)r, "w"))
 else:
-    json.dump(dict(owned=owned, tiles=tiles_held), open(%(out)r + ".r1", "w"))
+    json.dump(dict(owned=owned, tiles=tiles_held, predict=pred), open(%(out)r + ".r1", "w"))
 if world > 1:
     dist.destroy_process_group()
 '''
@@ -112,7 +132,7 @@ def _run_fit(tmp_path, world, port, extra_env=None):
     d = json.load(open(out))
     if world > 1:
         r1 = json.load(open(out + ".r1"))
-        d["owned_r1"], d["tiles_r1"] = r1["owned"], r1["tiles"]
+        d["owned_r1"], d["tiles_r1"], d["predict_r1"] = r1["owned"], r1["tiles"], r1.get("predict", {})
     return d
 
 
@@ -133,7 +153,7 @@ def test_row_tiles_on_two_ranks_equal_the_same_tiles_on_one(tmp_path):
     """Blocks 0 and 2 cut into 2 and 3 row tiles (tiles.py).  On one rank all five tiles are local; on two ranks they are
     dealt with the whole block (tiles of one block on DIFFERENT ranks: lockstep rounds over gloo, halo rows exchanged).  Same
     algorithm, same numbers: costs to 1e-9, labels exactly, over five EM iterations with a fixed parameter schedule."""
-    env = {"TEST_FIXED_SCHEDULE": "1", "TEST_TILE_PARTS": json.dumps({"0": 2, "2": 3})}
+    env = {"TEST_FIXED_SCHEDULE": "1", "TEST_TILE_PARTS": json.dumps({"0": 2, "2": 3}), "TEST_PREDICT_TILED": "1"}
     one = _run_fit(tmp_path, 1, 29765, env)
     two = _run_fit(tmp_path, 2, 29767, env)
     assert one["tiles"] == [[0, 0], [0, 1], [2, 0], [2, 1], [2, 2]] and one["owned"] == [1]
@@ -145,6 +165,14 @@ def test_row_tiles_on_two_ranks_equal_the_same_tiles_on_one(tmp_path):
     c1, c2 = np.array(one["cost_vec"]), np.array(two["cost_vec"])
     np.testing.assert_allclose(c2, c1, rtol=1e-9, atol=1e-12)
     assert np.array_equal(np.array(one["labels"]), np.array(two["labels"]))
+    # predict() of a split region is a collective of its holders alone, and every holder gets the whole region: what the
+    # one-rank run returns (labels exactly, log-likelihoods to the order of the sum)
+    assert sorted(one["predict"]) == ["0", "2"]
+    for ranks_pred in (two["predict"], two["predict_r1"]):
+        for r, (sha, lpsum, nlab, shape) in ranks_pred.items():
+            assert sha == one["predict"][r][0] and nlab == one["predict"][r][2] and shape == one["predict"][r][3]
+            assert abs(lpsum - one["predict"][r][1]) <= 1e-9 * abs(one["predict"][r][1])
+    assert set(two["predict"]) | set(two["predict_r1"]) == {"0", "2"}
 
 
 def test_two_ranks_on_one_gpu_fit_matches_the_single_rank_fit(tmp_path):

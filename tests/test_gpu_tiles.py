@@ -212,3 +212,45 @@ def test_tiled_cold_start_at_config_2_size_stays_below_gco(parts):
     for tl in g.local.values():
         tl.b.close()
     whole.close()
+
+
+def test_a_moved_pinned_row_is_reported():
+    """The safety net under the tiles' lockstep rounds: every re-pin counts the pinned nodes whose label is no longer the one
+    they were pinned with, and the round's read-back carries that count (PHMRF_ERR_STATE).  No move type may relabel a pinned
+    node, so the count can only be forced from outside: a label of the pinned row is changed behind the solver's back
+    between two phmrf_block_tile_pins calls."""
+    from phylo_hmrf_amd import Block
+    from phylo_hmrf_amd._lib import PhmrfError
+    H = W = 48
+    K = 5
+    blk = synth.make_block(seed=11, H=H, W=W, S=4, K=K, diagonal=True)
+    b = _whole(blk, H, W, True, K)
+    b.emission(blk["means"], blk["covars"])
+    b.solve(1.0, init_mode=1, max_rounds=2)
+    b.set_tile(True, False, 0)
+    # a clean pair of rounds first: nothing is reported
+    b.solve_begin(1.0, energy_tol_ppb=1000)
+    b.tile_pins(1, 0)
+    b.solve_round_launch()
+    counters, energy = b.solve_round_collect()
+    b.solve_round_decide(counters, energy)
+    b.tile_pins(2, 0)
+    b.solve_round_launch()
+    counters, energy = b.solve_round_collect()
+    b.solve_round_decide(counters, energy)
+    b.solve_end()
+    # now with the first row (pinned) relabelled between the pins of two rounds
+    b.solve_begin(1.0, energy_tol_ppb=1000)
+    b.tile_pins(1, 0)
+    b.solve_round_launch()
+    counters, energy = b.solve_round_collect()
+    b.solve_round_decide(counters, energy)
+    lab = b.get_labels()
+    lab[:5] = (lab[:5] + 1) % K
+    b.set_labels(lab)
+    b.tile_pins(2, 0)
+    b.solve_round_launch()
+    with pytest.raises(PhmrfError) as ei:
+        b.solve_round_collect()
+    assert ei.value.status == 5 and "pinned row" in str(ei.value)        # PHMRF_ERR_STATE
+    b.close()

@@ -149,3 +149,63 @@ def test_tile_group_payload_round_trip():
     rt, rb = g._rows(buf, 1)
     assert np.array_equal(rt[:97], top) and np.array_equal(rb[:60], bot)
     assert not buf[:o].any() and not buf[2 * o:].any()                # the other tiles' slots stay zero: an all-reduce is a gather
+
+
+@pytest.mark.parametrize("H,W,diag", [(37, 37, True), (20, 31, False), (2, 2, True)])
+def test_edge_lists_are_checked_against_the_grid_before_a_block_is_cut(H, W, diag):
+    """tiles.edges_fit_grid: the host-side form of phmrf_block_set_grid's 'edge list joins nodes that are not grid neighbours'
+    (the stencil of utility.py:1899-1905), asked before a block is cut into row tiles: a block whose list fails stays whole."""
+    from phylo_hmrf_amd import tiles
+    from phylo_hmrf_amd.graph_host import grid_edges
+    n = tiles.rows_nodes(0, H, W, diag)
+    i, j = tiles.node_coords(np.arange(n), W, diag)
+    ii, jj = np.triu_indices(H) if diag else np.divmod(np.arange(n), W)
+    assert np.array_equal(i, ii) and np.array_equal(j, jj)
+    X = np.random.default_rng(0).random((n, 3)) + 0.1
+    for nn in (8, 4):
+        assert tiles.edges_fit_grid(grid_edges(X, H, W, diag, nn)[:, :2], H, W, diag, nn)
+    e = grid_edges(X, H, W, diag, 8)
+    if n > 10:
+        bad = e.copy()
+        bad[0, 1] = n - 1                                             # joins the first node with the last
+        assert not tiles.edges_fit_grid(bad[:, :2], H, W, diag, 8)
+        assert not tiles.edges_fit_grid(e[:, :2], H, W, diag, 4)      # diagonal edges in a 4-neighbour block
+        bad = e.copy()
+        bad[1, 0] = n                                                 # a node id outside the block
+        assert not tiles.edges_fit_grid(bad[:, :2], H, W, diag, 8)
+    # the coordinates hold at the 10 kb chr1 block's size (310 M nodes: the float root is corrected)
+    W2 = 24896
+    n2 = W2 * (W2 + 1) // 2
+    ids = np.array([0, W2 - 1, W2, n2 - 1, n2 - 2, n2 - 3, 12345678901 % n2])
+    i, j = tiles.node_coords(ids, W2, True)
+    assert np.array_equal(i * W2 - (i * (i - 1)) // 2 + (j - i), ids) and (i <= j).all() and (j < W2).all()
+
+
+def test_tile_holders_that_disagree_on_the_schedule_fail_instead_of_hanging():
+    """Every holder of a block's tiles decides on the same sums; the status each decided travels with the next round's
+    payload, and a disagreement raises on every rank (instead of leaving the others in the next all-reduce)."""
+    from phylo_hmrf_amd import tiles
+
+    class B(object):
+        def solve_round_collect(self):
+            return np.zeros(128, dtype=np.uint64), np.zeros(2)
+
+        def tile_get_boundary(self, a, b):
+            return (np.zeros(a, dtype=np.uint8) if a else None), (np.zeros(b, dtype=np.uint8) if b else None)
+
+        def tile_put_halo(self, a, b):
+            pass
+
+        def solve_round_decide(self, c, e):
+            return 0
+
+    class Comm(object):                       # the other rank's tile reports that it decided "converged" last round
+        def allreduce_i64(self, buf):
+            buf = buf.copy()
+            buf[1 * g.slot + 128 + 2] = 1 + 1
+            return buf
+
+    tl = tiles.Tile(40, 40, True, 0, 20, 0, 2, 4, 5, lambda n, S, K: B())
+    g = tiles.TileGroup(0, (40, 40, True), 2, {0: tl}, Comm())
+    with pytest.raises(RuntimeError, match="disagree on the schedule"):
+        g.finish_round()
