@@ -20,14 +20,14 @@ north_star's "whole-genome run ... at 8 GPUs".  --scaling weak: N copies of the 
 out the same way, work per GPU fixed.
 
 Extra objects on the JSON line:
-  "roofline"          the kernel class with the largest device time: algorithmic bytes (SURVEY.md 8d accounting x the
-                      units the launches actually processed, COUNTED ON THE DEVICE) / the time during which at least one
-                      kernel of the class was running (HIP events on the blocks' streams, merged on one time line, so the
-                      class's time per step can never exceed ms_per_step), against the 8 TB/s HBM peak.  In the timed region
-                      only this class carries events (the timers of all ten cost 4 - 5 ms per EM iteration); `kernels` is
-                      filled by an instrumented pass after it.  `kernel_frac_isolated`: the same bytes over a launch's OWN
-                      duration (one block at a time, after the timed region) -- the kernel's fraction, where `frac` is
-                      the class's throughput with up to fourteen launches overlapping.
+  "roofline"          the kernel with the largest device time: `frac` = algorithmic bytes (SURVEY.md 8d accounting x the
+                      units the launches actually processed, COUNTED ON THE DEVICE) / the sum of the launches' OWN durations /
+                      the 8 TB/s HBM peak -- own durations from HIP events with one block in flight at a time (the timed region
+                      itself under --block-threads 1, otherwise an isolated pass right after it), split into `full_sweep` (first
+                      round of a solve) and `mop_up` launches.  `class_throughput` is what round 4 called frac: the class's bytes
+                      over the time during which at least one of its launches was running, fourteen blocks in flight.  In the
+                      timed region only this class carries events (the timers of all ten cost 4 - 5 ms per EM iteration);
+                      `kernels` is filled by an instrumented pass after it.
   "roofline_limiter"  what actually bounds that kernel, from this run's device counters only (LDS bytes, pairs, cells, DP
                       steps); the explanation -- instruction issue of in-order waves at 4 waves per SIMD -- and the
                       measurements behind it are in DESIGN.md 3.3 and profiles/README.md.
@@ -35,6 +35,8 @@ Extra objects on the JSON line:
   "cold_first_iteration_ms"  the first EM iteration of the warm-up (from argmax labels; child blocks allocated).
   "fit"               the whole fit under the reference's own stopping rules, run after the timed region (not part of
                       `value`): iterations executed, wall, node-iterations/s over the whole fit, per-iteration E-step ms.
+  "fit_reference_start"  the same whole fit with every labelling started from labels_local, as the reference does
+                      (phylo_hmrf.py:479): the drop-in's number under the reference's own rule next to `fit` (--warm-start best).
 
 Multi-GPU, round 4: a block that holds more than --split-above x a rank's share of the nodes is cut into ROW TILES held by
 different ranks (phylo_hmrf_amd/tiles.py: lockstep rounds, one small all-reduce per block and round), and the M-step's K
@@ -272,7 +274,7 @@ def main():
         b.sync()
     setup_s = time.time() - t_setup
     stats_dev = torch.zeros((max(len(unit_blocks), 1), n_stats + 4), dtype=torch.float64, device=dev)
-    state = dict(min_cost=1e30, params=params_cur.copy(), means=means, covars=covars)
+    state = dict(min_cost=1e30, params=params_cur.copy(), means=means, covars=covars, warm_start=a.warm_start)
     solver = dict(max_rounds=64, use_chains=True, use_components=True, use_strips=True, use_expansion=not a.no_expansion,
                   energy_tol_ppb=a.energy_tol_ppb)
     t_e, t_m = [], []
@@ -292,7 +294,7 @@ def main():
         b = blocks[i]
         tb0 = time.time()
         b.emission(state["means"], state["covars"])
-        if a.warm_start == "best":
+        if state["warm_start"] == "best":
             b.warm_start(a.beta, SLOT_LOCAL, report=False)     # labels_local or the previous E-step's labels: the lower energy
         else:
             b.restore_labels(SLOT_LOCAL)                       # init_labels = labels_local (phylo_hmrf.py:479)
@@ -303,7 +305,7 @@ def main():
             block_trace.append((i, b.n, tb0, time.time()))
 
     def tile_prepare(tl):
-        if a.warm_start != "best":
+        if state["warm_start"] != "best":
             tl.b.restore_labels(SLOT_LOCAL)
         tl.b.emission(state["means"], state["covars"])
 
@@ -322,7 +324,7 @@ def main():
             pending = runner.start(estep_block, order)
         if conductor.groups:
             conductor.solve(a.beta, solver, prepare=tile_prepare, finish=tile_finish,
-                            warm_slot=SLOT_LOCAL if a.warm_start == "best" else None)
+                            warm_slot=SLOT_LOCAL if state["warm_start"] == "best" else None)
             for tl in local_tiles:
                 tl.b.sync()
         if pending is not None:
@@ -440,19 +442,20 @@ def main():
                 ce = e0
         return float(tot + ce - cs)
 
-    def collect():
-        """per kernel class [stream ms, launches, algorithmic bytes] and the device-counted work, over this rank's blocks"""
+    def collect(first=False):
+        """per kernel class [stream ms, launches, algorithmic bytes] and the device-counted work, over this rank's blocks
+        (first: only the launches of the FIRST round of every solve -- a warm start's full sweeps)"""
         agg_, work_ = {}, dict(units=0, cells=0, staged_cells=0, dp_steps=0, launches=0, swept_cells=0, label_cells=0,
                                proposal_nodes=0)
         for b in unit_blocks:
-            for name, (ms, ln) in b.timing().items():
+            for name, (ms, ln) in (b.timing_first() if first else b.timing()).items():
                 d = agg_.setdefault(name, [0.0, 0, 0.0])
                 d[0] += ms
                 d[1] += ln
                 kb = kernel_bytes(name, b.n, K, S)
                 if kb is not None:
                     d[2] += kb * ln
-            for k, v in b.work().items():
+            for k, v in (b.work_first() if first else b.work()).items():
                 work_[k] += v
         if "strip" in agg_:
             agg_["strip"][2] = strip_bytes(work_)
@@ -463,6 +466,7 @@ def main():
         return agg_, work_
 
     agg_dom, work = collect()                                  # the timed region: the dominant class's events, all classes' work
+    agg_dom_first, _ = collect(first=True)
     busy_dom = {name: union_ms(np.concatenate([b.intervals(name) for b in unit_blocks] or [np.zeros((0, 2))]))
                 for name in agg_dom} if not a.no_kernel_timing and unit_blocks else {}
     # ---- the instrumented pass: a few more EM iterations with every class timed (after the timed region, not part of `value`)
@@ -483,13 +487,14 @@ def main():
     # ---- the same E-step once more, ONE BLOCK AT A TIME (after the timed region; not part of `value`): with a single
     #      stream in flight a launch's event time is the kernel's own duration, which the concurrent streams of the timed
     #      region cannot give (there a launch shares the GPU with up to thirteen others)
-    isolated = {}
+    isolated, agg_i, agg_i_first = {}, {}, {}
     if not a.no_kernel_timing and unit_blocks:
         for b in unit_blocks:
             b.reset_timing()
         estep_all(sequential=True)
         torch.cuda.synchronize()
         agg_i, _ = collect()
+        agg_i_first, _ = collect(first=True)
         isolated = {k: {"launches": int(v[1]), "avg_launch_us": round(v[0] * 1e3 / max(v[1], 1), 2),
                         "GBps": (round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[2] > 0 else None)}
                     for k, v in agg_i.items()}
@@ -498,13 +503,14 @@ def main():
     #      rules -- threshold 0.001 and at most 60 iterations (phylo_hmrf.py:1555, :1561), the relative-change tests after
     #      iteration 5 and the 50-iterations-past-the-minimum test (base.py:428-435), no M-step after the last E-step --
     #      cold first iteration included.  Same code path as the timed region; kernel timers off.
-    fit = None
-    if not a.no_fit:
+    def run_fit(warm_start):
+        """the whole fit from the bench's start under the reference's stopping rules, with the given start of an E-step's
+        labelling ("local": labels_local as the reference, phylo_hmrf.py:479; "best": that or the previous labelling)"""
         for b in unit_blocks:
             b.enable_timing(False)
             b.restore_labels(SLOT_INIT)
             b.save_labels(SLOT_LOCAL)
-        state.update(min_cost=1e30, params=params_cur.copy(), means=means, covars=covars)
+        state.update(min_cost=1e30, params=params_cur.copy(), means=means, covars=covars, warm_start=warm_start)
         gen = np.random.default_rng(a.seed + 4242)
         threshold, m_iter, max_iter1 = 0.001, 60, 50
         pre = [0.001, 0.001, 0.001]
@@ -547,40 +553,83 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fit_wall = float(t.item())
         iters = len(e_ms)
-        fit = {"iterations": iters, "stopped_by": stop, "wall_s": round(fit_wall, 4),
-               "value": n_norm * iters / fit_wall, "unit": "node-iterations/s over the whole fit (cold first iteration included)",
-               "estep_ms": [round(x, 2) for x in e_ms], "mstep_ms_mean": round(float(np.mean(m_ms)), 3) if m_ms else None,
-               "cost1": c1, "rules": "threshold 0.001, m_iter 60 (phylo_hmrf.py:1555,1561); base.py:416-435"}
+        state["warm_start"] = a.warm_start
+        return {"warm_start": warm_start, "iterations": iters, "stopped_by": stop, "wall_s": round(fit_wall, 4),
+                "value": n_norm * iters / fit_wall, "unit": "node-iterations/s over the whole fit (cold first iteration included)",
+                "estep_ms": [round(x, 2) for x in e_ms], "mstep_ms_mean": round(float(np.mean(m_ms)), 3) if m_ms else None,
+                "cost1": c1, "rules": "threshold 0.001, m_iter 60 (phylo_hmrf.py:1555,1561); base.py:416-435"}
+
+    # `fit`: with the start of an E-step's labelling this run was asked for (--warm-start; default "best");
+    # `fit_reference_start`: the same whole fit under the REFERENCE's own rule -- every labelling starts from labels_local
+    # (phylo_hmrf.py:479, base.py:416-420) -- so that the line carries the drop-in's number under the reference's policy next
+    # to the build's (--warm-start local makes the two the same run: it is then not repeated)
+    fit = fit_ref = None
+    if not a.no_fit:
+        fit = run_fit(a.warm_start)
+        fit_ref = fit if a.warm_start == "local" else run_fit("local")
 
     roofline = roofline_limiter = None
     # the dominant class among those with a byte model (the coarse expansions' gathers have none)
     with_model = {k: v for k, v in agg.items() if v[2] > 0}
     dom_name = max(with_model.items(), key=lambda kv: kv[1][0])[0] if with_model else None
     dom_name = dominant if (dominant in agg_dom and agg_dom[dominant][2] > 0) else dom_name
+    def own_split(all_, first_, name):
+        """launches of a class whose event times are the kernel's OWN durations (one stream in flight), split into the full
+        sweeps (first round of a solve) and the mop-up launches (later rounds: strips whose inputs changed)"""
+        ms, ln, by = all_[name]
+        fms, fln, fby = first_.get(name, [0.0, 0, 0.0])
+
+        def part(ms_, ln_, by_):
+            return {"launches": int(ln_), "bytes": int(by_), "own_ms": round(ms_, 4),
+                    "avg_launch_us": round(ms_ * 1e3 / max(ln_, 1), 2),
+                    "GBps": (round(by_ / (ms_ * 1e-3) / 1e9, 1) if ms_ > 0 and by_ > 0 else None)}
+        return part(ms, ln, by), part(fms, fln, fby), part(ms - fms, ln - fln, max(by - fby, 0.0))
+
     if dom_name and busy_dom.get(dom_name, 0) > 0 and agg_dom[dom_name][2] > 0:
         dom_ms, dom_launches, dom_bytes = agg_dom[dom_name]           # (measured in the timed region)
         busy_d = busy_dom[dom_name]
-        ach = dom_bytes / (busy_d * 1e-3) / 1e9
+        cls_ach = dom_bytes / (busy_d * 1e-3) / 1e9
         kernel_names = KERNELS_OF_CLASS.get(dom_name, [])
         traffic, traffic_note = pmc_traffic(a.workload, kernel_names)
-        iso = isolated.get(dom_name) or {}
-        roofline = {"bound": "hbm", "kernel": dom_name, "kernel_names": kernel_names, "achieved": round(ach, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": traffic_note, "launches": int(dom_launches),
-                    "algorithmic_bytes_per_launch": int(dom_bytes / max(dom_launches, 1)),
-                    "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2),
-                    "busy_ms_per_step": round(busy_d / a.steps, 3),
-                    "isolated": isolated.get(dom_name),
-                    "kernel_frac_isolated": (round(iso["GBps"] / HBM_PEAK_GBS, 5) if iso.get("GBps") else None),
-                    "note": "achieved = algorithmic bytes (SURVEY.md 8d accounting x the cells the launches processed, "
-                            "counted on the device) / time during which >= 1 launch of the class was running (blocks "
-                            "run concurrently on their own streams: a CLASS throughput); avg_launch_us = mean launch "
-                            "duration in the timed region, incl. the share of the GPU other streams took; isolated = the "
-                            "same E-step run one block at a time right after the timed region -- a launch's own duration "
-                            "and the rate at it, kernel_frac_isolated = that rate / peak: the fraction to compare with "
-                            "the rocprofv3 kernel durations under profiles/; traffic = PMC FETCH_SIZE + WRITE_SIZE per "
-                            "launch of the named kernels from the committed rocprofv3 passes, only if they were taken "
-                            "with this build (traffic_source)"}
+        # The kernel's fraction: algorithmic bytes / the launches' OWN durations / peak.  With one block in flight at a time
+        # (--block-threads 1: the profiled serial runs) the timed region's own event times are that; otherwise the isolated
+        # pass right after the timed region supplies them (same EM trajectory, one block at a time).
+        serial = runner.n_threads == 1 and not conductor.groups
+        if serial:
+            own_all, own_full, own_mop = own_split(agg_dom, agg_dom_first, dom_name)
+            own_from = "the timed region (--block-threads 1: one stream in flight, an event pair times the kernel alone)"
+        elif dom_name in agg_i:
+            own_all, own_full, own_mop = own_split(agg_i, agg_i_first, dom_name)
+            own_from = "the isolated pass: the same E-step one block at a time right after the timed region (not part of `value`)"
+        else:
+            own_all = own_full = own_mop = None
+            own_from = None
+        ach = own_all["GBps"] if own_all and own_all["GBps"] else None
+        roofline = {"bound": "hbm", "kernel": dom_name, "kernel_names": kernel_names,
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (round(ach / HBM_PEAK_GBS, 5) if ach else None),
+                    "traffic": traffic, "traffic_source": traffic_note,
+                    "own_durations_from": own_from,
+                    "launches": (own_all or {}).get("launches"),
+                    "algorithmic_bytes_per_launch": (int(own_all["bytes"] / max(own_all["launches"], 1)) if own_all else None),
+                    "avg_launch_us": (own_all or {}).get("avg_launch_us"),
+                    "full_sweep": own_full, "mop_up": own_mop,
+                    "class_throughput": {"achieved": round(cls_ach, 2), "frac": round(cls_ach / HBM_PEAK_GBS, 5),
+                                         "launches": int(dom_launches),
+                                         "algorithmic_bytes_per_launch": int(dom_bytes / max(dom_launches, 1)),
+                                         "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2),
+                                         "busy_ms_per_step": round(busy_d / a.steps, 3),
+                                         "note": "timed region, blocks in flight on their own streams: bytes of all launches of the "
+                                                 "class / time during which >= 1 of them was running -- a throughput of the CLASS with "
+                                                 "overlapping launches (round 4 reported this as `frac`), not the kernel's fraction"},
+                    "note": "frac = algorithmic bytes (SURVEY.md 8d accounting x the cells the launches processed, counted on the "
+                            "device) / the sum of the launches' OWN durations / peak, over every launch of the dominant kernel in "
+                            "the pass named by own_durations_from -- the number to hold against AverageNs of the kernel in the "
+                            "rocprofv3 --kernel-trace --stats summary of a --block-threads 1 run (profiles/, tests/"
+                            "test_roofline_profiles.py).  full_sweep = the launches of the first round of a solve (both "
+                            "orientations over the whole block), mop_up = the later rounds' (strips whose inputs changed: bound by "
+                            "one wave's label loop, few bytes).  traffic = PMC FETCH_SIZE x 2 + WRITE_SIZE per launch of the named "
+                            "kernels from the committed rocprofv3 passes, only if taken with this build (traffic_source)"}
         if dom_name in ("strip", "fusion"):
             # what the strip kernels move through LDS (device counters): a DP step reads 64 lanes x 8 B and its cell's
             # table (128 B) was written once; staging writes 17 B per staged cell and reads 9 x 5 B back per strip cell
@@ -619,7 +668,7 @@ def main():
             "metric": "EM-iterations/sec x nodes (bin-pairs)", "value": value, "unit": "node-iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": a.workload + ": " + desc,
+            "config": {"workload": "%s: %s; E-step start: %s" % (a.workload, desc, START_POLICY[a.warm_start]),
                        "sharding": ("%d blocks (%d nodes) as %d units (%d blocks cut into row tiles: those above %.2f x a rank's "
                                     "share) dealt to %d rank(s) by longest-processing-time-first; %s"
                                     % (len(all_blocks), n_global, len(units), n_split, a.split_above, eworld,
@@ -639,6 +688,7 @@ def main():
             "ms_per_step_median": float(np.median(np.asarray(t_e_timed) + np.asarray(t_m_timed)) * 1e3),
             "cold_first_iteration_ms": cold_first_ms,
             "fit": fit,
+            "fit_reference_start": fit_ref,
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
             "value_estep_only": n_norm * a.steps / float(np.sum(t_e_timed)),
@@ -671,6 +721,9 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+START_POLICY = {"best": "warm_start=best (labels_local or the previous labelling, whichever has the lower energy; the "
+                        "reference's rule is warm_start=local: see fit_reference_start)",
+                "local": "warm_start=local (labels_local, as the reference: phylo_hmrf.py:479)"}
 KERNELS_OF_CLASS = {"strip": ["strip_cols_kernel"], "fusion": ["fusion_cols_kernel", "strip_kernel"],
                     "propose": ["propose_grid_kernel", "propose_kernel"], "emission": ["emission_kernel"],
                     "energy": ["energy_grid_kernel", "energy_delta_grid_kernel", "energy_kernel"],
@@ -789,8 +842,8 @@ def cpu_baseline(a, S, K, nn, n_blocks=1, n_total=0, n_max=0):
          ref-vectorised  the same arithmetic in vectorised NumPy -- a fair CPU ceiling for that part
     One core = one reference block process (base.py:357-362).  The reference runs one process per block, so on C cores
     its whole-workload rate is at most min(#blocks, C, N_tot / n_largest_block) times the single-core figure
-    (`all_cores_upper_bound`, extrapolated, not measured); `measured_parallel` is the same faithful sample run in up to 8
-    fresh processes at once on this box's cores (one block each): measured, for that many cores.  The reference's M-step (K SLSQP runs, ~0.6 s each) is NOT
+    (`all_cores_upper_bound`, extrapolated, not measured); `measured_parallel` is the same faithful sample run in
+    min(#blocks, cores) fresh processes at once on this box's cores (one block each, as the reference would): measured.  The reference's M-step (K SLSQP runs, ~0.6 s each) is NOT
     included although `value` includes the build's M-step.  A stated baseline, never the target."""
     from oracle import gco_ref, ref_numpy as R, synth
     N = a.cpu_sample
@@ -839,7 +892,7 @@ def cpu_baseline(a, S, K, nn, n_blocks=1, n_total=0, n_max=0):
             "variant": "ref-faithful (Python posterior loops)",
             "vectorised": {"value": n / (t_em + t_cut + t_vec), "unit": "node-iterations/s", "cores": 1,
                            "variant": "ref-vectorised (same arithmetic in NumPy)"},
-            "measured_parallel": cpu_parallel(a, S, K, nn, int(max(1, min(8, cores // 2, n_blocks or 1)))),
+            "measured_parallel": cpu_parallel(a, S, K, nn, int(max(1, min(cores, n_blocks or 1)))),
             "all_cores_upper_bound": {"faithful": faithful * par, "vectorised": n / (t_em + t_cut + t_vec) * par,
                                       "processes": "one per block as in base.py:357-362: at most min(%d blocks, %d cores, "
                                                    "N_tot / largest block = %.1f) = %.1f x one core; extrapolated, not measured"

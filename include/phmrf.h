@@ -48,9 +48,9 @@ typedef struct phmrf_block* phmrf_block_t;
 /* ---- library ---------------------------------------------------------------------------------- */
 /* ABI version = major * 100 + minor.  110 (round 4): PHMRF_NUM_KERNEL_CLASSES is 10 and phmrf_block_get_timing takes the
  * capacity of the caller's arrays; phmrf_block_get_work writes 8 values; the resumable solve (phmrf_mrf_solve_begin ...
- * _end) and the row-tile entry points are new.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
+ * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
  * (phylo_hmrf_amd/_lib.py does). */
-#define PHMRF_VERSION 110
+#define PHMRF_VERSION 120
 PHMRF_API int phmrf_version(void);
 PHMRF_API const char* phmrf_last_error(void);
 PHMRF_API const char* phmrf_status_string(int status);
@@ -298,6 +298,8 @@ PHMRF_API int phmrf_block_enable_timing(phmrf_block_t b, int enable);
 PHMRF_API int phmrf_block_set_timing_classes(phmrf_block_t b, uint32_t class_mask);
 /* capacity = the length of the caller's arrays; min(capacity, PHMRF_NUM_KERNEL_CLASSES) entries are written */
 PHMRF_API int phmrf_block_get_timing(phmrf_block_t b, int capacity, double* ms /*[capacity]*/, int64_t* launches /*[capacity]*/);
+/* ... and the part of both that belongs to launches of the FIRST round of a solve (see phmrf_block_get_work_first) */
+PHMRF_API int phmrf_block_get_timing_first(phmrf_block_t b, int capacity, double* ms /*[capacity]*/, int64_t* launches /*[capacity]*/);
 PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
 /* Work the strip kernels (class 6) actually did since the last reset, counted ON THE DEVICE (inside a solve a strip
  * whose inputs did not change since its last quiet run is skipped after a look at its stamps and counts nothing):
@@ -310,6 +312,10 @@ PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
  *            out[6] cells x labels examined (one label's unary term per cell)
  *   out[7] nodes whose fusion proposal was recomputed (the proposal kernels skip node tiles without a new change stamp)  */
 PHMRF_API int phmrf_block_get_work(phmrf_block_t b, int64_t* out /*[8]*/);
+/* The part of that work done in the FIRST round of every solve since the reset (same slots): a warm-started solve's first
+ * round is the full sweep of both orientations, the later rounds revisit the strips whose inputs changed -- the two kinds of
+ * launch a roofline figure has to keep apart (bench.py: roofline.full_sweep / roofline.mop_up). */
+PHMRF_API int phmrf_block_get_work_first(phmrf_block_t b, int64_t* out /*[8]*/);
 /* The timed intervals of one kernel class on a time base common to all blocks of the calling thread's device
  * (phmrf_time_base_reset marks t = 0; call it before the timed region): out = [start_ms, end_ms] pairs, at most
  * `capacity` of them; *count = how many there are.  Blocks run on their own streams, so their intervals overlap:

@@ -75,6 +75,13 @@ def parse_args(argv=None):
                       "(phylo_hmrf.py:234-238) for the centres, the assignment of all nodes and the per-cluster "
                       "statistics on the GPU; 'sklearn' = the reference's initialisation verbatim on the host; "
                       "'device' = Lloyd k-means on the GPU")
+    parser.add_option("--warm_start", default="best", help="start of an E-step's labelling: 'local' = labels_local, the labels of "
+                      "the iteration with the lowest cost so far, as the reference does (phylo_hmrf.py:479); 'best' (default) = "
+                      "that or the previous E-step's labels, whichever has the lower energy under the new parameters")
+    parser.add_option("--checkpoint", default="", help="write an .npz checkpoint of the fit here after every "
+                      "--checkpoint_every-th EM iteration (parameters, cost bookkeeping, labellings, random generator)")
+    parser.add_option("--checkpoint_every", default="1", help="EM iterations between checkpoints")
+    parser.add_option("--resume", default="", help="continue a fit from this checkpoint (same data, states and options)")
     parser.add_option("-h", "--help", action="help")
     opts, _ = parser.parse_args(argv)
     return opts
@@ -132,7 +139,7 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
         initial_mode, initial_weight, initial_weight1, initial_magnitude, position1, position2, filter_sigma, beta,
         beta1, num_neighbor, filter_mode, conv_threshold, estimate_type, simu_version, annotation, reload_mode,
         diagonal_type, m_iter, resolution, quantile, ref_species, output_path, synthetic="0", seed="", quiet="0",
-        init_method="minibatch"):
+        init_method="minibatch", warm_start="best", checkpoint="", checkpoint_every="1", resume=""):
     run_id = int(run_id1)
     n_components1 = int(num_states)
     cons_param = float(cons_param)
@@ -228,7 +235,8 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
                           beta=beta, beta1=beta1, initial_mode=initial_mode, initial_weight=initial_weight,
                           initial_weight1=initial_weight1, initial_magnitude=initial_magnitude, learning_rate=0.001,
                           estimate_type=estimate_type, max_iter=100, n_iter=5000, tol=1e-7, num_neighbor=num_neighbor,
-                          random_state=seed, quiet=bool(int(quiet)), init_method=init_method)
+                          random_state=seed, quiet=bool(int(quiet)), init_method=init_method, warm_start=warm_start,
+                          checkpoint_path=checkpoint or None, checkpoint_every=int(checkpoint_every), resume_from=resume or None)
         print("fitting...")
         lambda_0 = cons_param
         filename = "%s/estimate_ou_%d_%.2f_%d_%s" % (output_path, run_id, lambda_0, n_components1, annotation)
@@ -260,4 +268,5 @@ if __name__ == "__main__":
         opts.initial_magnitude, opts.position1, opts.position2, opts.filter_sigma, opts.beta, opts.beta1,
         opts.num_neighbor, opts.filter_mode, opts.threshold, opts.estimate_type, opts.simu_version, opts.annotation,
         opts.reload, opts.dtype, opts.miter, opts.resolution, opts.quantile, opts.ref_species, opts.output,
-        synthetic=opts.synthetic, seed=opts.seed, quiet=opts.quiet, init_method=opts.init)
+        synthetic=opts.synthetic, seed=opts.seed, quiet=opts.quiet, init_method=opts.init, warm_start=opts.warm_start,
+        checkpoint=opts.checkpoint, checkpoint_every=opts.checkpoint_every, resume=opts.resume)

@@ -3,6 +3,9 @@
 What is kept: the method name, argument order, return tuple, the per-iteration bookkeeping (cost weighting by
 n_r/N, cost_vec rows, min_cost / min_cost1 tracking, labels_local warm start, t_labels from iteration 3 on,
 the three stopping rules, no M-step after the last E-step) and the per-iteration prints.
+New (optional, SURVEY.md section 5 "checkpoint/resume": the reference keeps everything in RAM only, base.py:412): a
+checkpoint per EM iteration (`checkpoint_path`, `checkpoint_every`) and `resume_from` -- the loop restarts at the saved
+iteration with the same bookkeeping state (base.py:402-435), labels snapshots and random generator.
 What is different: the E-step of every syntenic block runs on the GPU (no fork / Queue / pickle, base.py:352-372);
 labels stay on the device (labels_local / t_labels are device snapshots) and only the K*(1+S+S*S)+4 numbers of the
 reduction leave it; with several ranks the blocks are sharded and the reduction is one all-reduce.
@@ -40,6 +43,13 @@ class _BaseGraph(object):
         self.estimate_type = estimate_type
         self.weight_type = weight_type
         self.quiet = False
+        # optional .npz checkpoint of the fit (written by rank 0 after the M-step of every `checkpoint_every`-th iteration,
+        # atomically: temporary file + rename) and the file a fit resumes from (read by every rank)
+        self.checkpoint_path = None
+        self.checkpoint_every = 1
+        self.checkpoint_labels = True
+        self.resume_from = None
+        self.em_iteration_ = -1
 
     def _log(self, *a):
         if not self.quiet:
@@ -86,13 +96,76 @@ class _BaseGraph(object):
         """-> [(stats dict, cost numerators[4], owned nodes)] of the row tiles this rank holds (none by default)"""
         return []
 
+    # ---- checkpoint / resume -----------------------------------------------------------------------
+    CHECKPOINT_FORMAT = 1
+
+    def _write_checkpoint(self, it_next, loop):
+        """State of the fit after the M-step of iteration it_next - 1: everything the loop of fit_accumulate_test carries
+        (base.py:402-435), the model parameters, the random generator, and -- unless checkpoint_labels is off -- the three
+        labellings a resumed fit needs (labels_local, t_labels, the previous E-step's result).  Collective when the labels
+        are included (they are gathered from the ranks); rank 0 writes."""
+        import json
+        import os
+        d = dict(format=self.CHECKPOINT_FORMAT, it_next=it_next, n_components=self.n_components, n_features=self.n_features,
+                 params_vec1_model=self.params_vec1, means_=self.means_, covars_=self._covars_,
+                 init_ou_params=self.init_ou_params, cost_vec=np.asarray(loop["cost_vec"], dtype=np.float64).reshape(-1, 4),
+                 params_vecList=np.asarray(loop["params_vecList"]), min_cost=np.asarray(loop["min_cost"], dtype=np.float64),
+                 min_cost1=np.asarray(loop["min_cost1"], dtype=np.float64), params_vec_best=loop["params_vec"],
+                 params_vec1_best=loop["params_vec1"], pre=np.asarray(loop["pre"], dtype=np.float64),
+                 have_t_labels=int(loop["have_t_labels"]), rng_state=json.dumps(self.rng.bit_generator.state),
+                 len_vec=np.asarray(self.len_vec))
+        if self.checkpoint_labels:
+            self._snapshot_labels(SLOT_CURRENT)
+            d["labels_current"] = self._gather_labels(SLOT_CURRENT).astype(np.uint8)
+            d["labels_local"] = self._gather_labels(SLOT_LOCAL).astype(np.uint8)
+            if loop["have_t_labels"]:
+                d["labels_best3"] = self._gather_labels(SLOT_BEST3).astype(np.uint8)
+        if getattr(self, "rank", 0) == 0:
+            tmp = self.checkpoint_path + ".tmp.npz"
+            np.savez(tmp, **d)
+            os.replace(tmp, self.checkpoint_path)
+
+    def _read_checkpoint(self, path, loop):
+        """-> the iteration to continue with; fills `loop` and the model from the file, puts the labellings back on the device"""
+        import json
+        z = np.load(path, allow_pickle=False)
+        if int(z["format"]) != self.CHECKPOINT_FORMAT:
+            raise ValueError("checkpoint %s has format %d, this build reads %d" % (path, int(z["format"]), self.CHECKPOINT_FORMAT))
+        if int(z["n_components"]) != self.n_components or int(z["n_features"]) != self.n_features or \
+                not np.array_equal(np.asarray(z["len_vec"]), np.asarray(self.len_vec)):
+            raise ValueError("checkpoint %s belongs to another model or data set (states, species or len_vec differ)" % path)
+        if "labels_local" not in z.files:
+            raise ValueError("checkpoint %s was written without the labellings (checkpoint_labels=False): parameters can be "
+                             "read from it, a fit cannot resume from it" % path)
+        self.params_vec1 = z["params_vec1_model"].copy()
+        self.means_, self._covars_ = z["means_"].copy(), z["covars_"].copy()
+        self.init_ou_params = z["init_ou_params"].copy()
+        loop["cost_vec"] = [list(r) for r in z["cost_vec"].tolist()]
+        for r in loop["cost_vec"]:
+            r[0] = int(r[0])
+        loop["params_vecList"] = [p.copy() for p in z["params_vecList"]]
+        loop["min_cost"] = [int(z["min_cost"][0]), float(z["min_cost"][1])]
+        loop["min_cost1"] = [int(z["min_cost1"][0]), float(z["min_cost1"][1])]
+        loop["params_vec"], loop["params_vec1"] = z["params_vec_best"].copy(), z["params_vec1_best"].copy()
+        loop["pre"] = z["pre"].tolist()
+        loop["have_t_labels"] = bool(int(z["have_t_labels"]))
+        self.rng.bit_generator.state = json.loads(str(z["rng_state"]))
+        if loop["have_t_labels"]:
+            self._upload_labels_slot(np.int64(z["labels_best3"]), SLOT_BEST3)
+        self._upload_labels_slot(np.int64(z["labels_local"]), SLOT_LOCAL)
+        self._upload_labels_slot(np.int64(z["labels_current"]), None)        # last: the blocks' current labelling
+        return int(z["it_next"])
+
     # ---- the fit loop ----------------------------------------------------------------------------
     def fit_accumulate_test(self, X, len_vec, threshold, annotation, m_iter, lengths=None):
         """Estimate model parameters.  Returns
         (params_vec, params_vec1, params_vecList, iter_id1, iter_id2, cost_vec, t_labels)   (base.py:455)."""
         self._log("Initilization...")
         start = time.time()
-        self._init(X, lengths=lengths)
+        if self.resume_from:
+            _BaseGraph._init(self, X, lengths=lengths)    # (start / transition vectors only: the rest comes from the file)
+        else:
+            self._init(X, lengths=lengths)
         self._log("use time %s:" % (time.time() - start))
         self._check()
         self._log("model fitting...")
@@ -112,9 +185,20 @@ class _BaseGraph(object):
         K, S = self.n_components, self.n_features
         self.timing_ = {"estep": [], "mstep": []}
 
+        it0 = 0
+        if self.resume_from:
+            loop = {}
+            it0 = self._read_checkpoint(self.resume_from, loop)
+            cost_vec, params_vecList = loop["cost_vec"], loop["params_vecList"]
+            min_cost, min_cost1 = loop["min_cost"], loop["min_cost1"]
+            params_vec, params_vec1 = loop["params_vec"], loop["params_vec1"]
+            pairwise_cost_pre, unary_cost_pre, cost1_pre = loop["pre"]
+            have_t_labels = loop["have_t_labels"]
+            self._log("resumed from %s at iteration %d" % (self.resume_from, it0))
         self._log("n_iter, m_iter: %d %d" % (self.n_iter, max_iter))
-        for it in range(max_iter):
+        for it in range(it0, max_iter):
             self._log(it)
+            self.em_iteration_ = it
             stats = self._initialize_sufficient_statistics()
             start = time.time()
             # E-step of the regions this rank owns; un-normalised cost sums travel with the statistics
@@ -171,6 +255,11 @@ class _BaseGraph(object):
             self._do_mstep(stats)
             self.timing_["mstep"].append(time.time() - start)
             self._log("maximization use time %d %s" % (it, time.time() - start))
+            if self.checkpoint_path and (it + 1) % max(int(self.checkpoint_every), 1) == 0:
+                self._write_checkpoint(it + 1, dict(cost_vec=cost_vec, params_vecList=params_vecList, min_cost=min_cost,
+                                                    min_cost1=min_cost1, params_vec=params_vec, params_vec1=params_vec1,
+                                                    pre=[pairwise_cost_pre, unary_cost_pre, cost1_pre],
+                                                    have_t_labels=have_t_labels))
 
         self.params_vec1 = params_vec1.copy()                              # base.py:444
         self._ou_param_varied_constraint(params_vec)                       # base.py:445

@@ -304,10 +304,24 @@ class Block(object):
         check(self._L.phmrf_block_get_timing(self._h, _lib.NUM_KERNEL_CLASSES, ms, ln))
         return {name: (ms[i], ln[i]) for i, name in enumerate(_lib.KERNEL_CLASSES)}
 
+    def timing_first(self):
+        """The part of timing() that belongs to launches of the first round of a solve (a warm start's full sweeps)."""
+        ms = (ctypes.c_double * _lib.NUM_KERNEL_CLASSES)()
+        ln = (ctypes.c_int64 * _lib.NUM_KERNEL_CLASSES)()
+        check(self._L.phmrf_block_get_timing_first(self._h, _lib.NUM_KERNEL_CLASSES, ms, ln))
+        return {name: (ms[i], ln[i]) for i, name in enumerate(_lib.KERNEL_CLASSES)}
+
     def work(self):
         """Device-counted work of the strip kernels since reset_timing."""
         out = (ctypes.c_int64 * 8)()
         check(self._L.phmrf_block_get_work(self._h, out))
+        return dict(units=out[0], cells=out[1], staged_cells=out[2], dp_steps=out[3], launches=out[4], swept_cells=out[5],
+                    label_cells=out[6], proposal_nodes=out[7])
+
+    def work_first(self):
+        """The part of work() done in the first round of every solve (a warm start's full sweeps) since reset_timing."""
+        out = (ctypes.c_int64 * 8)()
+        check(self._L.phmrf_block_get_work_first(self._h, out))
         return dict(units=out[0], cells=out[1], staged_cells=out[2], dp_steps=out[3], launches=out[4], swept_cells=out[5],
                     label_cells=out[6], proposal_nodes=out[7])
 

@@ -42,11 +42,13 @@ void tic(phmrf_block* b, int kclass) {
 }
 
 void toc(phmrf_block* b, int kclass, int n_launches) {
+  const bool first = b->ss && b->ss->rounds == 0;           // (a launch of the first round of a solve: the full sweeps)
   b->launches[kclass] += n_launches;
+  if (first) b->launches_first[kclass] += n_launches;
   if (!b->timing || !b->cur_start) return;
   hipEvent_t e = take_event(b);
   if (e && hipEventRecord(e, b->stream) == hipSuccess) {
-    b->pending.push_back({kclass, b->cur_start, e});
+    b->pending.push_back({kclass, b->cur_start, e, first});
   } else {                                                  // no event: this interval is not timed
     if (e) b->free_events.push_back(e);
     b->free_events.push_back(b->cur_start);
@@ -66,6 +68,7 @@ static void resolve_timing(phmrf_block* b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
       b->ms[p.kclass] += ms;
+      if (p.first) b->ms_first[p.kclass] += ms;
       float t0 = 0.f;
       if (base && hipEventElapsedTime(&t0, base, p.a) == hipSuccess) b->intervals.push_back({p.kclass, t0, t0 + ms});
     }
@@ -394,7 +397,10 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->memo);
   dev_free(b->chain_memo);
   dev_free(b->fwd_w);
-  dev_free(b->uT);
+  if (b->uT_raw) {                          // (the planes own their allocation; a coarse child's live in its parent's arena)
+    dev_free(b->uT_raw);
+    b->uT = nullptr;
+  }
   dev_free(b->emis_params);
   dev_free(b->posteriors);
   for (int r = 0; r < 2; ++r) {
@@ -796,10 +802,14 @@ static int work_fetch_async(phmrf_block_t b) {
   PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long), b->stream));
   return PHMRF_OK;
 }
-static void work_fold(phmrf_block_t b) {
+static void work_fold(phmrf_block_t b, bool first_round = false) {
   static const int SLOT_OF[WORK_SLOTS] = {0, 1, 2, 3, 5, 6, 7};   // work[4] = launches (host-counted)
   for (int k = 0; k < WORK_BANKS; ++k)
-    for (int q = 0; q < WORK_SLOTS; ++q) b->work[SLOT_OF[q]] += (int64_t)b->work_host[k * WORK_SLOTS + q];
+    for (int q = 0; q < WORK_SLOTS; ++q) {
+      const int64_t v = (int64_t)b->work_host[k * WORK_SLOTS + q];
+      b->work[SLOT_OF[q]] += v;
+      if (first_round) b->work_first[SLOT_OF[q]] += v;
+    }
 }
 
 static int check_solvable(phmrf_block_t b) {
@@ -852,7 +862,7 @@ static int energy_now(phmrf_block_t b, double beta, double* eu, double* ep) {
 // snapshot of the labels and its tick behind for the next.  (PHMRF_ENERGY_FULL=1: always the full pass;
 // PHMRF_ENERGY_CHECK=1: both, compared.)  The carried values are (unary, pair without beta).
 static int energy_round_launch(phmrf_block_t b, bool* incremental_out, bool* snapshot_out) {
-  static const bool always_full = getenv("PHMRF_ENERGY_FULL") != nullptr;
+  static const bool always_full = PHMRF_DEV_ENV("PHMRF_ENERGY_FULL") != nullptr;
   const bool grid = b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->stamp && b->tick > 0 && b->n >= (1 << 18);
   const bool snapshot = grid && !always_full;
   const bool incremental = snapshot && energy_delta_available(b);
@@ -875,7 +885,7 @@ static int energy_round_launch(phmrf_block_t b, bool* incremental_out, bool* sna
 
 // (the stream has been synchronised)  -> *eu, *ep_raw: unary and pair sum (without beta) after the round
 static int energy_round_collect(phmrf_block_t b, double beta, bool incremental, double* eu_carry, double* ep_carry) {
-  static const bool check = getenv("PHMRF_ENERGY_CHECK") != nullptr;
+  static const bool check = PHMRF_DEV_ENV("PHMRF_ENERGY_CHECK") != nullptr;
   double du, dp;
   if (b->deterministic) {             // 2^-20 fixed-point integers in the two slots (kernels.hip energy_flush)
     long long q[2];
@@ -1148,10 +1158,10 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   // pass, in order.  A label whose predecessors in the batch moved something gets its problem rebuilt first -- decided on
   // the device (coarse_apply_kernel raises b->coarse_flag, the one-label rebuild returns at once while it is down): the
   // sequence of labellings is the one-label-at-a-time sequence, the host never waits.  PHMRF_COARSE_BATCH=1: one by one.
-  static const int batch_env = getenv("PHMRF_COARSE_BATCH") ? atoi(getenv("PHMRF_COARSE_BATCH")) : 4;
+  static const int batch_env = PHMRF_DEV_ENV("PHMRF_COARSE_BATCH") ? atoi(PHMRF_DEV_ENV("PHMRF_COARSE_BATCH")) : 4;
   const int batch = (batch_env == 1 || batch_env == 2) ? batch_env : 4;
-  static const bool no_gate = getenv("PHMRF_COARSE_NO_GATE") != nullptr;      // development: A/B timing
-  static const bool no_stamp_gate = getenv("PHMRF_COARSE_NO_STAMP_GATE") != nullptr;
+  static const bool no_gate = PHMRF_DEV_ENV("PHMRF_COARSE_NO_GATE") != nullptr;      // development: A/B timing
+  static const bool no_stamp_gate = PHMRF_DEV_ENV("PHMRF_COARSE_NO_STAMP_GATE") != nullptr;
   phmrf_block* ch[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int q = 0; q < batch; ++q) PHMRF_TRY(coarse_child(b, level * 4 + q, &ch[q]));
   if (!b->coarse_flag) PHMRF_TRY(dev_alloc(&b->coarse_flag, (size_t)1));
@@ -1530,7 +1540,7 @@ int solve_round_collect(phmrf_block_t b, unsigned long long* counters, double* e
   if (!s->collected) {
     PHMRF_HIP(hipStreamSynchronize(b->stream));
     PHMRF_TRY(energy_round_collect(b, s->beta, s->incremental, &s->eu_carry, &s->ep_carry));
-    if (b->timing) work_fold(b);
+    if (b->timing) work_fold(b, s->rounds == 0);
     s->collected = true;
     if (b->tile_top || b->tile_bot) {
       unsigned long long viol = 0;
@@ -1702,7 +1712,7 @@ int solve_end(phmrf_block_t b, phmrf_solve_result* res) {
     res->converged = s->converged;
     res->changed = s->total;
   }
-  static const bool child_count = getenv("PHMRF_CHILD_COUNT") != nullptr;     // development (with PHMRF_SOLVE_TRACE)
+  static const bool child_count = PHMRF_DEV_ENV("PHMRF_CHILD_COUNT") != nullptr;     // development (with PHMRF_SOLVE_TRACE)
   if (child_count) {
     (void)hipStreamSynchronize(b->stream);
     for (int lv = 0; lv < 3; ++lv) {
@@ -2027,14 +2037,25 @@ int phmrf_block_get_timing(phmrf_block_t b, int capacity, double* ms, int64_t* l
   return PHMRF_OK;
 }
 
+int phmrf_block_get_timing_first(phmrf_block_t b, int capacity, double* ms, int64_t* launches) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(capacity >= 0, PHMRF_ERR_INVALID, "capacity < 0");
+  resolve_timing(b);
+  for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES && i < capacity; ++i) {
+    if (ms) ms[i] = b->ms_first[i];
+    if (launches) launches[i] = b->launches_first[i];
+  }
+  return PHMRF_OK;
+}
+
 int phmrf_block_reset_timing(phmrf_block_t b) {
   PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
   resolve_timing(b);
   for (int i = 0; i < PHMRF_NUM_KERNEL_CLASSES; ++i) {
-    b->ms[i] = 0;
-    b->launches[i] = 0;
+    b->ms[i] = b->ms_first[i] = 0;
+    b->launches[i] = b->launches_first[i] = 0;
   }
-  for (int q = 0; q < 8; ++q) b->work[q] = 0;
+  for (int q = 0; q < 8; ++q) b->work[q] = b->work_first[q] = 0;
   PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long), b->stream));
   b->intervals.clear();
   return PHMRF_OK;
@@ -2054,6 +2075,12 @@ int phmrf_time_base_reset(void) {
 int phmrf_block_get_work(phmrf_block_t b, int64_t* out) {
   PHMRF_CHECK(b && out, PHMRF_ERR_INVALID, "NULL argument");
   for (int q = 0; q < 8; ++q) out[q] = b->work[q];
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_work_first(phmrf_block_t b, int64_t* out) {
+  PHMRF_CHECK(b && out, PHMRF_ERR_INVALID, "NULL argument");
+  for (int q = 0; q < 8; ++q) out[q] = b->work_first[q];
   return PHMRF_OK;
 }
 

@@ -105,6 +105,7 @@ struct phmrf_block {
   // grid-native inputs of the strip kernels
   float4* fwd_w = nullptr;                  // device [n]: weights of the four forward grid edges (E, SW, S, SE)
   float* uT = nullptr;                      // device [K][n]: unary planes, uT[k][i] = -logprob[i][k]
+  float* uT_raw = nullptr;                  //   ... the allocation: uT = uT_raw + UT_PAD (slack at both ends)
   bool uT_valid = false;                    //   ... current with logprob
   bool unary_pins = false;                  // a coarse child problem: unary terms >= 1e29 pin a cell (strip_kernel looks first)
   // coarse alpha-expansions (coarse.hip): child blocks holding the two-label problem of the super-cells, side 2, 4, 8
@@ -138,12 +139,15 @@ struct phmrf_block {
   bool timing = false;
   unsigned int timing_mask = ~0u;           // which kernel classes get event pairs while timing is on (launch counts: all)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  struct Pending { int kclass; hipEvent_t a, b; };
+  struct Pending { int kclass; hipEvent_t a, b; bool first; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   hipEvent_t cur_start = nullptr;
   double ms[PHMRF_NUM_KERNEL_CLASSES] = {};
   int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {};
+  double ms_first[PHMRF_NUM_KERNEL_CLASSES] = {};           // ... of the launches in the first round of a solve
+  int64_t launches_first[PHMRF_NUM_KERNEL_CLASSES] = {};
+  int64_t work_first[8] = {};               //   ... the part of it done in the first round of each solve
   int64_t work[8] = {};                     // strips staged, their cells, staged cells, DP steps, strip launches (since reset_timing)
   struct Interval { int kclass; float t0, t1; };
   std::vector<Interval> intervals;          // resolved timed intervals on the library's common time base (ms)
@@ -206,6 +210,15 @@ struct phmrf_solve_state {
 
 namespace phmrf {
 
+// Development knobs (environment variables that switch kernels' phases off, force slow paths for A/B timing or change
+// the schedule's shortcuts) exist only in builds with -DPHMRF_DEV (libphmrf_dev.so, tools/variant.sh).  The product library
+// reads PHMRF_DETERMINISTIC (a feature, include/phmrf.h) and PHMRF_SOLVE_TRACE (prints; changes no result) and nothing else.
+#ifdef PHMRF_DEV
+#define PHMRF_DEV_ENV(name) (getenv(name))
+#else
+#define PHMRF_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+constexpr int UT_PAD = 64;            // floats of slack before and after the unary planes (strip.hip: launch_unary_planes)
 constexpr int WORK_SLOTS = 7;         // see phmrf_block_get_work
 constexpr int WORK_BANKS = 256;       // work_acc[WORK_BANKS][WORK_SLOTS]: strips staged, their cells, staged cells (with rim), DP
                                       // steps of the strip kernels, one bank per workgroup id mod 256 (no hot address)

@@ -720,7 +720,7 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   constexpr int M = 1 + S + S * (S + 1) / 2;      // features [1 | x | x_s x_t, s <= t]: x x^T is symmetric
   constexpr int Mp = ((S + 1) % 2 == 0) ? S + 2 : S + 1;      // LDS holds [1 | x] per node
   const int K = b->K, Kp = padded_k(K);
-  static const int tb_env = getenv("PHMRF_POST_TB") ? atoi(getenv("PHMRF_POST_TB")) : 0;     // development: tile rows
+  static const int tb_env = PHMRF_DEV_ENV("PHMRF_POST_TB") ? atoi(PHMRF_DEV_ENV("PHMRF_POST_TB")) : 0;     // development: tile rows
   int TB = (tb_env == 64 || tb_env == 128 || tb_env == 256) ? tb_env : 256;
   const size_t acc_bytes = (size_t)K * M * sizeof(double);            // the workgroup's f64 statistics
   // (the tile prefers 64 KB, which leaves two workgroups per CU; K and S at their limits -- K = 64, S = 8: 72 KB at 64 rows --
@@ -729,7 +729,7 @@ int launch_posterior_s(const phmrf_block* b, float beta, int estimate_type, bool
   PHMRF_CHECK((size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes <= 158 * 1024, PHMRF_ERR_UNSUPPORTED,
               "posterior_stats: K and S too large for the LDS tile");
   const size_t lds = (size_t)TB * (Kp + Mp) * sizeof(float) + acc_bytes;
-  static const int cap_env = getenv("PHMRF_POST_GRID") ? atoi(getenv("PHMRF_POST_GRID")) : 0;   // development: grid cap
+  static const int cap_env = PHMRF_DEV_ENV("PHMRF_POST_GRID") ? atoi(PHMRF_DEV_ENV("PHMRF_POST_GRID")) : 0;   // development: grid cap
   // (grid cap swept on the 12.4 M-node block: 2048 -> 925 us, 1024 -> 1069, 768 = three resident workgroups per CU -> 885, 512 -> 1111)
   // (round 3, packed features: 39 KB at K = 20, S = 4 = four resident workgroups per CU: 768 -> 790 us, 1024 -> 680, 1280 -> 810;
   //  then only [1 | x] in LDS: 29 KB, and 84 registers under __launch_bounds__(256, 5) = five per CU: 1024 -> 700, 1280 -> 650)

@@ -700,7 +700,7 @@ int ensure(T** p, size_t count) {
 static int chain_debug() {   // timing experiments only (PHMRF_CHAIN_DEBUG=1: phase 1 only, 2: no backtrack, 3: phase 1a only, 4: 1b only)
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("PHMRF_CHAIN_DEBUG");
+    const char* e = PHMRF_DEV_ENV("PHMRF_CHAIN_DEBUG");
     v = e ? atoi(e) : 0;
   }
   return v;
@@ -744,7 +744,7 @@ int launch_component_pass(phmrf_block* b, float beta) {
   PHMRF_TRY(ensure(&b->comp_move, (size_t)n));
   hipStream_t st = b->stream;
   const int g = grid1d(n);
-  static const bool cc_rows = getenv("PHMRF_CC_ROWS") != nullptr;       // development: the adjacency-row form on grid blocks
+  static const bool cc_rows = PHMRF_DEV_ENV("PHMRF_CC_ROWS") != nullptr;       // development: the adjacency-row form on grid blocks
   if (b->has_grid && b->grid_complete && b->num_neighbor == 8 && D == 8 && !cc_rows) {
     hipLaunchKernelGGL(cc_init_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels);
     hipLaunchKernelGGL(cc_union_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels);

@@ -730,538 +730,7 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// strip_multi_kernel: EVERY alpha-expansion of a strip in one wave, behind an exact filter.
-//
-// One wave owns one strip of the cut for the whole launch: it stages the strip's rectangle once, keeps what does not
-// depend on the label (weights, neighbour labels, running unaries) in registers, and then runs the expansions of all
-// listed labels back to back.  Most (strip, label) pairs never reach the DP:
-//
-//   s_i  = cost of switching cell i ALONE to alpha, everything else as it is
-//        = u_i(alpha) - u_i(l_i) + sum_j w_ij ([alpha != l_j] - [l_i != l_j])
-//   If a set C of strip cells switches, every edge inside C is cheaper than the single-site sums say by
-//   disc_ij = w_ij (2 - [l_i != l_j]).  Hence, for an OPTIMAL switching set C*:
-//     (a) no member can leave at a profit:  s_i <= sum_{j in C*, j ~ i} disc_ij      for every i in C*
-//     (b) if C* improves the energy at all: s_i <  1/2 sum_{j in C*, j ~ i} disc_ij  for some i in C*  (a "seed")
-//   Starting from U = all cells with l_i != alpha and deleting cells that violate (a) with C* replaced by U only ever
-//   removes cells outside C* (the right-hand side shrinks with U), so C* stays inside U through every sweep; when no
-//   cell of U passes (b) there is NO improving expansion of this label on this strip -- exactly, not heuristically.
-//   Otherwise the DP runs with the cells outside U pinned, on the window U spans.  (Model: oracle/mrf_moves.peel.)
-//
-// In the steady state of an EM fit ~5 sweeps settle 4 of 5 pairs without a DP, and U holds a few per cent of the cells
-// of the others.  Per label the wave reads 4 B per cell (the label's unary plane); labels and weights are read once
-// per strip instead of once per (strip, label).
-// lanes of pass p (cell t = 64 p + lane, row t mod 5) whose row has a neighbour dr rows away
-constexpr unsigned long long row_mask(int p, int dr) {
-  unsigned long long m = 0ull;
-  for (int l = 0; l < 64; ++l) {
-    const int r = (64 * p + l) % SH + dr;
-    if (r >= 0 && r < SH) m |= 1ull << l;
-  }
-  return m;
-}
 constexpr int PEEL_MAX = 16;      // sweeps before the DP takes over with whatever U is left (any U is sound; measured: 8 -> 16 sweeps = -30 % DP steps, -1.5 % E-step)
-
-#ifndef PHMRF_MULTI_WPE
-#define PHMRF_MULTI_WPE 3       // waves per SIMD the register allocation aims at (168 VGPRs at 3)
-#endif
-#ifndef PHMRF_MULTI_WPB
-#define PHMRF_MULTI_WPB 1       // waves per workgroup: the waves are independent (a wave owns a strip), so one-wave
-#endif                          // workgroups give the dispatcher the finest grain and leave no slot waiting for a sibling
-template <int ORIENT>
-__global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_multi_kernel(StripGeom g, int64_t n, int K, int D,
-                                                             const int32_t* __restrict__ nbr,
-                                                             const float4* __restrict__ fwd_w,
-                                                             const float* __restrict__ uT, uint8_t* __restrict__ labels,
-                                                             float beta, unsigned long long label_mask,
-                                                             unsigned long long* __restrict__ changed,
-                                                             uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
-                                                             int tick0, unsigned long long* __restrict__ work, int peel_max) {
-  __shared__ __attribute__((aligned(16))) float tabs[PHMRF_MULTI_WPB * SLAB];
-  // the strip's node ids, cell order (lane <-> cell t = 64 p + lane): read back from LDS wherever the label loop needs
-  // them, so that they do not sit in (spilled) registers across it
-  __shared__ int node_tab[PHMRF_MULTI_WPB][NPASS * 64];
-  // per cell { unary term of its own label, weight sum of the neighbours that share it }: read once per label.  In LDS
-  // rather than in registers: the ten registers went to scratch, and a scratch reload waits for every older load --
-  // also for the next label's unary terms, which are meant to stay in flight behind the sweeps
-  __shared__ float2 cell_tab[PHMRF_MULTI_WPB][NPASS * 64];
-  __shared__ unsigned int wk[WORK_SLOTS];   // units, -, staged cells, DP steps, cells swept (once per strip visit), label-cells
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int WPB = blockDim.x >> 6;
-  const int nstrips = g.nbands * g.nsegs;
-  float* tab = tabs + wave * SLAB;
-  if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
-  __syncthreads();
-#ifdef PHMRF_PHASE_CLOCK
-  // development build: shader-clock cycles per phase into the work counters (1 memo/ids, 2 staging, 3 single-site costs
-  // incl. the wait for the label's unary terms, 4 sweeps, 5 DP and apply; slot 0 still counts the pairs)
-  unsigned int phc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-  unsigned long long pht = __builtin_amdgcn_s_memtime();
-#define PH(K_)                                                            \
-  {                                                                       \
-    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();          \
-    phc[K_] += (unsigned int)(tn_ - pht);                                 \
-    pht = tn_;                                                            \
-  }
-#else
-#define PH(K_)
-#endif
-
-  for (int strip_v = blockIdx.x * WPB + wave; strip_v < nstrips; strip_v += gridDim.x * WPB) {
-    // (the strip is the wave's, not the lane's: as scalars the geometry below lives in SGPRs instead of VGPRs that
-    //  ended up in scratch and were reloaded sixteen times per staging)
-    const int strip = __builtin_amdgcn_readfirstlane(strip_v);
-    const int bnd = strip / g.nsegs;
-    const int seg = strip - bnd * g.nsegs;
-    const int rs0 = bnd * (SH + 1) - g.shift_r;
-    const int cs0 = seg * 64 - g.shift_c;
-    const int ca = cs0 > 0 ? cs0 : 0;
-    const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
-    const int ncols = cb > ca ? cb - ca : 0;
-    const int ncell = ncols * SH;
-    if (ncell <= 0) continue;
-    PH(1)
-
-    // ---- the strip's nodes (lane <-> cell t = 64 p + lane, column-major) and the labels that need a run: a label
-    //      is skipped while no (dilated) change stamp of the strip is newer than its last quiet run on this cut
-    int nodev[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      int t = p * 64 + lane;
-      asm volatile("" : "+v"(t));
-      nodev[p] = -1;
-      if (t < ncell) {
-        const int cc = t / SH, rr = t - cc * SH;
-        nodev[p] = strip_node(g, rs0 + rr, ca + cc);
-      }
-      node_tab[wave][p * 64 + lane] = nodev[p];
-    }
-    unsigned long long todo = label_mask;
-    uint16_t* mrow = memo ? memo + (int64_t)strip * (K + 1) : nullptr;
-    if (mrow) {
-      int nw = 0;
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p)
-        {                                   // (absent cells read node 0: the five loads go out together)
-          const int st = stamp[nodev[p] >= 0 ? nodev[p] : 0];
-          nw = (nodev[p] >= 0 && st > nw) ? st : nw;
-        }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const int o2 = __shfl_xor(nw, off, 64);
-        nw = o2 > nw ? o2 : nw;
-      }
-      const int lq = lane < K ? (int)mrow[lane] : 0;
-      todo &= __ballot(lane < K && !(lq && nw < lq));
-    }
-    todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
-           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
-    if (!todo) continue;
-
-    // label-independent cell data, in registers for the whole label loop
-    float v8[NPASS][8];            // per neighbour d: inside the strip  w (2 - [l != l_d])  (= disc), outside  w
-    unsigned int laba[NPASS], labb[NPASS];   // the eight neighbour labels, one byte each
-    unsigned int meta[NPASS];      // own label | eq mask << 8 | inside mask << 16
-    unsigned long long pres[NPASS]; // (scalar) labels present among the neighbours of the pass's cells
-    bool staged = false;
-    // the label's unary terms: loaded one label AHEAD into the same registers (they are free once the single-site
-    // costs are formed; the rare DP reads its label's terms again), so that the load's latency hides behind the sweeps
-    float u1[NPASS];
-    int alpha_cur = __ffsll((long long)todo) - 1;
-    {
-      // (node ids from LDS through an opaque index: kept in registers across the label loop -- as ids or as hoisted
-      //  64-bit addresses -- they get spilled, and every load then waits for a scratch reload and for the load before.
-      //  Absent cells load node 0; their value is never used: `ok` below tests the node bit.)
-      int nd[NPASS];
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        int ix = p * 64 + lane;
-        asm volatile("" : "+v"(ix));
-        nd[p] = node_tab[wave][ix];
-      }
-      const float* plane = uT + (int64_t)alpha_cur * n;
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        u1[p] = plane[nd[p] < 0 ? 0 : nd[p]];     // (no select on the loaded value: it would wait for the load right here)
-      }
-    }
-
-    PH(1)
-    while (todo) {
-      if (!staged) {
-        // ---- staging (as strip_kernel, step A): labels and forward weights of the strip's rectangle and rim -> LDS
-        {
-          constexpr int NEP = (ECELLS + 63) / 64;
-          int enode[NEP], eidx[NEP];
-#pragma unroll
-          for (int q = 0; q < NEP; ++q) {
-            int er, ec;
-            if (ORIENT == 0) {
-              int l2 = lane;
-              asm volatile("" : "+v"(l2));
-              er = q < EH ? q : l2;
-              ec = q < EH ? l2 : 64;
-              if (q >= EH && l2 >= EH) ec = 1 << 20;
-            } else {
-              int e = q * 64 + lane;
-              asm volatile("" : "+v"(e));
-              ec = e / EH;
-              er = e - ec * EH;
-            }
-            const bool have = ec < ncols + 2;
-            eidx[q] = have ? ec * EH + er : -1;
-            enode[q] = have ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
-          }
-          int elab[NEP];
-          float4 ef[NEP];
-#pragma unroll
-          for (int q = 0; q < NEP; ++q) {
-            const int node = enode[q];
-            elab[q] = 0;
-            ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (node >= 0) {
-              elab[q] = labels[node];
-              ef[q] = fwd_w[node];
-            }
-          }
-          __builtin_amdgcn_wave_barrier();        // (the slab may still hold the tables of the previous label's DP)
-#pragma unroll
-          for (int q = 0; q < NEP; ++q) {
-            const int e = eidx[q];
-            if (e >= 0) {
-              tab[e * REC + 0] = ef[q].x * beta;
-              tab[e * REC + 1] = ef[q].y * beta;
-              tab[e * REC + 2] = ef[q].z * beta;
-              tab[e * REC + 3] = ef[q].w * beta;
-              tab[e * REC + 4] = __builtin_bit_cast(float, (int)(enode[q] >= 0 ? elab[q] : 0));
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-#ifndef PHMRF_PHASE_CLOCK
-          atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
-          atomicAdd(&wk[4], (unsigned int)ncell);               // the strip's cells, swept for every listed label
-#endif
-        }
-        // ---- extraction: lane <-> strip cell.  The unary terms of the cells' own labels first, all five loads in flight
-        //      while the neighbourhoods are put together (absent cells read node 0 of label 0 and drop it)
-        float ucl[NPASS];
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-          int t = p * 64 + lane;
-          asm volatile("" : "+v"(t));
-          const int cc = t / SH, rr = t - cc * SH;
-          const int e0 = (cc + 1) * EH + (rr + 1);
-          const int nd = node_tab[wave][t];           // (from LDS: kept in registers across the label loop they spill)
-          const bool have = nd >= 0;
-          const int l = have ? __builtin_bit_cast(int, tab[have ? e0 * REC + 4 : 4]) & 255 : 0;
-          ucl[p] = uT[(int64_t)l * n + (have ? nd : 0)];
-        }
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-          int t = p * 64 + lane;
-          asm volatile("" : "+v"(t));
-          unsigned int la = 0u, lb = 0u, mt = 0u;
-          unsigned long long pm = 0ull;
-          float hs = 0.f, uc = 0.f;
-#pragma unroll
-          for (int d = 0; d < 8; ++d) v8[p][d] = 0.f;
-          if (node_tab[wave][t] >= 0) {
-            const int cc = t / SH, rr = t - cc * SH;
-            const int e0 = (cc + 1) * EH + (rr + 1);
-            const int l = __builtin_bit_cast(int, tab[e0 * REC + 4]) & 255;
-            mt = (unsigned int)l | (1u << 24);            // bit 24: the cell is a node
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-              constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-              constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-              const int dr = DR[d], dc = DC[d];
-              const int di = ORIENT ? dc : dr, dj = ORIENT ? dr : dc;
-              const bool fwd = di > 0 || (di == 0 && dj > 0);
-              const int comp = (di == 0) ? 0 : (fwd ? dj + 2 : 2 - dj);
-              const int en = e0 + dc * EH + dr;
-              const float w = fwd ? tab[e0 * REC + comp] : tab[en * REC + comp];
-              const int lj = __builtin_bit_cast(int, tab[en * REC + 4]) & 255;
-              const int r2 = rr + dr, c2 = cc + dc;
-              const bool inside = r2 >= 0 && r2 < SH && c2 >= 0 && c2 < ncols;
-              const bool eq = lj == l;
-              hs += eq ? w : 0.f;
-              v8[p][d] = (inside && eq) ? w + w : w;
-              mt |= (eq ? 1u : 0u) << (8 + d);
-              mt |= (inside ? 1u : 0u) << (16 + d);
-              pm |= 1ull << (lj & 63);
-              if (d < 4) la |= (unsigned int)lj << (8 * d);
-              else lb |= (unsigned int)lj << (8 * (d - 4));
-            }
-            uc = ucl[p];
-          }
-          laba[p] = la; labb[p] = lb; meta[p] = mt;
-          cell_tab[wave][t] = make_float2(uc, hs);
-          {
-            unsigned int p0 = (unsigned int)pm, p1 = (unsigned int)(pm >> 32);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-              p0 |= (unsigned int)__shfl_xor((int)p0, off, 64);
-              p1 |= (unsigned int)__shfl_xor((int)p1, off, 64);
-            }
-            pres[p] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)p1) << 32) |
-                      (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)p0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_wave_barrier();          // the slab is free for the cost tables from here on
-        staged = true;
-        PH(2)
-      }
-
-      const int alpha = alpha_cur;
-      todo &= todo - 1ull;
-      if (lane == 0) {
-        atomicAdd(&wk[0], 1u);
-#ifndef PHMRF_PHASE_CLOCK
-        atomicAdd(&wk[5], (unsigned int)ncell);                 // one label's unary terms for the strip's cells
-#endif
-      }
-
-      // ---- single-site costs and the starting set
-      float sc[NPASS];
-      unsigned long long U[NPASS];
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        float hist = 0.f;
-        if ((pres[p] >> alpha) & 1ull) {             // (wave-uniform: many labels are absent from a pass's neighbourhoods)
-#pragma unroll
-          for (int d = 0; d < 8; ++d) {
-            const int lj = (int)(((d < 4 ? laba[p] : labb[p]) >> (8 * (d & 3))) & 255u);
-            hist += lj == alpha ? v8[p][d] : 0.f;    // (a neighbour labelled alpha differs from l_i: v8 holds plain w)
-          }
-        }
-        const int l = (int)(meta[p] & 255u);
-        const bool ok = ((meta[p] >> 24) & 1u) && l != alpha && u1[p] < 1.0e29f;
-        int ix = p * 64 + lane;
-        asm volatile("" : "+v"(ix));
-        const float2 uh = cell_tab[wave][ix];
-        sc[p] = u1[p] - uh.x + uh.y - hist;
-        U[p] = __ballot(ok);
-      }
-      PH(3)
-      if (todo) {                                   // the next label's terms, in flight during the sweeps
-        alpha_cur = __ffsll((long long)todo) - 1;
-    {
-      // (node ids from LDS through an opaque index: kept in registers across the label loop -- as ids or as hoisted
-      //  64-bit addresses -- they get spilled, and every load then waits for a scratch reload and for the load before.
-      //  Absent cells load node 0; their value is never used: `ok` below tests the node bit.)
-      int nd[NPASS];
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        int ix = p * 64 + lane;
-        asm volatile("" : "+v"(ix));
-        nd[p] = node_tab[wave][ix];
-      }
-      const float* plane = uT + (int64_t)alpha_cur * n;
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        u1[p] = plane[nd[p] < 0 ? 0 : nd[p]];     // (no select on the loaded value: it would wait for the load right here)
-      }
-    }
-      }
-
-      PH(1)
-      // ---- the filter: delete cells that could leave any switching set at a profit; stop when no seed is left
-      bool quiet = false;
-      for (int it = 0; it < peel_max; ++it) {
-        unsigned long long seeds = 0ull;
-        bool shrunk = false;
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-          if (U[p] == 0ull) continue;
-          // bit `lane` of M_d: is neighbour d of cell 64 p + lane in U?  Column-major cells: the neighbour sits dc * 5 + dr
-          // cells away, so M_d is a funnel shift of the (scalar) U words, cut to the lanes whose row has that neighbour
-          // (a compile-time pattern: the row of cell t is t mod 5).  All of it is SALU work; the VALU only adds the
-          // weight under the mask.
-          const unsigned long long up = U[p];
-          const unsigned long long lo = p > 0 ? U[p > 0 ? p - 1 : 0] : 0ull;
-          const unsigned long long hi = p < NPASS - 1 ? U[p < NPASS - 1 ? p + 1 : 0] : 0ull;
-          float cap = 0.f;
-#pragma unroll
-          for (int d = 0; d < 8; ++d) {
-            constexpr int DR[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-            constexpr int DC[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-            const int off = DC[d] * SH + DR[d];
-            unsigned long long M = off > 0 ? (up >> (off > 0 ? off : 1)) | (hi << (off > 0 ? 64 - off : 1))
-                                           : (up << (off < 0 ? -off : 1)) | (lo >> (off < 0 ? 64 + off : 1));
-            M &= row_mask(p, DR[d]);
-            cap += __builtin_amdgcn_inverse_ballot_w64(M) ? v8[p][d] : 0.f;
-          }
-          const float capx = cap * 1.0001f + 1e-6f;                      // a hair of slack for the f32 sums
-          const unsigned long long keep = __ballot(sc[p] <= capx);
-          const unsigned long long sd = __ballot(sc[p] < 0.5f * capx);
-          const unsigned long long nu = U[p] & keep;
-          seeds |= nu & sd;
-          shrunk = shrunk || nu != U[p];
-          U[p] = nu;
-        }
-        if (!seeds) {
-          quiet = true;
-          break;
-        }
-        if (!shrunk) break;
-      }
-      PH(4)
-      const int tick_a = tick0 + alpha;
-      if (quiet) {
-        if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
-        continue;
-      }
-
-      // ---- cell records of the DP (lane <-> cell), cells outside U pinned
-      float rc0[NPASS], rc1[NPASS], rwu[NPASS], rwlu[NPASS], rwl[NPASS], rwld[NPASS];
-      int rbits[NPASS];
-      int t_lo = NCELL_MAX, t_hi = -1;
-      // (the label's unary terms again -- u1 already holds the NEXT label's: five loads in flight together)
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        int ix = p * 64 + lane;
-        asm volatile("" : "+v"(ix));
-        const int nd = node_tab[wave][ix];
-        rc1[p] = (uT + (int64_t)alpha * n)[nd < 0 ? 0 : nd];
-      }
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        float c0 = 0.f, c1 = BIG, w4[4] = {0.f, 0.f, 0.f, 0.f};
-        int bits = 0;
-        if ((meta[p] >> 24) & 1u) {
-          const int l = (int)(meta[p] & 255u);
-          const bool in_u = (U[p] >> lane) & 1ull;
-          float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-          for (int d = 0; d < 8; ++d) {
-            constexpr int QOF[8] = {1, 0, -1, 2, -1, 3, -1, -1};
-            const int lj = (int)(((d < 4 ? laba[p] : labb[p]) >> (8 * (d & 3))) & 255u);
-            const bool eq = (meta[p] >> (8 + d)) & 1u;
-            const bool inside = (meta[p] >> (16 + d)) & 1u;
-            if (!inside) {
-              a0 += eq ? 0.f : v8[p][d];
-              a1 += lj != alpha ? v8[p][d] : 0.f;
-            } else if (QOF[d] >= 0) {
-              w4[QOF[d] >= 0 ? QOF[d] : 0] = eq ? 0.5f * v8[p][d] : v8[p][d];
-              const int nib = (eq ? 0 : 1) | (l != alpha ? 2 : 0) | (lj != alpha ? 4 : 0);
-              bits |= nib << (4 * (QOF[d] >= 0 ? QOF[d] : 0));
-            }
-          }
-          c0 = cell_tab[wave][p * 64 + lane].x + a0;
-          c1 = in_u ? rc1[p] + a1 : BIG;
-        }
-        rc0[p] = c0; rc1[p] = c1; rwu[p] = w4[0]; rwlu[p] = w4[1]; rwl[p] = w4[2]; rwld[p] = w4[3];
-        rbits[p] = bits;
-        if (U[p]) {
-          const int first = p * 64 + __ffsll((long long)U[p]) - 1;
-          const int last = p * 64 + 63 - __clzll((long long)U[p]);
-          t_lo = first < t_lo ? first : t_lo;
-          t_hi = last > t_hi ? last : t_hi;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (t_hi < 0) {
-        if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
-        PH(5)
-        continue;
-      }
-      t_lo = __builtin_amdgcn_readfirstlane(t_lo);
-      int t_end = __builtin_amdgcn_readfirstlane(t_hi) + SH + 1;
-      {
-        const int pe = t_end >> 6, re = t_end & 63;
-        int r6 = re - re % 6 + 5;
-        if (r6 > 63) r6 = 63;
-        t_end = pe * 64 + r6;
-        if (t_end > NPASS * 64 - 1) t_end = NPASS * 64 - 1;
-        const int pl = t_lo >> 6, rl = t_lo & 63;
-        t_lo = pl * 64 + (rl - rl % 6);
-      }
-#ifndef PHMRF_PHASE_CLOCK
-      if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
-#endif
-
-      float m = lane == 0 ? 0.f : BIG;
-      unsigned long long took = 0ull;
-      unsigned int dlo[NPASS], dhi[NPASS];
-      dp_pass<0, false>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
-      dp_pass<1, false>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
-      dp_pass<2, false>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
-      dp_pass<3, false>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
-      dp_pass<4, false>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
-      const int q_end = t_end % 6;
-      int sidx = 0;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) sidx |= ((state_of_lane(lane) >> ((q_end - j + 6) % 6)) & 1) << j;
-      const float mmin = wave_min_f32(m);
-      if (!(took & 1ull) && PHMRF_RL(m, 0) == mmin) {
-        if (mrow && lane == 0) mrow[alpha] = (uint16_t)tick_a;
-        PH(5)
-        continue;
-      }
-      m = lane == 0 ? 0.f : BIG;
-      dp_pass<0, true>(m, took, lane, tab, rc0[0], rc1[0], rwu[0], rwlu[0], rwl[0], rwld[0], rbits[0], t_lo, t_end, dlo[0], dhi[0]);
-      dp_pass<1, true>(m, took, lane, tab, rc0[1], rc1[1], rwu[1], rwlu[1], rwl[1], rwld[1], rbits[1], t_lo, t_end, dlo[1], dhi[1]);
-      dp_pass<2, true>(m, took, lane, tab, rc0[2], rc1[2], rwu[2], rwlu[2], rwl[2], rwld[2], rbits[2], t_lo, t_end, dlo[2], dhi[2]);
-      dp_pass<3, true>(m, took, lane, tab, rc0[3], rc1[3], rwu[3], rwlu[3], rwl[3], rwld[3], rbits[3], t_lo, t_end, dlo[3], dhi[3]);
-      dp_pass<4, true>(m, took, lane, tab, rc0[4], rc1[4], rwu[4], rwlu[4], rwl[4], rwld[4], rbits[4], t_lo, t_end, dlo[4], dhi[4]);
-      const float mmin2 = wave_min_f32(m);   // the recorded walk starts at the window's first group, the common walk at
-    //  the pass start: their values differ by the keep-costs of the cells in between -> the recorded walk's own minimum
-    const float cand = (m == mmin2) ? (float)sidx : 127.f;
-      const float best = wave_min_f32(cand);
-      int s = state_of_lane(__ffsll((long long)__ballot(cand == best)) - 1);
-      unsigned int xsel[NPASS];
-      s = __builtin_amdgcn_readfirstlane(s);
-      backtrack_pass<4>(s, t_lo, t_end, dlo[4], dhi[4], xsel[4]);
-      backtrack_pass<3>(s, t_lo, t_end, dlo[3], dhi[3], xsel[3]);
-      backtrack_pass<2>(s, t_lo, t_end, dlo[2], dhi[2], xsel[2]);
-      backtrack_pass<1>(s, t_lo, t_end, dlo[1], dhi[1], xsel[1]);
-      backtrack_pass<0>(s, t_lo, t_end, dlo[0], dhi[0], xsel[0]);
-
-      __builtin_amdgcn_wave_barrier();
-      unsigned int my_changed = 0;
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int node = node_tab[wave][p * 64 + lane];
-        if (xsel[p] && node >= 0) {
-          labels[node] = (uint8_t)alpha;
-          if (stamp) {
-            stamp[node] = (uint16_t)tick_a;
-            const int32_t* nb2 = nbr + (int64_t)node * D;
-            for (int j = 0; j < D; ++j)
-              if (nb2[j] >= 0) stamp[nb2[j]] = (uint16_t)tick_a;
-          }
-          ++my_changed;
-        }
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) my_changed += __shfl_xor(my_changed, off, 64);
-      if (lane == 0) {
-        if (my_changed) atomicAdd(changed + alpha, (unsigned long long)my_changed);
-        if (mrow) mrow[alpha] = my_changed ? (uint16_t)0 : (uint16_t)tick_a;
-      }
-      if (my_changed) {
-        __threadfence();          // the restaging below reads the labels this wave has just written
-        staged = false;
-      }
-      PH(5)
-    }
-  }
-#ifdef PHMRF_PHASE_CLOCK
-  if (lane == 0)
-    for (int k = 1; k < 6; ++k) wk[k] = phc[k] >> 4;
-#endif
-#undef PH
-  __syncthreads();
-  if (work && threadIdx.x < WORK_SLOTS) {
-    const unsigned int v = wk[threadIdx.x];
-    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + threadIdx.x, (unsigned long long)v);
-  }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // strip_cols_kernel (round 3): the same launch -- every alpha-expansion of a strip in one wave, behind the exact
@@ -1270,14 +739,14 @@ __global__ __launch_bounds__(64 * PHMRF_MULTI_WPB, PHMRF_MULTI_WPE) void strip_m
 // Filter (lane c owns the five cells of strip column c): the set U is five 64-bit scalars, one per strip row, bit c =
 // column c.  "Is my neighbour (r + dr, c + dc) in U" is bit c of U[r + dr] shifted by dc: ten scalar shifts per sweep
 // instead of a funnel shift, an AND with a row pattern and a pass-boundary fix-up per (pass, direction) -- a sweep is
-// ~110 instructions where the cell-order layout of strip_multi_kernel needs ~300.  Sweeps are Jacobi (five independent
+// ~110 instructions where the cell-order layout of round 2's strip_multi_kernel (deleted in round 5) needed ~300.  Sweeps are Jacobi (five independent
 // chains per wave).  A label that occurs nowhere in the strip's rectangle (most labels: a 64-bit presence mask formed at
 // staging) needs no neighbour-label compare at all, and its first sweep is the compare of the single-site cost with a
 // label-independent cap.  The label's unary terms are 5 row loads per wave, contiguous in orientation 0.
 // Flagged (label, U) pairs wait in a small LDS buffer; then the wave turns to the DP in cell order (lane <-> cell
 // t = 64 p + lane as before): records straight from the slab (which the filter never overwrites), only for the passes
 // the window touches, tables built and walked in chunks of 18 cells (2.6 KB instead of a 9.2 KB slab per pass).
-// The order of events is that of strip_multi_kernel: labels ascending, and after a move on the strip everything later
+// The order of events: labels ascending, and after a move on the strip everything later
 // is filtered again on the new labels -- so the launch still equals the single-label passes of the move model.
 // the staged rectangle of strip_cols_kernel: the four forward weights of the cells of rows -1 .. 4 plus the one weight of the
 // bottom rim row that the strip needs (orientation 1: the edge to strip row 4 of the next column): 24 + 1 words per column
@@ -1804,16 +1273,61 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
              (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)p0);
     }
     
+    // ---- where a label's unary terms of my column live: ONE wave-uniform base per label and per-lane 32-bit byte offsets
+    //      (a load is  global_load_dword v, v_off, s[base] offset:imm:  no 64-bit address per lane and row).  node(i, j) =
+    //      rowbase(i) + j with rowbase(i) = i W - i (i - 1) / 2 - i in an upper-triangular block, i W otherwise.
+    //      Orientation 0: strip row r is grid row rs0 + r, lane c is grid column ca + c: one offset register per row.
+    //      Orientation 1: strip row r is grid COLUMN rs0 + r, lane c is grid row ca + c: the five cells of a lane are
+    //      consecutive floats -- one offset register and the instruction's immediate offset.
+    //      Cells that do not exist read a neighbouring element (rows and lanes clamped into the block; a column index up to
+    //      five beyond either end of its row, for which the planes carry UT_PAD floats of slack at both ends); what they load
+    //      is never used.
+    unsigned long long plane0 = reinterpret_cast<unsigned long long>(uT_), pstride = (unsigned long long)n * 4ull;
+    unsigned int voffr[ORIENT == 0 ? SH : 1];
+    {
+      int lc = lane;
+      asm volatile("" : "+v"(lc));
+      lc = lc < ncols ? lc : ncols - 1;
+      if (ORIENT == 0) {
+        int i0 = rs0 < 0 ? 0 : (rs0 > g.H - 1 ? g.H - 1 : rs0);
+        const int rb0 = (g.diagonal ? i0 * g.W - (i0 * (i0 - 1)) / 2 - i0 : i0 * g.W) + ca;
+        plane0 += (unsigned long long)(long long)rb0 << 2;
+#pragma unroll
+        for (int r = 0; r < SH; ++r) {
+          int i = rs0 + r;
+          i = i < 0 ? 0 : (i > g.H - 1 ? g.H - 1 : i);
+          const int rb = (g.diagonal ? i * g.W - (i * (i - 1)) / 2 - i : i * g.W) + ca;
+          voffr[ORIENT == 0 ? r : 0] = (unsigned int)(rb - rb0 + lc) * 4u;
+        }
+      } else {
+        const int i = ca + lc;
+        const int rb = g.diagonal ? i * g.W - (i * (i - 1)) / 2 - i : i * g.W;
+        const int rb0 = g.diagonal ? ca * g.W - (ca * (ca - 1)) / 2 - ca : ca * g.W;
+        voffr[0] = (unsigned int)(rb - rb0) * 4u;
+        plane0 += (unsigned long long)(long long)(rb0 + rs0) << 2;
+      }
+    }
+    // (base and stride as values of their own: left as kernel arguments, the register allocator re-reads them from the
+    //  kernel-argument segment inside the label loop -- an s_load and its wait per label)
+    asm volatile("" : "+s"(plane0), "+s"(pstride));
+#define PHMRF_LOAD_U1(ALPHA_)                                                                                          \
+  {                                                                                                                    \
+    unsigned long long pb_ = plane0 + (unsigned long long)(ALPHA_) * pstride;                                          \
+    asm volatile("" : "+s"(pb_));                                                                                      \
+    _Pragma("unroll") for (int r = 0; r < SH; ++r) {                                                                   \
+      /* (opaque, so that the zero extension of the lane offset is not hoisted out of the block that loads: base in     \
+          SGPRs + zext(32-bit VGPR) + constant is what selects the saddr form) */                                       \
+      unsigned int vo_ = voffr[ORIENT == 0 ? r : 0];                                                                   \
+      asm volatile("" : "+v"(vo_));                                                                                    \
+      u1[r] = *reinterpret_cast<const global_ptr<const float>>(pb_ + (unsigned long long)vo_ + (ORIENT == 0 ? 0 : 4 * r)); \
+    }                                                                                                                  \
+  }
     FPH(0)
     // ---- the filter over the labels still to do; flagged ones wait in ubuf
         int nbuf = 0;
     float u1[SH];
     int alpha_cur = __ffsll((long long)todo) - 1;
-    {
-      const global_ptr<const float> plane = uT + (int64_t)alpha_cur * n;
-#pragma unroll
-      for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
-    }
+    PHMRF_LOAD_U1(alpha_cur)
     // (quiet labels and the pair count are kept on the scalar side and written once at the end: a global store per
     //  label put a store round trip into every label's s_waitcnt vmcnt(0), next to the prefetched unary terms)
     unsigned long long quiet_mask = 0ull;
@@ -1844,9 +1358,7 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
         FPH(1)
       if (todo) {                                  // the next label's terms, in flight during the sweeps
         alpha_cur = __ffsll((long long)todo) - 1;
-        const global_ptr<const float> plane = uT + (int64_t)alpha_cur * n;
-#pragma unroll
-        for (int r = 0; r < SH; ++r) u1[r] = plane[ndx[r]];
+        PHMRF_LOAD_U1(alpha_cur)
       }
       // ---- the filter (peel_strip): the caps start from the label-independent sum over ALL in-strip neighbours, minus --
       //      for a label that occurs in the rectangle -- the cells that carry it
@@ -1882,6 +1394,7 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
     }
 #endif
 #undef FPH
+#undef PHMRF_LOAD_U1
     if (mrow && ((quiet_mask >> lane) & 1ull)) mrow[lane] = (uint16_t)(tick0 + lane);      // lane <-> label
     if (lane == 0) {
       *nbuf_out = nbuf;
@@ -1943,6 +1456,10 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
     const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
     if (ncell <= 0) continue;
+    // A strip of the grid's bounding rectangle that holds no node: in an upper-triangular block every strip below the
+    // diagonal -- half of them.  (Until round 5 such a strip went through staging, extraction and the filter of every
+    // label with empty masks: a third of a real strip's instructions for nothing.)
+    if (g.diagonal && (ORIENT == 0 ? (rs0 > 0 ? rs0 : 0) > cb - 1 : ca > (rs0 + SH - 1 < g.Hs - 1 ? rs0 + SH - 1 : g.Hs - 1))) continue;
     PH(1)
 
     // ---- column layout: lane c <-> strip column c; the node of row r is nodec[r] (-1: none)
@@ -1973,7 +1490,7 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
     }
     todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
            (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
-    if (!todo) continue;
+    if (!todo || !(valid[0] | valid[1] | valid[2] | valid[3] | valid[4])) continue;
     bool staged = false;
 
     while (todo) {
@@ -2142,6 +1659,7 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
     const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
     if (ncell <= 0) continue;
+    if (g.diagonal && (ORIENT == 0 ? (rs0 > 0 ? rs0 : 0) > cb - 1 : ca > (rs0 + SH - 1 < g.Hs - 1 ? rs0 + SH - 1 : g.Hs - 1))) continue;   // no node (see strip_cols_kernel)
 
     // ---- column layout, memo test (slot K of the strip's memo row: the fusion pass)
     unsigned long long valid[SH];
@@ -2168,6 +1686,7 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
     }
 #pragma unroll
     for (int r = 0; r < SH; ++r) valid[r] = __ballot(ndx[r] >= 0);
+    if (!(valid[0] | valid[1] | valid[2] | valid[3] | valid[4])) continue;
 
     // ---- staging: labels, proposals and forward weights of the strip's rectangle and rim -> LDS
     {
@@ -2478,10 +1997,13 @@ int launch_propose(phmrf_block* b, float beta) {
   return PHMRF_OK;
 }
 
+// Development knobs (read from the environment) exist only in builds with -DPHMRF_DEV (tools/variant.sh): the product
+// library has none that can change or break a labelling.
+#ifdef PHMRF_DEV
 static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: phase 1 only, 2: no backtrack/apply, +4: count strips)
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("PHMRF_STRIP_DEBUG");
+    const char* e = PHMRF_DEV_ENV("PHMRF_STRIP_DEBUG");
     v = e ? atoi(e) : 0;
   }
   return v;
@@ -2490,21 +2012,16 @@ static int strip_debug() {   // timing experiments only (PHMRF_STRIP_DEBUG=1: ph
 static int peel_sweeps() {   // PHMRF_PEEL_SWEEPS=0 switches the filter off (timing experiments: every pair goes to the DP)
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("PHMRF_PEEL_SWEEPS");
+    const char* e = PHMRF_DEV_ENV("PHMRF_PEEL_SWEEPS");
     v = e ? atoi(e) : PEEL_MAX;
     if (v < 0 || v > 64) v = PEEL_MAX;
   }
   return v;
 }
-
-static int multi_version() {   // PHMRF_MULTI_V=1: strip_multi_kernel (round 2) instead of strip_cols_kernel
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PHMRF_MULTI_V");
-    v = e ? atoi(e) : 2;
-  }
-  return v;
-}
+#else
+static constexpr int strip_debug() { return 0; }
+static constexpr int peel_sweeps() { return PEEL_MAX; }
+#endif
 
 static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int shift_c) {
   StripGeom g;
@@ -2523,7 +2040,11 @@ static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int sh
 
 int launch_unary_planes(phmrf_block* b) {
   if (b->uT_valid) return PHMRF_OK;
-  if (!b->uT) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->uT), (size_t)b->n * b->K * sizeof(float)));
+  if (!b->uT) {      // (UT_PAD floats of slack at both ends: strip_cols_kernel's row loads may run up to five columns past a row)
+    PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->uT_raw), ((size_t)b->n * b->K + 2 * UT_PAD) * sizeof(float)));
+    PHMRF_HIP(hipMemsetAsync(b->uT_raw, 0, ((size_t)b->n * b->K + 2 * UT_PAD) * sizeof(float), b->stream));
+    b->uT = b->uT_raw + UT_PAD;
+  }
   const int K = b->K, TB = 256, Kp = padded_k(K);
   const size_t lds = (size_t)TB * Kp * sizeof(float);
   int64_t g64 = (b->n + TB - 1) / TB;
@@ -2546,9 +2067,8 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   if (grid > (1 << 22)) grid = 1 << 22;          // one workgroup per strip (see launch_strip_multi)
   const bool use_memo = b->tick && geom >= 0 && b->memo && (int64_t)nstrips <= b->memo_strips;
   // the fusion pass of a solve (proposals in labels_tmp) runs behind the exact filter (fusion_cols_kernel); the
-  // single-label passes of the API and the coarse child problems keep strip_kernel.  PHMRF_FUSION_V=1: strip_kernel always.
-  static const int fusion_v = getenv("PHMRF_FUSION_V") ? atoi(getenv("PHMRF_FUSION_V")) : 2;
-  if (alpha < 0 && fusion_v != 1) {
+  // single-label passes of the API and the coarse child problems keep strip_kernel.
+  if (alpha < 0) {
 #define PHMRF_LAUNCH_FUSION(O_)                                                                                       \
   hipLaunchKernelGGL((fusion_cols_kernel<O_>), dim3(grid), dim3(64), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,  \
                      b->uT, b->labels, b->labels_tmp, b->sgain, beta, b->counters + b->counter_slot,                   \
@@ -2561,8 +2081,12 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
     PHMRF_HIP(hipGetLastError());
     return PHMRF_OK;
   }
-  static const bool no_pin_look = getenv("PHMRF_NO_PIN_LOOK") != nullptr;      // development: A/B timing
-  static const bool child_count = getenv("PHMRF_CHILD_COUNT") != nullptr;     // development: strips seen / staged / into the DP
+#ifdef PHMRF_DEV
+  static const bool no_pin_look = PHMRF_DEV_ENV("PHMRF_NO_PIN_LOOK") != nullptr;      // development: A/B timing
+  static const bool child_count = PHMRF_DEV_ENV("PHMRF_CHILD_COUNT") != nullptr;     // development: strips seen / staged / into the DP
+#else
+  constexpr bool no_pin_look = false, child_count = false;
+#endif
   const int pin_look = b->unary_pins ? ((no_pin_look ? 0 : 32) | (child_count ? 4 : 0)) : 0;   // (coarse child problems)
 #define PHMRF_LAUNCH_STRIP(O_)                                                                                        \
   hipLaunchKernelGGL((strip_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, b->uT, \
@@ -2579,7 +2103,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
 }
 
 // every alpha-expansion of the labels in `label_mask` on the cut (orient, shift_r, shift_c), one wave per strip
-// (strip_multi_kernel).  geom >= 0: the memo of quiet runs of that fixed cut applies (inside a solve).  The launch uses
+// (strip_cols_kernel).  geom >= 0: the memo of quiet runs of that fixed cut applies (inside a solve).  The launch uses
 // the ticks b->tick .. b->tick + K - 1 (one per label, so that a label's quiet run after another label's move on the
 // same strip stays valid); the caller advances b->tick by K.
 int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, unsigned long long label_mask,
@@ -2588,24 +2112,19 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
   const int nstrips = g.nbands * g.nsegs;
   if (nstrips <= 0 || !label_mask) return PHMRF_OK;
   if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
-  const int WPB = PHMRF_MULTI_WPB, TB = 64 * WPB;
-  int grid = (nstrips + WPB - 1) / WPB;
+  const int TB = 64;
+  int grid = nstrips;
   // one workgroup per strip up to 4 M strips: the dispatcher hands a free slot the next strip, which balances the
   // uneven strips better than waves striding over them (measured against a cap of 8 resident sets: -3 % on the rows cut)
   if (grid > (1 << 22)) grid = 1 << 22;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
-#define PHMRF_LAUNCH_MULTI(KERN_, O_)                                                                                 \
-  hipLaunchKernelGGL((KERN_<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,           \
+#define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
+  hipLaunchKernelGGL((strip_cols_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
                      b->uT, b->labels, beta, label_mask, b->counters + 8, b->tick ? b->stamp : nullptr,               \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
                      b->tick, b->work_acc, peel_sweeps())
-  if (multi_version() == 1) {          // development: the round-2 kernel (cell-order filter), for A/B timing
-    if (orient) PHMRF_LAUNCH_MULTI(strip_multi_kernel, 1);
-    else PHMRF_LAUNCH_MULTI(strip_multi_kernel, 0);
-  } else {
-    if (orient) PHMRF_LAUNCH_MULTI(strip_cols_kernel, 1);
-    else PHMRF_LAUNCH_MULTI(strip_cols_kernel, 0);
-  }
+  if (orient) PHMRF_LAUNCH_MULTI(1);
+  else PHMRF_LAUNCH_MULTI(0);
 #undef PHMRF_LAUNCH_MULTI
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;

@@ -33,7 +33,8 @@ class phyloHMRF(_BaseGraph):
                  random_state=None, n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
                  learning_rate=0.001, num_neighbor=8, block_factory=None, reducer=None, world=None, rank=None,
                  solver_opts=None, mstep_workers=None, quiet=False, device_graph=False, block_threads=14,
-                 init_method="minibatch", split_above=1.0, tile_parts=None, warm_start="best"):
+                 init_method="minibatch", split_above=1.0, tile_parts=None, warm_start="best", checkpoint_path=None,
+                 checkpoint_every=1, checkpoint_labels=True, resume_from=None):
         _BaseGraph.__init__(self, n_components=n_components, run_id=run_id, estimate_type=estimate_type,
                             startprob_prior=startprob_prior, transmat_prior=transmat_prior, algorithm=algorithm,
                             random_state=random_state, n_iter=n_iter, tol=tol, params=params, verbose=verbose,
@@ -48,6 +49,8 @@ class phyloHMRF(_BaseGraph):
             # the emission kernel alone goes to S = 16 (phmrf_emission_dev)
             raise ValueError("phyloHMRF on the GPU supports at most 8 species (n_features = %d)" % n_features)
         self.quiet = quiet
+        self.checkpoint_path, self.checkpoint_every = checkpoint_path, checkpoint_every
+        self.checkpoint_labels, self.resume_from = checkpoint_labels, resume_from
         self.covariance_type = covariance_type
         self.min_covar = min_covar
         self.max_iter = max_iter
@@ -328,6 +331,13 @@ class phyloHMRF(_BaseGraph):
         for b, _, _, stored in self._local_units():          # (a tile takes its halo rows too)
             b.set_labels(np.asarray(labels[stored]))
             b.save_labels(SLOT_LOCAL)
+
+    def _upload_labels_slot(self, labels, slot):
+        """a labelling of all samples -> the blocks' snapshot `slot` (None: their current labels); a tile takes its halo rows"""
+        for b, _, _, stored in self._local_units():
+            b.set_labels(np.asarray(labels[stored]))
+            if slot is not None:
+                b.save_labels(slot)
 
     def _snapshot_labels(self, slot):
         for b, _, _, _ in self._local_units():

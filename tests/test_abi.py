@@ -50,6 +50,35 @@ def test_product_path_fails_loudly_without_a_gpu():
         Block(10, 4, 5)
 
 
+DEV_KNOBS = ("PHMRF_PEEL_SWEEPS", "PHMRF_STRIP_DEBUG", "PHMRF_CHAIN_DEBUG", "PHMRF_COARSE_NO_GATE", "PHMRF_COARSE_NO_STAMP_GATE",
+             "PHMRF_COARSE_BATCH", "PHMRF_NO_PIN_LOOK", "PHMRF_ENERGY_FULL", "PHMRF_ENERGY_CHECK", "PHMRF_CC_ROWS", "PHMRF_POST_TB",
+             "PHMRF_POST_GRID", "PHMRF_CHILD_COUNT", "PHMRF_MULTI_V", "PHMRF_FUSION_V")
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libphmrf.so not built")
+def test_product_library_has_no_development_knobs():
+    """The product library cannot be talked into another labelling through the environment: the names of the development
+    knobs (timing experiments that cut kernels short, slow paths for A/B runs, the deleted round-2 kernels' switches) do not
+    occur in its binary at all -- the getenv calls are compiled only with -DPHMRF_DEV (common.h, PHMRF_DEV_ENV), into
+    libphmrf_dev.so, which the tests that A/B a shortcut load through PHMRF_LIB.  What the product does read:
+    PHMRF_DETERMINISTIC (a feature of the boundary, include/phmrf.h) and PHMRF_SOLVE_TRACE (prints, changes no result)."""
+    blob = open(LIB, "rb").read()
+    present = [k for k in DEV_KNOBS if k.encode() in blob]
+    assert not present, present
+    assert b"PHMRF_DETERMINISTIC" in blob and b"PHMRF_SOLVE_TRACE" in blob
+    dev = os.path.join(ROOT, "phylo_hmrf_amd", "libphmrf_dev.so")
+    if os.path.exists(dev):
+        dblob = open(dev, "rb").read()
+        for k in ("PHMRF_PEEL_SWEEPS", "PHMRF_COARSE_BATCH", "PHMRF_NO_PIN_LOOK", "PHMRF_COARSE_NO_STAMP_GATE"):
+            assert k.encode() in dblob, k
+        L = ctypes.CDLL(dev)
+        missing = [s for s in declared_symbols() if not hasattr(L, s)]
+        assert not missing, missing
+    src = os.path.join(ROOT, "phylo_hmrf_amd", "csrc")
+    n_getenv = sum(open(os.path.join(src, f)).read().count("getenv(") for f in os.listdir(src) if f.endswith(".hip"))
+    assert n_getenv <= 4, n_getenv
+
+
 def test_emission_pack_is_host_only_and_matches_oracle():
     """phmrf_emission_pack is pure host code (Cholesky, inverse factor, log-det): check it without a GPU."""
     if not os.path.exists(LIB):

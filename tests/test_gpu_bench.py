@@ -32,13 +32,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # the dominant kernel's time per step is measured on one time line: it cannot exceed the step
-    assert 0 < r["busy_ms_per_step"] <= d["ms_per_step"]
+    # frac is the KERNEL's fraction: bytes over the launches' own durations, full sweeps and mop-up launches apart
+    full, mop = r["full_sweep"], r["mop_up"]
+    assert r["own_durations_from"] and full["launches"] > 0 and full["bytes"] > 0 and full["own_ms"] > 0
+    assert full["launches"] + mop["launches"] == r["launches"] and mop["launches"] >= 0
+    assert abs((full["bytes"] + mop["bytes"]) / max(r["launches"], 1) - r["algorithmic_bytes_per_launch"]) <= 2
+    assert abs(r["achieved"] - (full["bytes"] + mop["bytes"]) / ((full["own_ms"] + mop["own_ms"]) * 1e-3) / 1e9) <= 0.02 * r["achieved"] + 0.2
+    # the class's time per step is measured on one time line: it cannot exceed the step
+    ct = r["class_throughput"]
+    assert 0 < ct["busy_ms_per_step"] <= d["ms_per_step"] and abs(ct["frac"] - ct["achieved"] / r["peak"]) < 1e-3
     for k in d["kernels"].values():
         assert k["busy_ms"] <= k["ms"] + 1e-3 and k["busy_ms"] <= d["ms_per_step"] * d["steps"] + 1e-3
     # every figure in the roofline object is measured in this run or says where it comes from
     assert "traffic_source" in r and (r["traffic"] is None or r["traffic"] > 0)
-    assert r["isolated"] is not None and r["isolated"]["avg_launch_us"] > 0 and r["isolated"]["launches"] > 0
+    # the start of an E-step's labelling is on the line where the driver keeps it, and the whole fit is there under both rules
+    assert "warm_start=best" in d["config"]["workload"]
+    assert d["fit"]["warm_start"] == "best" and d["fit_reference_start"]["warm_start"] == "local"
+    for f in (d["fit"], d["fit_reference_start"]):
+        assert f["iterations"] >= 1 and f["value"] > 0 and len(f["estep_ms"]) == f["iterations"]
     assert d["build"]["source_hash"]
     if r["kernel"] in ("strip", "fusion"):
         lim = d["roofline_limiter"]

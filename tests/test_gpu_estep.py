@@ -818,8 +818,12 @@ def test_coarse_labels_in_batches_give_the_one_by_one_sequence():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = []
+    dev = os.path.join(root, "phylo_hmrf_amd", "libphmrf_dev.so")      # (the knob exists in the -DPHMRF_DEV build only)
+    assert os.path.exists(dev), "libphmrf_dev.so not built (make -C phylo_hmrf_amd/csrc)"
     for batch in ("4", "1"):
         env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", PHMRF_COARSE_BATCH=batch)
+        if batch != "4":
+            env["PHMRF_LIB"] = dev                                     # the product library (batches of 4) against it
         out = subprocess.run([sys.executable, "-c", DET_SCRIPT.replace("range(3)", "range(1)")], capture_output=True, text=True,
                              timeout=600, env=env)
         assert out.returncode == 0, out.stderr[-3000:]
@@ -840,7 +844,9 @@ def test_coarse_shortcuts_leave_the_labellings_alone():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = []
-    for extra in ({}, {"PHMRF_COARSE_NO_STAMP_GATE": "1"}, {"PHMRF_NO_PIN_LOOK": "1"}):
+    dev = os.path.join(root, "phylo_hmrf_amd", "libphmrf_dev.so")      # (the knobs exist in the -DPHMRF_DEV build only)
+    assert os.path.exists(dev), "libphmrf_dev.so not built (make -C phylo_hmrf_amd/csrc)"
+    for extra in ({}, {"PHMRF_COARSE_NO_STAMP_GATE": "1", "PHMRF_LIB": dev}, {"PHMRF_NO_PIN_LOOK": "1", "PHMRF_LIB": dev}):
         env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", **extra)
         out = subprocess.run([sys.executable, "-c", DET_SCRIPT.replace("range(3)", "range(1)")], capture_output=True, text=True,
                              timeout=600, env=env)

@@ -1,0 +1,55 @@
+"""CPU: `roofline.frac` of the bench line is the dominant kernel's own fraction of the HBM roofline, and it can be recomputed
+from the committed profile pair of ONE run (profiles/r5_bench_under_rocprof_serial.json = the JSON line of
+`rocprofv3 --kernel-trace --stats -- python3 bench.py --block-threads 1 ...`, profiles/r5_kernel_stats_serial.csv = that
+run's per-kernel summary): algorithmic bytes per launch (SURVEY.md 8d accounting x device-counted cells, from the line) over
+the kernel's average duration in the profiler's summary, against the same peak.  The two must agree within 10 %
+(the summary also holds the launches of the cold warm-up iteration and of the passes after the timed region, whose mix of
+full sweeps and mop-up launches differs a little from the timed region's)."""
+import csv
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINE = os.path.join(ROOT, "profiles", "r5_bench_under_rocprof_serial.json")
+STATS = os.path.join(ROOT, "profiles", "r5_kernel_stats_serial.csv")
+
+
+def _load():
+    assert os.path.exists(LINE) and os.path.exists(STATS), "profiles/r5_bench_under_rocprof_serial.json / r5_kernel_stats_serial.csv missing"
+    d = json.loads(open(LINE).read().strip().splitlines()[-1])
+    rows = list(csv.DictReader(open(STATS)))
+    return d, rows
+
+
+def test_frac_of_the_bench_line_follows_from_the_profilers_kernel_durations():
+    d, rows = _load()
+    r = d["roofline"]
+    assert d["block_threads"] == 1, "the pair must come from a --block-threads 1 run (one stream in flight)"
+    names = r["kernel_names"]
+    calls = total_ns = 0
+    for row in rows:
+        if any(("::" + k + "<") in row["Name"] or ("::" + k + "(") in row["Name"] for k in names):
+            calls += int(row["Calls"])
+            total_ns += float(row["TotalDurationNs"])
+    assert calls > 0, names
+    avg_us = total_ns / calls / 1e3
+    frac_csv = r["algorithmic_bytes_per_launch"] / (avg_us * 1e-6) / 1e9 / r["peak"]
+    assert abs(frac_csv - r["frac"]) <= 0.10 * r["frac"], (frac_csv, r["frac"], avg_us, r["avg_launch_us"])
+    # the line's own durations (HIP events around each launch) against the profiler's
+    assert abs(avg_us - r["avg_launch_us"]) <= 0.10 * avg_us, (avg_us, r["avg_launch_us"])
+
+
+def test_frac_is_bytes_over_own_durations_and_its_parts_add_up():
+    d, _ = _load()
+    r = d["roofline"]
+    full, mop = r["full_sweep"], r["mop_up"]
+    by, ms = full["bytes"] + mop["bytes"], full["own_ms"] + mop["own_ms"]
+    assert full["launches"] + mop["launches"] == r["launches"]
+    assert abs(by / (ms * 1e-3) / 1e9 - r["achieved"]) <= 0.01 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # a full sweep moves far more bytes per launch than a mop-up launch and runs nearer the roofline
+    assert full["bytes"] / full["launches"] > mop["bytes"] / max(mop["launches"], 1)
+    assert full["GBps"] > (mop["GBps"] or 0.0)
+    assert d["build"]["source_hash"]
