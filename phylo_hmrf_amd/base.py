@@ -162,8 +162,11 @@ class _BaseGraph(object):
         (params_vec, params_vec1, params_vecList, iter_id1, iter_id2, cost_vec, t_labels)   (base.py:455)."""
         self._log("Initilization...")
         start = time.time()
+        resumed = {}
+        it0 = 0
         if self.resume_from:
             _BaseGraph._init(self, X, lengths=lengths)    # (start / transition vectors only: the rest comes from the file)
+            it0 = self._read_checkpoint(self.resume_from, resumed)
         else:
             self._init(X, lengths=lengths)
         self._log("use time %s:" % (time.time() - start))
@@ -185,10 +188,8 @@ class _BaseGraph(object):
         K, S = self.n_components, self.n_features
         self.timing_ = {"estep": [], "mstep": []}
 
-        it0 = 0
         if self.resume_from:
-            loop = {}
-            it0 = self._read_checkpoint(self.resume_from, loop)
+            loop = resumed
             cost_vec, params_vecList = loop["cost_vec"], loop["params_vecList"]
             min_cost, min_cost1 = loop["min_cost"], loop["min_cost1"]
             params_vec, params_vec1 = loop["params_vec"], loop["params_vec1"]

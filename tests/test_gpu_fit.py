@@ -209,3 +209,61 @@ def test_cli_runs_from_raw_hic_text(tmp_path, filter_mode):
     assert os.path.exists(os.path.join(d, "chrom_quantile_test.txt"))
     dm = scipy.io.loadmat(mat)
     assert dm["state_vec"].size == samples.shape[0] and np.all(np.isfinite(dm["cost_vec"]))
+
+
+def test_checkpoint_and_resume_continue_the_fit_exactly(tmp_path, monkeypatch):
+    """SURVEY.md section 5 (checkpoint/resume; the reference keeps its state in RAM only, base.py:412): six EM iterations
+    straight against three iterations + a checkpoint + a resumed fit to six, solver deterministic (PHMRF_DETERMINISTIC=1) and
+    the reference's own M-step with its random restarts (the generator's state travels in the checkpoint).  The resumed fit
+    continues with the same bookkeeping (base.py:402-435): every row of cost_vec equal to 1e-12, labels exactly, the
+    parameter history and the returned iteration ids equal."""
+    import phylo_hmrf as cli
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    monkeypatch.setenv("PHMRF_DETERMINISTIC", "1")
+    Xs, lens, edges, tree, off = [], [], [], None, 0
+    for N, seed in ((48, 1), (61, 2)):
+        X, lv, ev, tree = cli.synthetic_cache(N, 4, 5, 8, seed)
+        n = X.shape[0]
+        row = list(lv[0])
+        row[1], row[2], row[7] = off, off + n, len(lens)
+        Xs.append(X)
+        lens.append(row)
+        edges.append(ev[0])
+        off += n
+    X = np.concatenate(Xs)
+    ck = str(tmp_path / "fit.ckpt.npz")
+
+    def model(**kw):
+        return phyloHMRF(n_components=5, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree,
+                         len_vec=lens, type_id=1, branch_list=[1.0] * 7, edge_list_1=edges, cons_param=1.0, beta=1.0,
+                         beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0,
+                         learning_rate=0.001, estimate_type=3, max_iter=100, n_iter=5000, tol=1e-7, random_state=9,
+                         quiet=True, mstep_workers=1, block_threads=1, init_method="sklearn", **kw)
+
+    m = model()
+    straight = m.fit_accumulate_test(X, lens, 1e-12, "t", 6)
+    m.close()
+    m = model(checkpoint_path=ck, checkpoint_every=1)
+    first = m.fit_accumulate_test(X, lens, 1e-12, "t", 3)
+    m.close()
+    assert os.path.exists(ck) and not os.path.exists(ck + ".tmp.npz")
+    z = np.load(ck)
+    assert int(z["it_next"]) == 3 and z["cost_vec"].shape == (3, 4) and z["labels_local"].shape == (X.shape[0],)
+    np.testing.assert_allclose(first[5], straight[5][:3], rtol=1e-12, atol=0)
+    m = model(resume_from=ck)
+    resumed = m.fit_accumulate_test(X, lens, 1e-12, "t", 6)
+    m.close()
+    assert resumed[5].shape == straight[5].shape == (6, 4)
+    np.testing.assert_allclose(resumed[5], straight[5], rtol=1e-12, atol=0)         # cost_vec, all six rows
+    assert np.array_equal(resumed[6], straight[6])                                   # t_labels
+    assert resumed[3] == straight[3] and resumed[4] == straight[4]                   # iter_id1, iter_id2
+    np.testing.assert_allclose(resumed[2], straight[2], rtol=1e-12, atol=0)         # params_vecList
+    np.testing.assert_allclose(resumed[0], straight[0], rtol=1e-12, atol=0)
+    # a checkpoint of another model is refused
+    m = phyloHMRF(n_components=4, run_id=0, n_samples=X.shape[0], n_features=4, observation=X, edge_list=tree, len_vec=lens,
+                  type_id=1, branch_list=[1.0] * 7, edge_list_1=edges, cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0,
+                  initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, learning_rate=0.001, estimate_type=3,
+                  max_iter=100, n_iter=5000, tol=1e-7, random_state=9, quiet=True, mstep_workers=1, resume_from=ck)
+    with pytest.raises(ValueError):
+        m.fit_accumulate_test(X, lens, 1e-12, "t", 6)
+    m.close()
