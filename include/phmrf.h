@@ -48,7 +48,7 @@ typedef struct phmrf_block* phmrf_block_t;
 /* ---- library ---------------------------------------------------------------------------------- */
 /* ABI version = major * 100 + minor.  110 (round 4): PHMRF_NUM_KERNEL_CLASSES is 10 and phmrf_block_get_timing takes the
  * capacity of the caller's arrays; phmrf_block_get_work writes 8 values; the resumable solve (phmrf_mrf_solve_begin ...
- * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
+ * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
  * (phylo_hmrf_amd/_lib.py does). */
 #define PHMRF_VERSION 120
 PHMRF_API int phmrf_version(void);
@@ -168,6 +168,14 @@ typedef struct phmrf_solve_opts {
                           a quarter of the tolerance -- a heuristic about labels, not a bound on the energy a stop
                           leaves behind (what the stops do leave is measured against gco in the parity tests).
                           0: run to the exact fixed point                                                          */
+  int coarse_start;    /* 1: a cold start (init_mode 1) of a grid block begins COARSE-TO-FINE: the labelling problem of its
+                          4 x 4 super-cells (unary terms and crossing pair weights summed: an ordinary Potts problem on a
+                          grid of n / 16 nodes) is solved by this same solver -- recursively while it is large --, its
+                          labels are copied down to the cells, and the fine moves start from there instead of from
+                          argmax_k logprob.  Only the START of the solve changes (8-neighbour grid blocks of >= 1,024
+                          nodes that are not row tiles; otherwise ignored).  0 (default): off -- measured in round 5 on
+                          the synthetic Hi-C workloads: the prolongated coarse labelling starts HIGHER than argmax + one
+                          ICM sweep and the solve is slower, so nothing in the fit or the bench uses it */
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {

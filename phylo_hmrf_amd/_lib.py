@@ -25,7 +25,8 @@ class PhmrfError(RuntimeError):
 class SolveOpts(ctypes.Structure):
     _fields_ = [("max_rounds", ctypes.c_int), ("use_chains", ctypes.c_int), ("use_components", ctypes.c_int),
                 ("init_mode", ctypes.c_int), ("use_strips", ctypes.c_int), ("use_expansion", ctypes.c_int),
-                ("min_changed", ctypes.c_int), ("use_coarse", ctypes.c_int), ("energy_tol_ppb", ctypes.c_int)]
+                ("min_changed", ctypes.c_int), ("use_coarse", ctypes.c_int), ("energy_tol_ppb", ctypes.c_int),
+                ("coarse_start", ctypes.c_int)]
 
 
 class SolveResult(ctypes.Structure):

@@ -120,26 +120,26 @@ class Block(object):
 
     # -- b2 ---------------------------------------------------------------------------------------
     def solve(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
-              use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True):
+              use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True, coarse_start=0):
         o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
-                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb))
+                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb), int(coarse_start))
         r = SolveResult()
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), ctypes.byref(r)))
         return dict(energy=r.energy, energy_unary=r.energy_unary, energy_pair=r.energy_pair,
                     energy_init=r.energy_init, rounds=r.rounds, converged=bool(r.converged), changed=r.changed)
 
     def solve_fast(self, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
-                   use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True):
+                   use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True, coarse_start=0):
         """Same without the two energy evaluations."""
         o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
-                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb))
+                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb), int(coarse_start))
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), None))
 
     # -- the solve in pieces (lockstep rounds of the row tiles of one block: tiles.py) ----------------
     def solve_begin(self, beta, want_init_energy=False, max_rounds=64, use_chains=True, use_components=True, init_mode=0,
-                    use_strips=True, use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True):
+                    use_strips=True, use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True, coarse_start=0):
         o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
-                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb))
+                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb), int(coarse_start))
         check(self._L.phmrf_mrf_solve_begin(self._h, float(beta), ctypes.byref(o), int(bool(want_init_energy))))
 
     def solve_round_launch(self):

@@ -375,6 +375,10 @@ int phmrf_block_destroy(phmrf_block_t b) {
   if (!b) return PHMRF_OK;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   coarse_children_destroy(b);
+  if (b->c2f) {
+    (void)phmrf_block_destroy(b->c2f);
+    b->c2f = nullptr;
+  }
   dev_free(b->X);
   dev_free(b->logprob);
   dev_free(b->labels);
@@ -1278,6 +1282,47 @@ int tile_queue_boundary(phmrf_block* b) {
   return PHMRF_OK;
 }
 
+// The coarse-to-fine start of a cold solve (c2f.hip): the labelling problem of the block's 4 x 4 super-cells as a block of
+// its own (created at the first cold solve; its graph is built once, the graph of the block being constant over a fit),
+// solved from ITS cold start by this same solver -- which recurses while the coarse block is large --, and copied down.
+// *started: the block's labels are the prolongated coarse labels (otherwise the caller takes argmax_k logprob).
+static int c2f_start(phmrf_block_t b, double beta, const phmrf_solve_opts& o, bool* started) {
+  *started = false;
+  if (o.coarse_start <= 0 || !b->has_grid || !b->fwd_w || b->num_neighbor != 8 || !b->grid_complete) return PHMRF_OK;
+  if (b->tile_top || b->tile_bot || !o.use_strips) return PHMRF_OK;
+  if (b->n < 1024 || b->H < 2 * C2F_SCALE || b->W < 2 * C2F_SCALE) return PHMRF_OK;
+  const int s = C2F_SCALE;
+  if (!b->c2f) {
+    const int Hc = (b->H + s - 1) / s, Wc = (b->W + s - 1) / s;
+    Geometry gc(Hc, Wc, b->diagonal);
+    phmrf_block_t c = nullptr;
+    PHMRF_TRY(phmrf_block_create(gc.count(), 1, b->K, &c));
+    b->c2f = c;
+    b->c2f_Hc = Hc;
+    b->c2f_Wc = Wc;
+    c->stream = b->stream;                      // (the child's kernels read the parent's logprob and write its labels)
+    PHMRF_TRY(dev_alloc(&c->nbr, (size_t)c->n * 8));
+    PHMRF_TRY(dev_alloc(&c->wgt, (size_t)c->n * 8));
+    c->D = 8;
+    PHMRF_TRY(launch_c2f_graph(b, c, Hc, Wc, s));
+    if (!c->colour_nodes) PHMRF_TRY(dev_alloc(&c->colour_nodes, (size_t)c->n));
+    c->has_graph = true;
+    PHMRF_TRY(setup_grid_tables(c, gc, 8));
+    c->grid_complete = true;
+  }
+  phmrf_block* c = b->c2f;
+  c->stream = b->stream;
+  PHMRF_TRY(launch_c2f_logprob(b, c, b->c2f_Wc, s));
+  c->has_logprob = true;
+  c->uT_valid = false;
+  phmrf_solve_opts oc = o;
+  oc.init_mode = 1;
+  PHMRF_TRY(phmrf_mrf_solve(c, beta, &oc, nullptr));
+  PHMRF_TRY(launch_c2f_prolong(b, c, b->c2f_Wc, s));
+  *started = true;
+  return PHMRF_OK;
+}
+
 int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool want_init_energy) {
   PHMRF_TRY(check_solvable(b));
   if (b->ss) solve_scope_exit(b);                 // (an abandoned solve)
@@ -1305,7 +1350,9 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
     ~Abort() { if (armed) solve_scope_exit(blk); }
   } abort_guard{b};
   if (o.init_mode == 1) {
-    PHMRF_TRY(launch_argmax_labels(b));
+    bool started = false;
+    PHMRF_TRY(c2f_start(b, beta, o, &started));        // coarse-to-fine (c2f.hip), where the block qualifies
+    if (!started) PHMRF_TRY(launch_argmax_labels(b));
     b->has_labels = true;
   }
   if (want_init_energy) {

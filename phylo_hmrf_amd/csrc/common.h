@@ -111,6 +111,9 @@ struct phmrf_block {
   // coarse alpha-expansions (coarse.hip): child blocks holding the two-label problem of the super-cells, side 2, 4, 8
   phmrf_block* coarse[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [level * 4 + slot in a batch of labels]
   unsigned int* coarse_flag = nullptr;      // device: set by coarse_apply_kernel when a label of the batch has moved
+  // coarse-to-fine start of a cold solve (c2f.hip): the block of C2F_SCALE x C2F_SCALE super-cells, a full block of its own
+  phmrf_block* c2f = nullptr;
+  int c2f_Hc = 0, c2f_Wc = 0;
   char* coarse_arena = nullptr;             // ONE allocation behind the twelve child problems (labels, unary planes, weights, counters)
   int prop_tick = -1;                       // tick of the last proposal launch of this solve (-1: none)
   int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
@@ -218,6 +221,7 @@ namespace phmrf {
 #else
 #define PHMRF_DEV_ENV(name) (static_cast<const char*>(nullptr))
 #endif
+constexpr int C2F_SCALE = 4;          // super-cells of the coarse-to-fine start (c2f.hip)
 constexpr int UT_PAD = 64;            // floats of slack before and after the unary planes (strip.hip: launch_unary_planes)
 constexpr int WORK_SLOTS = 7;         // see phmrf_block_get_work
 constexpr int WORK_BANKS = 256;       // work_acc[WORK_BANKS][WORK_SLOTS]: strips staged, their cells, staged cells (with rim), DP
@@ -257,6 +261,9 @@ int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, con
                          const unsigned int* rebuild, int since, bool reset);
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr,
                         unsigned int* moved_flag = nullptr);
+int launch_c2f_graph(const phmrf_block* b, phmrf_block* child, int Hc, int Wc, int s);     // c2f.hip
+int launch_c2f_logprob(const phmrf_block* b, phmrf_block* child, int Wc, int s);
+int launch_c2f_prolong(const phmrf_block* b, const phmrf_block* child, int Wc, int s);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
 // row tiles (tile.hip)
 constexpr float PIN_COST = 1.0e9f;      // unary term of every label but its own at a pinned node (<< f32 max: sums of a strip's

