@@ -416,11 +416,29 @@ def main():
     barrier()
     from phylo_hmrf_amd.block import time_base_reset
     time_base_reset()                                          # t = 0 of the kernel-interval time line
+    for g in conductor.groups:
+        g.reset_clock()
     t0 = time.time()
     for _ in range(a.steps):
         em_step()
     barrier()
     elapsed = time.time() - t0 - untimed[0]
+    # the lockstep rounds of this rank's split blocks in the timed region: host time per round and group of the exchange
+    # (boundary rows out of the pinned buffers + pack, the all-reduce over the block's holders, unpack + halo rows in)
+    tile_rounds = None
+    if conductor.groups:
+        rs = sum(g.clock["rounds"] for g in conductor.groups)
+        tile_rounds = {"groups": len(conductor.groups), "rounds": int(rs), "rounds_per_solve": round(rs / float(a.steps * len(conductor.groups)), 2),
+                       "tile_round_exchange_us": round(1e6 * sum(g.clock["exchange"] for g in conductor.groups) / max(rs, 1), 1),
+                       "of_which_allreduce_us": round(1e6 * sum(g.clock["allreduce"] for g in conductor.groups) / max(rs, 1), 1),
+                       "collect_wait_us": round(1e6 * sum(g.clock["collect"] for g in conductor.groups) / max(rs, 1), 1),
+                       "decide_us": round(1e6 * sum(g.clock["decide"] for g in conductor.groups) / max(rs, 1), 1),
+                       "transport": ("local (every tile of the block on this rank)" if all(g.comm is None or g.comm.group is None
+                                                                                          for g in conductor.groups)
+                                     else "torch.distributed %s over %d ranks" % (backend, world)),
+                       "note": "host wall time per lockstep round and split block on rank 0: exchange = boundary rows + pack, the "
+                               "all-reduce over the ranks that hold the block's tiles, unpack + halo rows queued; collect_wait = "
+                               "waiting for the round's kernels (the tiles' E-step work itself)"}
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -689,6 +707,7 @@ def main():
             "cold_first_iteration_ms": cold_first_ms,
             "fit": fit,
             "fit_reference_start": fit_ref,
+            "tile_rounds": tile_rounds,
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
             "value_estep_only": n_norm * a.steps / float(np.sum(t_e_timed)),

@@ -177,6 +177,13 @@ class TileGroup(object):
         self.status = 0
         self.missing = set(range(self.ntiles)) - set(self.local) if comm is None else set()
         self.result = None
+        # host wall time of the rounds' parts since reset_clock(): waiting for the local tiles' kernels (collect), the
+        # exchange proper (pack, all-reduce over the holders, unpack + halo rows in), the schedule's decision
+        self.clock = dict(rounds=0, collect=0.0, exchange=0.0, allreduce=0.0, decide=0.0)
+
+    def reset_clock(self):
+        for k in self.clock:
+            self.clock[k] = 0 if k == "rounds" else 0.0
 
     # the payload of tile t: [counters 128 | energy 2 (float64 bits) | 1 + the status its holder decided last round |
     # first owned row | last owned row], int64 words
@@ -244,14 +251,22 @@ class TileGroup(object):
 
     def finish_round(self):
         """wait for the local tiles, exchange with the others, decide.  -> status (the same on every rank)"""
+        import time
         buf = np.zeros(self.ntiles * self.slot, dtype=np.int64)
+        t0 = time.perf_counter()
+        got = []
         for t in sorted(self.local):
             tl = self.local[t]
             counters, energy = tl.b.solve_round_collect()
+            got.append((t, tl, counters, energy))
+        t1 = time.perf_counter()
+        for t, tl, counters, energy in got:
             top, bot = tl.b.tile_get_boundary(tl.top_out, tl.bot_out)
             self._pack(buf, t, counters, energy, top, bot)
+        ta = time.perf_counter()
         if self.comm is not None:
             buf = self.comm.allreduce_i64(buf)
+        tb = time.perf_counter()
         tot_c = np.zeros(N_COUNTERS, dtype=np.uint64)
         tot_e = np.zeros(2, dtype=np.float64)
         seen = set()
@@ -275,9 +290,18 @@ class TileGroup(object):
             if tl.bottom and (t + 1) not in self.missing:
                 halo_bot = self._rows(buf, t + 1)[0][:tl.bot_in]           # the lower neighbour's first owned row
             tl.b.tile_put_halo(halo_top, halo_bot)
-            st = tl.b.solve_round_decide(tot_c, tot_e)
+        t2 = time.perf_counter()
+        for t in sorted(self.local):
+            st = self.local[t].b.solve_round_decide(tot_c, tot_e)
             assert status is None or status == st, "tiles of one block disagree on the schedule"
             status = st
+        t3 = time.perf_counter()
+        c = self.clock
+        c["rounds"] += 1
+        c["collect"] += t1 - t0
+        c["exchange"] += t2 - t1
+        c["allreduce"] += tb - ta
+        c["decide"] += t3 - t2
         self.rounds += 1
         self.status = status
         return status
