@@ -945,8 +945,21 @@ int phmrf_block_warm_start(phmrf_block_t b, double beta, int slot, int choose, d
     if (e_saved) *e_saved = 0.0;
     return PHMRF_OK;
   }
-  // the two evaluations and the choice are queued on the block's stream; the host waits only if it wants the numbers
   double* const extra = b->accum + (ACCUM_DOUBLES - 4);     // (behind every statistic the accum area can hold)
+  if (choose && !report && energy_diff_available(b)) {
+    // nobody asked for the two energies: what decides is the SIGN of their difference, which comes from the nodes where the
+    // two labellings differ (energy_diff_grid_kernel) -- one light pass instead of two full ones; the choice kernel then
+    // compares (difference, 0)
+    PHMRF_TRY(zero_accum(b, 4, 2));
+    PHMRF_TRY(zero_accum(b, ACCUM_DOUBLES - 4, 2));
+    tic(b, KC_ENERGY);
+    PHMRF_TRY(launch_energy_diff(b, b->saved[slot]));
+    PHMRF_TRY(launch_choose_labels(b, b->saved[slot], b->accum + 4, extra, beta));
+    toc(b, KC_ENERGY, 2);
+    b->labels_are_slot = 0;
+    return PHMRF_OK;
+  }
+  // the two evaluations and the choice are queued on the block's stream; the host waits only if it wants the numbers
   PHMRF_TRY(zero_accum(b, 4, 2));
   PHMRF_TRY(zero_accum(b, ACCUM_DOUBLES - 4, 2));
   tic(b, KC_ENERGY);

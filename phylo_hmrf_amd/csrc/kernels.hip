@@ -463,6 +463,78 @@ __global__ __launch_bounds__(256) void energy_delta_grid_kernel(const float* __r
   if (threadIdx.x == 0 && (tu != 0.0 || tp != 0.0)) energy_flush(accum, tu, tp, det);
 }
 
+// E(labels) - E(other) of two labellings of a grid block, from the nodes where they DIFFER: an edge's term can only differ
+// where an end differs, and every edge is held by its upper / left end, so a node contributes if it or one of its four
+// forward neighbours carries different labels in the two -- its unary terms (if it differs itself) and its forward edges,
+// term by term exact in f32 and summed in f64.  Reads two label bytes per node and neighbour (cached), 24 B more where the
+// labellings differ: the warm start of an E-step (phmrf_block_warm_start: labels_local against the previous result, which
+// differ in a few per cent of the nodes) needs the SIGN of this difference, not two full energy passes.  Same thread layout as
+// energy_grid_kernel; rows [row0, row1) are counted (a row tile's owned rows).
+__global__ __launch_bounds__(256) void energy_diff_grid_kernel(const float* __restrict__ uT, int64_t n, int H, int W, int diagonal,
+                                                               const float4* __restrict__ fwd_w,
+                                                               const uint8_t* __restrict__ labels,
+                                                               const uint8_t* __restrict__ other, double* __restrict__ accum,
+                                                               int det, int row0, int row1) {
+  __shared__ double red[8];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  double eu = 0.0, ep = 0.0;
+  constexpr int UR = 4;
+  const int stride = gridDim.y * 4;
+  for (int i0 = row0 + blockIdx.y * 4 + (threadIdx.x >> 6); i0 < row1; i0 += stride * UR) {
+    int64_t me[UR], c[UR][4];
+    bool in[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int i = i0 + u * stride;
+      in[u] = i < row1 && j < W && !(diagonal && j < i);
+      const int64_t row = diagonal ? (int64_t)i * W - ((int64_t)i * (i - 1)) / 2 - i : (int64_t)i * W;      // node = row + j
+      const int64_t row2 = diagonal ? (int64_t)(i + 1) * W - ((int64_t)(i + 1) * i) / 2 - (i + 1) : (int64_t)(i + 1) * W;
+      const int jlo = diagonal ? i + 1 : 0;
+      const bool below = in[u] && i + 1 < H;
+      me[u] = in[u] ? row + j : 0;
+      c[u][0] = (in[u] && j + 1 < W) ? me[u] + 1 : me[u];                       // E
+      c[u][1] = (below && j - 1 >= jlo) ? row2 + j - 1 : me[u];                 // SW
+      c[u][2] = (below && j >= jlo) ? row2 + j : me[u];                         // S
+      c[u][3] = (below && j + 1 < W) ? row2 + j + 1 : me[u];                    // SE
+    }
+    int la[UR], lb[UR], na[UR][4], nb[UR][4];
+    bool on[UR];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      la[u] = labels[me[u]];
+      lb[u] = other[me[u]];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        na[u][q] = labels[c[u][q]];
+        nb[u][q] = other[c[u][q]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      on[u] = in[u] && (la[u] != lb[u] || na[u][0] != nb[u][0] || na[u][1] != nb[u][1] || na[u][2] != nb[u][2] || na[u][3] != nb[u][3]);
+      any = any || on[u];
+    }
+    if (!__any(any)) continue;
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      if (!on[u]) continue;
+      const float4 w = fwd_w[me[u]];
+      if (la[u] != lb[u]) eu += (double)uT[(int64_t)la[u] * n + me[u]] - (double)uT[(int64_t)lb[u] * n + me[u]];
+      float s = 0.f;
+      // (an absent neighbour is the node itself: equal labels in both, and its weight is 0)
+      s += (na[u][0] != la[u] ? w.x : 0.f) - (nb[u][0] != lb[u] ? w.x : 0.f);
+      s += (na[u][1] != la[u] ? w.y : 0.f) - (nb[u][1] != lb[u] ? w.y : 0.f);
+      s += (na[u][2] != la[u] ? w.z : 0.f) - (nb[u][2] != lb[u] ? w.z : 0.f);
+      s += (na[u][3] != la[u] ? w.w : 0.f) - (nb[u][3] != lb[u] ? w.w : 0.f);
+      ep += (double)s;
+    }
+  }
+  const double tu = block_sum(eu, red);
+  const double tp = block_sum(ep, red);
+  if (threadIdx.x == 0 && (tu != 0.0 || tp != 0.0)) energy_flush(accum, tu, tp, det);
+}
+
 // -------------------------------------------------------------------------------------------------
 // b3 posteriors + costs + sufficient statistics, fused (phylo_hmrf.py:334-355, :374-396, :311-314).
 //   pp[i,k]   = beta * sum_{e in inc(i)} w'_e [l_other != k]          (w' = w if estimate_type==3 else 1)
@@ -833,6 +905,23 @@ int launch_choose_labels(const phmrf_block* b, const uint8_t* saved, const doubl
   const int grid = (int)(g64 > 4096 ? 4096 : g64);
   hipLaunchKernelGGL(choose_labels_kernel, dim3(grid), dim3(256), 0, b->stream, b->labels, saved, b->n, acc_cur, acc_sav, beta,
                      b->deterministic ? 1 : 0);
+  PHMRF_HIP(hipGetLastError());
+  return PHMRF_OK;
+}
+
+// E(current labels) - E(other) into the block's energy slots (caller zeroes them); grid blocks with unary planes only
+bool energy_diff_available(const phmrf_block* b) {
+  return b->has_grid && b->fwd_w && b->H > 0 && b->W > 0 && b->uT && b->uT_valid && b->n >= (1 << 16);
+}
+
+int launch_energy_diff(const phmrf_block* b, const uint8_t* other) {
+  const int gx = (b->W + 63) / 64;
+  int gy = (b->H + 3) / 4;
+  const int cap = 2048 / gx + 1;
+  if (gy > cap) gy = cap;
+  const int row0 = b->own_r1 >= 0 ? b->own_r0 : 0, row1 = b->own_r1 >= 0 ? b->own_r1 : b->H;
+  hipLaunchKernelGGL(energy_diff_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->uT, b->n, b->H, b->W, b->diagonal, b->fwd_w,
+                     b->labels, other, b->accum, b->deterministic ? 1 : 0, row0, row1);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

@@ -329,6 +329,8 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
     const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
     const int ncols = cb > ca ? cb - ca : 0;
     const int ncell = ncols * SH;
+    // (a strip of the bounding rectangle that holds no node -- below the diagonal of an upper-triangular block: see strip_cols_kernel)
+    if (g.diagonal && (ORIENT == 0 ? (rs0 > 0 ? rs0 : 0) > cb - 1 : ca > (rs0 + SH - 1 < g.Hs - 1 ? rs0 + SH - 1 : g.Hs - 1))) continue;
 
     // ---- memo test (inside a solve, fixed cuts): a (dilated) change stamp is renewed whenever the node or one of its
     //      neighbours changes label, so the newest stamp among the strip's cells covers the fixed border too.  If nothing

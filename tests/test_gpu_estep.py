@@ -897,3 +897,48 @@ def test_energy_of_later_rounds_from_the_touched_nodes_equals_the_full_pass(H, W
     assert res["rounds"] >= 2 and res["energy"] < res["energy_init"]
     np.testing.assert_allclose([res["energy"], res["energy_unary"], res["energy_pair"]], [e_tot, e_un, e_pw], rtol=1e-11)
     b.close()
+
+
+def test_warm_start_choice_from_the_difference_equals_the_choice_from_two_energies():
+    """phmrf_block_warm_start without a report (the fit's and the bench's call): on a large grid block the choice between the
+    current labels and the snapshot comes from E(current) - E(snapshot) summed over the nodes where the two differ
+    (energy_diff_grid_kernel) instead of from two full energy passes.  Same decision as the reported energies give, in both
+    directions, on an upper-triangular and on a rectangular block; the difference itself is checked against the float64
+    oracle through the reported energies (rel 1e-6 each)."""
+    import torch
+    from phylo_hmrf_amd import Block, synthetic
+    from phylo_hmrf_amd.tree import PhyloTree
+    K, S = 8, 4
+    tree = PhyloTree(synthetic.tree_for(S))
+    rng = np.random.default_rng(12)
+    P = synthetic.sample_ou_params(rng, tree, K)
+    mu, cv = tree.mean_cov(P)
+    cv = cv + 1e-3 * np.eye(S)
+    dev = torch.device("cuda", 0)
+    for H, W, diag in ((420, 420, True), (260, 300, False)):
+        X = synthetic.device_observations(torch, dev, 3, H, W, diag, K, mu, cv)
+        torch.cuda.synchronize()
+        n = X.shape[0]
+        assert n >= 1 << 16
+        b = Block(n, S, K)
+        b.set_observations_dev(X.data_ptr())
+        b.sync()
+        b.build_grid_graph(H, W, diag, 8, 0.5)
+        b.emission(mu, cv)
+        b.solve_fast(1.0, init_mode=1, energy_tol_ppb=1000)
+        good = b.get_labels()
+        worse = good.copy()
+        idx = rng.choice(n, size=n // 40, replace=False)
+        worse[idx] = rng.integers(0, K, idx.size)
+        for cur, snap in ((good, worse), (worse, good), (good, good)):
+            b.set_labels(snap)
+            b.save_labels(1)
+            b.set_labels(cur)
+            ec, es, took = b.warm_start(1.0, 1, choose=False)                # the two energies, nothing chosen
+            assert np.array_equal(b.get_labels(), cur)
+            b.warm_start(1.0, 1, report=False)                                # the choice, from the difference
+            chosen = b.get_labels()
+            want = snap if not (ec < es) else cur
+            assert np.array_equal(chosen, want), (diag, ec, es)
+            assert took == (not (ec < es))
+        b.close()
