@@ -165,7 +165,8 @@ def test_warm_start_policy_and_row_tiles_stay_below_the_reference_at_every_itera
         print("full chr22, iteration %d, %d tiles: reference %.2f  unsplit %.2f  tiled %.2f (%+.1e)"
               % (it, parts, e_ref_lab, e_whole, e_tiled, (e_tiled - e_whole) / abs(e_whole)))
         assert e_tiled <= e_ref_lab, (it, e_tiled, e_ref_lab)          # strictly at or below the reference
-        assert e_tiled <= e_whole + 1e-3 * abs(e_whole), (it, e_tiled, e_whole)
+        # (measured over the five iterations: +4e-5 ... -2.1e-3 with 2 and 3 tiles; worst +2.8e-4)
+        assert e_tiled <= e_whole + 5e-4 * abs(e_whole), (it, e_tiled, e_whole)
     whole.close()
     if grp is not None:
         for tl in grp.local.values():
