@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256) void coarsen_kernel(CoarseGeom g, int64_t n, i
       if (out.c_counter[q]) *out.c_counter[q] = 0ull;
   }
   for (int I = blockIdx.y; I < g.Hc; I += gridDim.y) {
+    // (an upper-triangular block: the columns of this workgroup hold no node from this coarse row on)
+    if (g.diagonal && I * SCALE > (int)(blockIdx.x * blockDim.x + blockDim.x - 1)) break;
     if (stamp) {
       const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x) - g.off;
       bool dirty = false;
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const u
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   // (row groups strided over gridDim.y: the launch that finds the gate down -- most of them -- is a small one)
   for (int i = blockIdx.y * blockDim.y + threadIdx.y; i < g.H; i += gridDim.y * blockDim.y) {
+    if (g.diagonal && i > (int)(blockIdx.x * blockDim.x + blockDim.x - 1)) break;     // (no node below the diagonal)
     bool moved = false;
     const int node = fine_node(g, i, j);
     if (node >= 0) {

@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256) void energy_grid_kernel(const float* __restric
   // coalesce, where the node-major rows cost a 64-byte sector per node).
   constexpr int UR = 4;
   const int stride = gridDim.y * 4;
-  for (int i0 = row0 + blockIdx.y * 4 + (threadIdx.x >> 6); i0 < row1; i0 += stride * UR) {
+  // (an upper-triangular block: the 64 columns of this workgroup hold no node below row 64 blockIdx.x + 63 -- until round 5
+  //  every workgroup walked all H rows, half of the trips over nothing)
+  const int row_end = (diagonal && blockIdx.x * 64 + 64 < row1) ? blockIdx.x * 64 + 64 : row1;
+  for (int i0 = row0 + blockIdx.y * 4 + (threadIdx.x >> 6); i0 < row_end; i0 += stride * UR) {
     int64_t node[UR];
     int lab[UR];
     bool on[UR];
@@ -402,7 +405,8 @@ __global__ __launch_bounds__(256) void energy_delta_grid_kernel(const float* __r
   double eu = 0.0, ep = 0.0;
   constexpr int UR = 4;
   const int stride = gridDim.y * 4;
-  for (int i0 = blockIdx.y * 4 + (threadIdx.x >> 6); i0 < H; i0 += stride * UR) {
+  const int row_end = (diagonal && blockIdx.x * 64 + 64 < H) ? blockIdx.x * 64 + 64 : H;      // (see energy_grid_kernel)
+  for (int i0 = blockIdx.y * 4 + (threadIdx.x >> 6); i0 < row_end; i0 += stride * UR) {
     int64_t node[UR];
     bool on[UR];
     bool any = false;
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(256) void energy_diff_grid_kernel(const float* __re
   double eu = 0.0, ep = 0.0;
   constexpr int UR = 4;
   const int stride = gridDim.y * 4;
-  for (int i0 = row0 + blockIdx.y * 4 + (threadIdx.x >> 6); i0 < row1; i0 += stride * UR) {
+  const int row_end = (diagonal && blockIdx.x * 64 + 64 < row1) ? blockIdx.x * 64 + 64 : row1;   // (see energy_grid_kernel)
+  for (int i0 = row0 + blockIdx.y * 4 + (threadIdx.x >> 6); i0 < row_end; i0 += stride * UR) {
     int64_t me[UR], c[UR][4];
     bool in[UR];
 #pragma unroll
