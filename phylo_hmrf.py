@@ -95,15 +95,54 @@ def cache_names(output_path, resolution, run_id, annot1="observed"):
 
 
 def write_cache(output_path, resolution, run_id, samples, edge_list_vec, len_vec):
-    if int(os.environ.get("RANK", "0")) != 0:      # (several ranks: every one builds the same data, rank 0 writes the cache)
+    """(several ranks: every one builds the same data, rank 0 writes the cache -- each file under a temporary name first and
+    renamed when complete, so that no reader ever sees a truncated file)"""
+    if int(os.environ.get("RANK", "0")) != 0:
         return
     f1, f2, f3 = cache_names(output_path, resolution, run_id)
-    np.save(f1, samples)
     arr = np.empty(len(edge_list_vec), dtype=object)
     for i, e in enumerate(edge_list_vec):
         arr[i] = e
-    np.save(f2, arr, allow_pickle=True)
-    np.savetxt(f3, np.asarray(len_vec), fmt="%d", delimiter="\t")
+    with open(f1 + ".tmp", "wb") as fh:
+        np.save(fh, samples)
+    with open(f2 + ".tmp", "wb") as fh:
+        np.save(fh, arr, allow_pickle=True)
+    np.savetxt(f3 + ".tmp", np.asarray(len_vec), fmt="%d", delimiter="\t")
+    for f in (f1, f2, f3):
+        os.replace(f + ".tmp", f)
+
+
+def init_process_group():
+    """several GPUs (`python -m torch.distributed.run --nproc-per-node N phylo_hmrf.py ...`): the process group is set up FIRST
+    -- before any data is loaded, so that a rank that fails early does not leave the others waiting in the rendezvous, and
+    before anything touches the GPU.  -> (rank, world)"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29519")
+            backend = os.environ.get("PHMRF_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                local = 0 if os.environ.get("PHMRF_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def all_ranks_agree(value):
+    """rank 0's value on every rank (a decision about files must be ONE decision)"""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return value
+    import torch.distributed as dist
+    box = [value]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def load_cache(output_path, resolution, run_id):
@@ -160,8 +199,8 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
     synthetic = int(synthetic)
     seed = None if seed == "" else int(seed)
     print("estimate type %d" % estimate_type)
-    if not os.path.exists(output_path):
-        os.makedirs(output_path)
+    os.makedirs(output_path, exist_ok=True)
+    rank, world = init_process_group()
 
     from phylo_hmrf_amd import mstep
     from phylo_hmrf_amd.tree import load_tree_files
@@ -177,7 +216,8 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
         write_cache(output_path, resolution, run_id, samples, edge_list_vec, len_vec)
     else:
         edge_list, branch_list, species = load_tree_files(data_path)       # phylo_hmrf.py:1607-1631
-        have_cache = all(os.path.exists(f) for f in cache_names(output_path, resolution, run_id))
+        # (rank 0 looks, everybody follows: with --reload 1 no rank may find the cache half there while another writes it)
+        have_cache = all_ranks_agree(all(os.path.exists(f) for f in cache_names(output_path, resolution, run_id)))
         if reload_mode == 1 and not have_cache:
             print("%s does not exist" % cache_names(output_path, resolution, run_id)[0])   # :1682-1684
             reload_mode = 0
@@ -197,7 +237,8 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
                 x_max = float(np.median(np.atleast_2d(np.loadtxt(qfile, delimiter="\t"))[:, 6]))
             else:
                 m_vec_list = preprocess.quantile_contact_vec(chrom_vec, resolution, ref_filename, filename_list, species)
-                np.savetxt(qfile, m_vec_list, fmt="%.4f", delimiter="\t")
+                if rank == 0:
+                    np.savetxt(qfile, m_vec_list, fmt="%.4f", delimiter="\t")
                 x_max = float(np.median(m_vec_list[:, 6]))
             print(x_max)
             samples, len_vec, edge_list_vec = preprocess.load_data_chromosome2(
@@ -210,25 +251,8 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
 
     if method_mode == 1:
         from phylo_hmrf_amd.hmrf import phyloHMRF
-        # several GPUs: `python -m torch.distributed.run --nproc-per-node N phylo_hmrf.py ...` -- one process per GPU; the
-        # blocks (and row tiles of the ones larger than a GPU's share) are dealt to the ranks, every rank loads the data,
-        # rank 0 writes the result.  The process group is set up here, before anything touches the GPU.
-        world = int(os.environ.get("WORLD_SIZE", "1"))
-        rank = int(os.environ.get("RANK", "0"))
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29519")
-                backend = os.environ.get("PHMRF_DIST_BACKEND", "nccl")
-                if backend == "nccl":
-                    local = 0 if os.environ.get("PHMRF_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
-                    torch.cuda.set_device(local)
-                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-                else:
-                    dist.init_process_group(backend, rank=rank, world_size=world)
+        # several GPUs: one process per GPU (init_process_group above); the blocks (and row tiles of the ones larger than a
+        # GPU's share) are dealt to the ranks, every rank loads the data, rank 0 writes the result
         tree1 = phyloHMRF(n_components=n_components1, run_id=run_id, n_samples=samples.shape[0],
                           n_features=samples[0].shape[-1], observation=samples, edge_list=edge_list, len_vec=len_vec,
                           type_id=version, branch_list=branch_list, edge_list_1=edge_list_vec, cons_param=cons_param,
