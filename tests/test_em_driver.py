@@ -45,7 +45,7 @@ def make_model(g, **kw):
         m._upload_labels(g["init_label"])
 
     def fake_mstep(stats):
-        state["it"] += 1
+        state["it"] = m.em_iteration_ + 1        # (the driver's iteration counter: a resumed fit continues the schedule)
         m.params_vec1 = sched[state["it"]].copy()
         m._ou_param_varied_constraint(m.params_vec1)
         m._covars_ = m._covars_ + 1e-3 * np.eye(S)
@@ -69,6 +69,32 @@ def test_driver_reproduces_the_reference_em_trace():
     assert np.array_equal(t_labels, g["t_labels"])
     np.testing.assert_allclose(m.means_, g["final_means"], rtol=1e-12)
     np.testing.assert_allclose(m._covars_, g["final_covars"], rtol=1e-12)
+
+
+@pytest.mark.skipif(not gco_ref.available(), reason="needs the reference gco (oracle/_ref)")
+def test_the_reference_trace_survives_a_checkpoint_and_a_resume(tmp_path):
+    """The reference's recorded 8-iteration trace again, but in two halves: four iterations with a checkpoint after every
+    M-step (phylo_hmrf_amd/base.py; the reference itself keeps this state in RAM only, base.py:412), then a NEW model that
+    resumes from the file and runs to the end.  Everything fit_accumulate_test returns must be what the straight run -- and
+    the reference -- returns: the bookkeeping of base.py:402-435 (min_cost, min_cost1, the previous costs of the stopping
+    rule), labels_local and t_labels all travel in the checkpoint."""
+    g = np.load(os.path.join(G, "em_trace.npz"))
+    ck = str(tmp_path / "trace.ckpt.npz")
+    m = make_model(g, checkpoint_path=ck)
+    m.fit_accumulate_test(g["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", 4)
+    z = np.load(ck)
+    assert int(z["it_next"]) == 4 and z["cost_vec"].shape == (4, 4)
+    np.testing.assert_allclose(z["cost_vec"], g["cost_vec"][:4], rtol=1e-9, atol=1e-12)
+    m = make_model(g, resume_from=ck)
+    res = m.fit_accumulate_test(g["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", int(g["m_iter"]))
+    params_vec, params_vec1, params_vecList, it1, it2, cost_vec, t_labels = res
+    np.testing.assert_allclose(cost_vec, g["cost_vec"], rtol=1e-9, atol=1e-12)
+    assert (it1, it2) == (int(g["iter_id1"]), int(g["iter_id2"]))
+    np.testing.assert_allclose(params_vec, g["params_vec"])
+    np.testing.assert_allclose(params_vec1, g["params_vec1"])
+    np.testing.assert_allclose(params_vecList, g["params_vecList"])
+    assert np.array_equal(t_labels, g["t_labels"])
+    np.testing.assert_allclose(m.means_, g["final_means"], rtol=1e-12)
 
 
 def test_lpt_assignment_balances_and_is_deterministic():

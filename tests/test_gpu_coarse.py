@@ -129,7 +129,7 @@ def test_coarse_to_fine_start_is_a_start_and_nothing_else():
     from phylo_hmrf_amd import Block
     from oracle import mrf_moves as M
     from oracle import ref_numpy as R
-    H = W = 96
+    H = W = 320          # 51,360 nodes: the 4 x 4 child has 3,240 and starts coarse-to-fine itself (its own child: 210)
     K = 6
     blk = synth.make_block(seed=5, H=H, W=W, S=4, K=K, diagonal=True)
     X = blk["X"]
