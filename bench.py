@@ -80,6 +80,11 @@ def parse():
                     help="start of an E-step's labelling: local = labels_local as the reference (phylo_hmrf.py:479); best = "
                          "labels_local or the previous E-step's labels, whichever has the lower energy under the new parameters")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mean-run", type=int, default=25,
+                    help="synthetic data: mean side (bins) of the ground-truth label image's rectangles (SURVEY.md 8d: 25)")
+    ap.add_argument("--noise", type=float, default=1.0,
+                    help="synthetic data: factor on the states' standard deviations (1: as sampled; another data regime for the "
+                         "label solver's schedule)")
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,7 +239,8 @@ def main():
         comm = tiles.GroupComm(owners, tile_comm_dev) if (split and world > 1) else None   # (collective: every rank, block order)
         if erank not in owners:
             continue
-        Xd = synthetic.device_observations(torch, dev, a.seed * 1000 + bi, H, W, diag, K, means_true, cov_true)
+        Xd = synthetic.device_observations(torch, dev, a.seed * 1000 + bi, H, W, diag, K, means_true, cov_true,
+                                           mean_run=a.mean_run, noise=a.noise)
         torch.cuda.synchronize()
         if not split:
             b = Block(workloads.block_nodes(H, W, diag), S, K)
@@ -686,7 +692,10 @@ def main():
             "metric": "EM-iterations/sec x nodes (bin-pairs)", "value": value, "unit": "node-iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s; E-step start: %s" % (a.workload, desc, START_POLICY[a.warm_start]),
+            "config": {"workload": "%s: %s%s; E-step start: %s" % (
+                           a.workload, desc, ("" if (a.mean_run == 25 and a.noise == 1.0) else
+                                              " [data regime: mean run %d bins, noise x %.2f]" % (a.mean_run, a.noise)),
+                           START_POLICY[a.warm_start]),
                        "sharding": ("%d blocks (%d nodes) as %d units (%d blocks cut into row tiles: those above %.2f x a rank's "
                                     "share) dealt to %d rank(s) by longest-processing-time-first; %s"
                                     % (len(all_blocks), n_global, len(units), n_split, a.split_above, eworld,

@@ -385,6 +385,9 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->labels_tmp);
   dev_free(b->labels_eval);
   dev_free(b->coarse_flag);
+  dev_free(b->coarse_lab);
+  if (b->coarse_lab_host) (void)hipHostFree(b->coarse_lab_host);
+  b->coarse_lab_host = nullptr;
   dev_free(b->sgain);
   for (int s = 0; s < 4; ++s) dev_free(b->saved[s]);
   dev_free(b->nbr);
@@ -1167,7 +1170,7 @@ static int coarse_child(phmrf_block_t b, int level_slot, phmrf_block** out) {   
 // every label alpha of `labels_mask` once at one scale / offset: coarsen -> one strip pass per orientation on the
 // super-cell grid -> apply.  4 launches per label.
 static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off, int shift_r, int shift_c, int alpha_lo,
-                                int alpha_hi) {
+                                int alpha_hi, unsigned long long label_mask = ~0ull) {
   const int s = COARSE_SCALE[level];
   if (!b->uT_valid) PHMRF_TRY(launch_unary_planes(b));
   // Labels in batches of four: one pass over the block builds the four child problems (the label-independent two thirds of
@@ -1184,9 +1187,14 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
   if (!b->coarse_flag) PHMRF_TRY(dev_alloc(&b->coarse_flag, (size_t)1));
   tic(b, KC_COARSE);
   int n_launch = 0;
-  for (int a0 = alpha_lo; a0 < alpha_hi; a0 += batch) {
-    const int nl = std::min(batch, alpha_hi - a0);
-    int alphas[4] = {a0, a0 + 1, a0 + 2, a0 + 3};
+  // (the labels of [alpha_lo, alpha_hi) that `label_mask` lists, ascending, in batches)
+  std::vector<int> todo;
+  for (int a = alpha_lo; a < alpha_hi; ++a)
+    if ((label_mask >> a) & 1ull) todo.push_back(a);
+  for (size_t t0 = 0; t0 < todo.size(); t0 += (size_t)batch) {
+    const int nl = (int)std::min<size_t>((size_t)batch, todo.size() - t0);
+    int alphas[4] = {0, 0, 0, 0};
+    for (int q = 0; q < nl; ++q) alphas[q] = todo[t0 + q];
     // The apply pass (a thread per fine node) returns at once when the child's two passes switched no super-cell: the
     // child counts its switches in its own counter slot 0, and the apply kernel reads it on the device.  (The batch's pass
     // zeroes those counters and the block's moved-flag itself.)
@@ -1207,7 +1215,8 @@ static int coarse_sweep_nocount(phmrf_block_t b, float beta, int level, int off,
       PHMRF_TRY(launch_strip_pass(c, beta, 0, shift_r % 6, shift_c % 64, 1, -1));
       PHMRF_TRY(launch_strip_pass(c, beta, 1, (shift_r + 3) % 6, (shift_c + 31) % 64, 1, -1));
       if (b->tick) ++b->tick;
-      PHMRF_TRY(launch_coarse_apply(b, c, s, off, alphas[q], no_gate ? nullptr : c->counters, b->coarse_flag));
+      PHMRF_TRY(launch_coarse_apply(b, c, s, off, alphas[q], no_gate ? nullptr : c->counters, b->coarse_flag,
+                                    b->coarse_lab ? b->coarse_lab + level * 64 + alphas[q] : nullptr));
       n_launch += 3;
     }
   }
@@ -1558,7 +1567,27 @@ int solve_round_launch(phmrf_block_t b) {
   // start of a later EM iteration, which moves 1-3 %, does not pay for them at all.
   // A scale that changed labels in its last run stays on (like every move type), with the super-cell grid shifted by
   // one node per round; a verification round tries every shift of both scales.
+  // Round 5: inside a scale the LABELS rest like the fine expansions' labels do: a label whose expansion at this scale
+  // changed nothing in its last run is left out until the scale is switched on afresh (a round that moved the labelling at
+  // large), a verification round or the forced last say runs all labels again.  A coarse round costs what its labels cost
+  // -- a share of the coarsen pass, two child strip passes and an apply pass each --, and after the first coarse round of a
+  // cold or far-off solve a few labels per scale are still moving (measured: DESIGN.md 3.1).  Row tiles keep every label
+  // (their schedule runs on sums over the tiles; the per-label counts are local).
+  const bool rest_coarse_labels = !(b->tile_top || b->tile_bot) && o.energy_tol_ppb > 0;
   if (s->coarse) {
+    bool any_on = false;
+    for (int lv = 0; lv < N_COARSE_LV; ++lv) {
+      const bool verify_coarse = verifying && (o.energy_tol_ppb == 0 || s->total * COARSE_ON_DIV >= s->sched_n);
+      any_on = any_on || verify_coarse || s->force_coarse ||
+               (active[80 + lv] && (s->last_changed * COARSE_ROUND_DIV >= s->sched_n || s->coarse_changed[lv] > 0));
+    }
+    if (any_on && rest_coarse_labels) {
+      if (!b->coarse_lab) {
+        PHMRF_TRY(dev_alloc(&b->coarse_lab, (size_t)N_COARSE_LV * 64));
+        PHMRF_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->coarse_lab_host), N_COARSE_LV * 64 * sizeof(unsigned long long)));
+      }
+      PHMRF_HIP(hipMemsetAsync(b->coarse_lab, 0, N_COARSE_LV * 64 * sizeof(unsigned long long), b->stream));
+    }
     for (int lv = 0; lv < N_COARSE_LV; ++lv) {
       const int sc = COARSE_SCALE[lv];
       // (a verification round tries every shift of every scale -- as long as the solve has moved the labelling at
@@ -1569,12 +1598,22 @@ int solve_round_launch(phmrf_block_t b) {
                       (active[80 + lv] && (s->last_changed * COARSE_ROUND_DIV >= s->sched_n || s->coarse_changed[lv] > 0));
       s->coarse_ran[lv] = on;
       if (!on) continue;
+      // every label: a verification round, the forced last say, a scale switched on by a round that moved at large
+      const bool all_labels = !rest_coarse_labels || verify_coarse || s->force_coarse ||
+                              s->last_changed * COARSE_ROUND_DIV >= s->sched_n;
+      const unsigned long long kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+      if (all_labels) s->coarse_lab_mask[lv] = kmask;
+      s->coarse_all[lv] = all_labels;
       b->counter_slot = 80 + lv;
       ran[80 + lv] = 1;
       for (int off = 0; off < sc; ++off)
         if (verify_coarse || off == r % sc)
-          PHMRF_TRY(coarse_sweep_nocount(b, bf, lv, off, (2 * r + lv + off) % 6, (17 * r + 5 * lv + 13 * off) % 64, 0, K));
+          PHMRF_TRY(coarse_sweep_nocount(b, bf, lv, off, (2 * r + lv + off) % 6, (17 * r + 5 * lv + 13 * off) % 64, 0, K,
+                                         s->coarse_lab_mask[lv] & kmask));
     }
+    if (any_on && rest_coarse_labels)
+      PHMRF_HIP(hipMemcpyAsync(b->coarse_lab_host, b->coarse_lab, N_COARSE_LV * 64 * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, b->stream));
   }
   b->counter_slot = 0;
   if (b->timing) PHMRF_TRY(work_fetch_async(b));
@@ -1644,7 +1683,16 @@ int solve_round_decide(phmrf_block_t b, const unsigned long long* counters, cons
   s->prev_moving = moving;
   if (moving) s->geom = (s->geom + 1) % 3;
   for (int lv = 0; lv < N_COARSE_LV; ++lv)
-    if (s->coarse_ran[lv]) s->coarse_changed[lv] = (int64_t)counters[80 + lv];
+    if (s->coarse_ran[lv]) {
+      s->coarse_changed[lv] = (int64_t)counters[80 + lv];
+      // the labels that moved something at this scale stay; the others rest (round_launch decides when all run again)
+      if (b->coarse_lab_host && !(b->tile_top || b->tile_bot) && o.energy_tol_ppb > 0) {
+        unsigned long long keep = 0ull;
+        for (int a = 0; a < b->K; ++a)
+          if (b->coarse_lab_host[lv * 64 + a] > 0ull) keep |= 1ull << a;
+        s->coarse_lab_mask[lv] = keep;
+      }
+    }
   ++s->rounds;
   const bool improved = std::isinf(s->e_prev) ? ch > 0 : e_now < s->e_prev - 1e-11 * std::fabs(s->e_prev);
   static const bool trace = getenv("PHMRF_SOLVE_TRACE") != nullptr;   // development aid (one block at a time)

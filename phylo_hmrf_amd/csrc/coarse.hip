@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const u
                                                            const int32_t* __restrict__ nbr, int D,
                                                            unsigned long long* __restrict__ changed,
                                                            const unsigned long long* __restrict__ gate,
-                                                           unsigned int* __restrict__ moved_flag) {
+                                                           unsigned int* __restrict__ moved_flag,
+                                                           unsigned long long* __restrict__ changed_label) {
   if (gate && *gate == 0ull) return;            // the child's passes switched no super-cell: nothing to take over
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   // (row groups strided over gridDim.y: the launch that finds the gate down -- most of them -- is a small one)
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void coarse_apply_kernel(CoarseGeom g, const u
     const unsigned long long m = __ballot(moved);
     if ((threadIdx.x & 63) == 0 && m) {
       atomicAdd(changed, (unsigned long long)__popcll(m));
+      if (changed_label) atomicAdd(changed_label, (unsigned long long)__popcll(m));     // (per scale and label: the schedule rests labels)
       if (moved_flag) *moved_flag = 1u;         // the labelling has changed: later labels of the batch rebuild their problems
     }
   }
@@ -351,12 +353,12 @@ int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int
 }
 
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate,
-                        unsigned int* moved_flag) {
+                        unsigned int* moved_flag, unsigned long long* changed_label) {
   const CoarseGeom g = make_coarse_geom(b, s, off);
   const int gx = (g.W + 63) / 64;
   const dim3 blk(64, 4), grd(gx, std::max(1, std::min((g.H + 3) / 4, (gate ? 2048 : (1 << 20)) / gx)));
   hipLaunchKernelGGL(coarse_apply_kernel, grd, blk, 0, b->stream, g, child->labels, alpha, b->labels,
-                     b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot, gate, moved_flag);
+                     b->tick ? b->stamp : nullptr, b->tick, b->nbr, b->D, b->counters + b->counter_slot, gate, moved_flag, changed_label);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }

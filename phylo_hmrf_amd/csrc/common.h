@@ -114,6 +114,8 @@ struct phmrf_block {
   // coarse-to-fine start of a cold solve (c2f.hip): the block of C2F_SCALE x C2F_SCALE super-cells, a full block of its own
   phmrf_block* c2f = nullptr;
   int c2f_Hc = 0, c2f_Wc = 0;
+  unsigned long long* coarse_lab = nullptr;       // device [3][64]: labels changed per coarse scale and label in the round (the schedule rests labels)
+  unsigned long long* coarse_lab_host = nullptr;  //   ... its pinned host mirror
   char* coarse_arena = nullptr;             // ONE allocation behind the twelve child problems (labels, unary planes, weights, counters)
   int prop_tick = -1;                       // tick of the last proposal launch of this solve (-1: none)
   int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
@@ -194,6 +196,8 @@ struct phmrf_solve_state {
   int64_t last_changed = 0;            // labels changed by the previous round
   int64_t coarse_changed[3] = {0, 0, 0};  // ... by the coarse scales in their last run
   bool coarse_ran[3] = {false, false, false};
+  unsigned long long coarse_lab_mask[3] = {~0ull, ~0ull, ~0ull};   // the labels a coarse scale still runs (bit per label)
+  bool coarse_all[3] = {true, true, true};                         //   ... this round it ran all of them
   bool force_coarse = false;           // the tolerance wants to stop, but the coarse scales have not had their say
   bool coarse_checked = false;
   std::vector<char> active, ran;
@@ -262,7 +266,7 @@ int launch_coarsen(const phmrf_block* b, phmrf_block* child, int s, int off, int
 int launch_coarsen_batch(const phmrf_block* b, phmrf_block* const* children, const int* alphas, int nl, int s, int off, float beta,
                          const unsigned int* rebuild, int since, bool reset);
 int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, int off, int alpha, const unsigned long long* gate = nullptr,
-                        unsigned int* moved_flag = nullptr);
+                        unsigned int* moved_flag = nullptr, unsigned long long* changed_label = nullptr);
 int launch_c2f_graph(const phmrf_block* b, phmrf_block* child, int Hc, int Wc, int s);     // c2f.hip
 int launch_c2f_logprob(const phmrf_block* b, phmrf_block* child, int Wc, int s);
 int launch_c2f_prolong(const phmrf_block* b, const phmrf_block* child, int Wc, int s);

@@ -43,10 +43,11 @@ def label_image(rng, H, W, K, mean_run=25):
     return img
 
 
-def device_observations(torch, dev, seed, H, W, diagonal, K, means, covars, chunk=4 << 20):
-    """-> torch f32 [n, S] on `dev` for one block (upper triangle row-major when diagonal)."""
+def device_observations(torch, dev, seed, H, W, diagonal, K, means, covars, chunk=4 << 20, mean_run=25, noise=1.0):
+    """-> torch f32 [n, S] on `dev` for one block (upper triangle row-major when diagonal).  mean_run: mean side of the
+    ground truth's rectangles (bins); noise: factor on the states' standard deviations (1: as sampled)."""
     rng = np.random.default_rng(seed)
-    img = label_image(rng, H, W, K)
+    img = label_image(rng, H, W, K, mean_run)
     if diagonal:
         ii, jj = np.triu_indices(H)
         lab = img[ii, jj]
@@ -64,6 +65,6 @@ def device_observations(torch, dev, seed, H, W, diagonal, K, means, covars, chun
         e = min(n, s + chunk)
         l = torch.from_numpy(lab[s:e]).to(dev)
         z = torch.randn((e - s, S), generator=gen, device=dev, dtype=torch.float32)
-        x = mu[l] + torch.einsum("nij,nj->ni", L[l], z)
+        x = mu[l] + float(noise) * torch.einsum("nij,nj->ni", L[l], z)
         out[s:e] = torch.clamp_min(x, 0.0)
     return out
