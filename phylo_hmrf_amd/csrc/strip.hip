@@ -889,9 +889,18 @@ __device__ __forceinline__ void peel_drop(float (&cap)[SH], const float (&v8)[SH
   }
 }
 
+#ifdef PHMRF_FILTER_STATS
+// development: per-wave tallies of the filter (scalar): passes run, rows of a pass that lost a cell
+#define PHMRF_FS_PARAMS , unsigned int& fs_drops_, unsigned int& fs_passes_
+#define PHMRF_FS_ARGS , fs_drops_, fs_passes_
+#else
+#define PHMRF_FS_PARAMS
+#define PHMRF_FS_ARGS
+#endif
 template <int R>
 __device__ __forceinline__ void peel_row(const float (&sc)[SH], const float (&v8)[SH][8], float (&cap)[SH],
-                                         unsigned long long (&U)[SH], unsigned long long& seeds, unsigned long long& gone) {
+                                         unsigned long long (&U)[SH], unsigned long long& seeds, unsigned long long& gone
+                                         PHMRF_FS_PARAMS) {
   // (a hair of slack for the f32 sums: the caps are carried by subtraction, so the slack has an absolute part that covers
   //  eight roundings at the largest cap a strip can have)
   const float capx = __builtin_fmaf(cap[R], 1.0001f, 2e-5f);
@@ -901,19 +910,25 @@ __device__ __forceinline__ void peel_row(const float (&sc)[SH], const float (&v8
   U[R] &= keep;
   seeds |= U[R] & sd;
   gone |= del;
+#ifdef PHMRF_FILTER_STATS
+  if (del) ++fs_drops_;
+#endif
   peel_drop<R>(cap, v8, del);
 }
 
 // -> true: no seed is left (no improving switching set exists on this strip); false: the DP has to decide, on U
 __device__ __forceinline__ bool peel_strip(const float (&sc)[SH], const float (&v8)[SH][8], float (&cap)[SH],
-                                           unsigned long long (&U)[SH], int peel_max) {
+                                           unsigned long long (&U)[SH], int peel_max PHMRF_FS_PARAMS) {
   for (int it = 0; it < peel_max; ++it) {
     unsigned long long seeds = 0ull, gone = 0ull;
-    peel_row<0>(sc, v8, cap, U, seeds, gone);
-    peel_row<4>(sc, v8, cap, U, seeds, gone);
-    peel_row<1>(sc, v8, cap, U, seeds, gone);
-    peel_row<3>(sc, v8, cap, U, seeds, gone);
-    peel_row<2>(sc, v8, cap, U, seeds, gone);
+#ifdef PHMRF_FILTER_STATS
+    ++fs_passes_;
+#endif
+    peel_row<0>(sc, v8, cap, U, seeds, gone PHMRF_FS_ARGS);
+    peel_row<4>(sc, v8, cap, U, seeds, gone PHMRF_FS_ARGS);
+    peel_row<1>(sc, v8, cap, U, seeds, gone PHMRF_FS_ARGS);
+    peel_row<3>(sc, v8, cap, U, seeds, gone PHMRF_FS_ARGS);
+    peel_row<2>(sc, v8, cap, U, seeds, gone PHMRF_FS_ARGS);
     if (!seeds) return true;
     if (!gone) break;
   }
@@ -1029,7 +1044,9 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
       t_lo = pl * 64 + (rl / CH) * CH;
     }
 #ifndef PHMRF_PHASE_CLOCK
+    #ifndef PHMRF_FILTER_STATS
     if (lane == 0) atomicAdd(&wk[3], (unsigned int)(t_end - t_lo + 1));
+#endif
 #endif
 #ifdef PHMRF_DP_COUNT
     if (lane == 0) {                     // development build: solver-trace counters (PHMRF_SOLVE_TRACE)
@@ -1334,6 +1351,11 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
     //  label put a store round trip into every label's s_waitcnt vmcnt(0), next to the prefetched unary terms)
     unsigned long long quiet_mask = 0ull;
     unsigned int n_pairs = 0u;
+#ifdef PHMRF_FILTER_STATS
+    // development: work slots 1 passes, 2 rows of a pass that lost a cell, 3 pairs whose label occurs in the rectangle,
+    // 4 flagged pairs, 5 rows with a cell of the label (the caps' initial drops); slot 0 stays the pairs
+    unsigned int fs_drops_ = 0u, fs_passes_ = 0u, fs_present = 0u, fs_flagged = 0u, fs_init = 0u;
+#endif
     while (todo && nbuf < NBUF) {
       const int alpha = alpha_cur;
       todo &= todo - 1ull;
@@ -1368,6 +1390,12 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
       float cap[SH];
 #pragma unroll
       for (int r = 0; r < SH; ++r) cap[r] = capf[r];
+#ifdef PHMRF_FILTER_STATS
+      if (present) {
+        ++fs_present;
+        for (int r = 0; r < SH; ++r) fs_init += (valid[r] & ~U[r]) ? 1u : 0u;
+      }
+#endif
       if (present) {
         peel_drop<0>(cap, v8, valid[0] & ~U[0]);
         peel_drop<1>(cap, v8, valid[1] & ~U[1]);
@@ -1375,7 +1403,7 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
         peel_drop<3>(cap, v8, valid[3] & ~U[3]);
         peel_drop<4>(cap, v8, valid[4] & ~U[4]);
       }
-      const bool quiet = peel_strip(sc, v8, cap, U, peel_max);
+      const bool quiet = peel_strip(sc, v8, cap, U, peel_max PHMRF_FS_ARGS);
       FPH(2)
       if (quiet) {
         quiet_mask |= 1ull << alpha;
@@ -1386,6 +1414,9 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
         for (int r = 0; r < SH; ++r) ubuf[nbuf][r] = U[r];
         abuf[nbuf] = alpha;
       }
+#ifdef PHMRF_FILTER_STATS
+      ++fs_flagged;
+#endif
       ++nbuf;
     }
 #if defined(PHMRF_PHASE_CLOCK) && !defined(PHMRF_PHASE_DP)
@@ -1401,7 +1432,13 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
     if (lane == 0) {
       *nbuf_out = nbuf;
       atomicAdd(&wk[0], n_pairs);
-#ifndef PHMRF_PHASE_CLOCK
+#ifdef PHMRF_FILTER_STATS
+      atomicAdd(&wk[1], fs_passes_);
+      atomicAdd(&wk[2], fs_drops_);
+      atomicAdd(&wk[3], fs_present);
+      atomicAdd(&wk[4], fs_flagged);
+      atomicAdd(&wk[5], fs_init);
+#elif !defined(PHMRF_PHASE_CLOCK)
       atomicAdd(&wk[5], n_pairs * (unsigned int)ncell);
 #endif
     }
@@ -1554,7 +1591,7 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-#ifndef PHMRF_PHASE_CLOCK
+#if !defined(PHMRF_PHASE_CLOCK) && !defined(PHMRF_FILTER_STATS)
           atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
           atomicAdd(&wk[4], (unsigned int)ncell);
 #endif
@@ -1750,9 +1787,11 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
       __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) {
+#ifndef PHMRF_FILTER_STATS
       atomicAdd(&wk[0], 1u);
       atomicAdd(&wk[1], (unsigned int)ncell);                  // nodes this unit re-decides
       atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));     // the staged rectangle
+#endif
     }
 
     // ---- extraction, lane <-> column: single-site costs, clipped pair discounts, the cells that have a proposal
@@ -1808,7 +1847,10 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
       }
     }
     // (cap holds the discounts of all in-strip neighbours that have a proposal = exactly the neighbours in the first U)
-    const bool quiet = !(U[0] | U[1] | U[2] | U[3] | U[4]) || peel_strip(sc, v8, cap, U, peel_max);
+#ifdef PHMRF_FILTER_STATS
+    unsigned int fs_drops_ = 0u, fs_passes_ = 0u;
+#endif
+    const bool quiet = !(U[0] | U[1] | U[2] | U[3] | U[4]) || peel_strip(sc, v8, cap, U, peel_max PHMRF_FS_ARGS);
     if (quiet) {
       if (mslot && lane == 0) *mslot = (uint16_t)tick;
       continue;
