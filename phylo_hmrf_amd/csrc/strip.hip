@@ -1445,6 +1445,46 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
     return todo;
 }
 
+// Which strip a workgroup of strip_cols_kernel takes.  Orientation 0: the workgroups' order is the strips' order (a strip's
+// rows are contiguous in memory, neighbouring strips share nothing but a segment's end).  Orientation 1: a lane's five cells
+// are 20 consecutive bytes of ONE grid row, a wave's load of a label's terms touches 63 lines of 128 bytes, and the strips of
+// the bands next door (same segment: the next six grid columns) read the SAME lines -- 5.3 bands to a line.  Workgroups are
+// dealt round-robin to the 8 XCDs, each with an L2 of its own (MI355X_MICROARCH.md, workgroup dispatch: blocks b and b + 8
+// share an XCD; speed only, never correctness): in the strips' own order the bands that share lines are nsegs workgroups apart
+// and land in different L2s, and every line came from HBM once per band (PMC, round 4: 293 MB fetched per launch against
+// 109 MB in orientation 0).  So: groups of six adjacent bands are dealt to the XCD labels round-robin (an upper-triangular
+// block's work grows with the band, neighbouring groups weigh the same), and within a label the workgroups run segment by
+// segment through a group's six bands -- six consecutive workgroups of one XCD read one set of lines.  A bijection onto the
+// strips plus padding workgroups that return at once; the strips of a launch are independent, so the labelling does not
+// depend on the order.
+#ifndef PHMRF_XCD_GROUP_BANDS
+#define PHMRF_XCD_GROUP_BANDS 6
+#endif
+constexpr int XCD_GROUP_BANDS = PHMRF_XCD_GROUP_BANDS;
+__host__ __device__ inline int strip_slots(int orient, int nbands, int nsegs) {
+#ifdef PHMRF_NO_XCD_MAP
+  return nbands * nsegs;
+#else
+  if (!orient) return nbands * nsegs;
+  const int ngroups = (nbands + XCD_GROUP_BANDS - 1) / XCD_GROUP_BANDS;
+  return ((ngroups + 7) / 8) * 8 * XCD_GROUP_BANDS * nsegs;
+#endif
+}
+template <int ORIENT>
+__device__ __forceinline__ int strip_of_slot(const StripGeom& g, int q) {
+#ifndef PHMRF_NO_XCD_MAP
+  if (ORIENT == 1) {
+    const int per = XCD_GROUP_BANDS * g.nsegs;
+    const int x = q & 7, j = q >> 3;
+    const int gidx = j / per, rem = j - gidx * per;
+    const int seg = rem / XCD_GROUP_BANDS, bi = rem - seg * XCD_GROUP_BANDS;
+    const int bnd = (gidx * 8 + x) * XCD_GROUP_BANDS + bi;
+    return bnd < g.nbands ? bnd * g.nsegs + seg : -1;
+  }
+#endif
+  return q;
+}
+
 #ifndef PHMRF_COLS_WPE
 #define PHMRF_COLS_WPE 4
 #endif
@@ -1484,8 +1524,10 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 #define PH(K_)
 #endif
 
-  for (int strip_v = blockIdx.x; strip_v < nstrips; strip_v += gridDim.x) {
-    const int strip = __builtin_amdgcn_readfirstlane(strip_v);
+  const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs);
+  for (int slot_v = blockIdx.x; slot_v < nslots; slot_v += gridDim.x) {
+    const int strip = strip_of_slot<ORIENT>(g, __builtin_amdgcn_readfirstlane(slot_v));
+    if (strip < 0 || strip >= nstrips) continue;
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
     const int rs0 = bnd * (SH + 1) - g.shift_r;
@@ -1687,8 +1729,10 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
   if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
   __syncthreads();
 
-  for (int strip_v = blockIdx.x; strip_v < nstrips; strip_v += gridDim.x) {
-    const int strip = __builtin_amdgcn_readfirstlane(strip_v);
+  const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs);      // (the XCD-aware order of orientation 1: strip_of_slot)
+  for (int slot_v = blockIdx.x; slot_v < nslots; slot_v += gridDim.x) {
+    const int strip = strip_of_slot<ORIENT>(g, __builtin_amdgcn_readfirstlane(slot_v));
+    if (strip < 0 || strip >= nstrips) continue;
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
     const int rs0 = bnd * (SH + 1) - g.shift_r;
@@ -2113,8 +2157,10 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   // the fusion pass of a solve (proposals in labels_tmp) runs behind the exact filter (fusion_cols_kernel); the
   // single-label passes of the API and the coarse child problems keep strip_kernel.
   if (alpha < 0) {
+    int fgrid = strip_slots(orient, g.nbands, g.nsegs);
+    if (fgrid > (1 << 22)) fgrid = 1 << 22;
 #define PHMRF_LAUNCH_FUSION(O_)                                                                                       \
-  hipLaunchKernelGGL((fusion_cols_kernel<O_>), dim3(grid), dim3(64), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,  \
+  hipLaunchKernelGGL((fusion_cols_kernel<O_>), dim3(fgrid), dim3(64), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,  \
                      b->uT, b->labels, b->labels_tmp, b->sgain, beta, b->counters + b->counter_slot,                   \
                      b->tick ? b->stamp : nullptr,                                                                    \
                      use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr, b->tick, \
@@ -2157,9 +2203,10 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
   if (nstrips <= 0 || !label_mask) return PHMRF_OK;
   if (!b->fwd_w || !b->uT || !b->uT_valid) return fail(PHMRF_ERR_STATE, "strip moves need the grid tables (fwd_w, unary planes)");
   const int TB = 64;
-  int grid = nstrips;
-  // one workgroup per strip up to 4 M strips: the dispatcher hands a free slot the next strip, which balances the
-  // uneven strips better than waves striding over them (measured against a cap of 8 resident sets: -3 % on the rows cut)
+  // one workgroup per strip (orientation 1: per slot of the XCD-aware order, strip_of_slot) up to 4 M: the dispatcher hands a
+  // free slot the next strip, which balances the uneven strips better than waves striding over them (measured against a cap
+  // of 8 resident sets: -3 % on the rows cut)
+  int grid = strip_slots(orient, g.nbands, g.nsegs);
   if (grid > (1 << 22)) grid = 1 << 22;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
 #define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
