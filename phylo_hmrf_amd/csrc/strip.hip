@@ -29,6 +29,7 @@ constexpr float BIG = 1.0e30f;
 
 struct StripGeom {
   int H, W, diagonal, orient, shift_r, shift_c, Hs, Ws, nbands, nsegs;
+  int xcd;      // 1: orientation 1's strips in the XCD-aware order (strip_of_slot); 0: in their own order (development A/B)
 };
 
 __device__ __forceinline__ int strip_node(const StripGeom& g, int sr, int sc) {
@@ -1472,19 +1473,14 @@ __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsi
 #define PHMRF_XCD_GROUP_BANDS 6
 #endif
 constexpr int XCD_GROUP_BANDS = PHMRF_XCD_GROUP_BANDS;
-__host__ __device__ inline int strip_slots(int orient, int nbands, int nsegs) {
-#ifdef PHMRF_NO_XCD_MAP
-  return nbands * nsegs;
-#else
-  if (!orient) return nbands * nsegs;
+__host__ __device__ inline int strip_slots(int orient, int nbands, int nsegs, int xcd) {
+  if (!orient || !xcd) return nbands * nsegs;
   const int ngroups = (nbands + XCD_GROUP_BANDS - 1) / XCD_GROUP_BANDS;
   return ((ngroups + 7) / 8) * 8 * XCD_GROUP_BANDS * nsegs;
-#endif
 }
 template <int ORIENT>
 __device__ __forceinline__ int strip_of_slot(const StripGeom& g, int q) {
-#ifndef PHMRF_NO_XCD_MAP
-  if (ORIENT == 1) {
+  if (ORIENT == 1 && g.xcd) {
     const int per = XCD_GROUP_BANDS * g.nsegs;
     const int x = q & 7, j = q >> 3;
     const int gidx = j / per, rem = j - gidx * per;
@@ -1492,7 +1488,6 @@ __device__ __forceinline__ int strip_of_slot(const StripGeom& g, int q) {
     const int bnd = (gidx * 8 + x) * XCD_GROUP_BANDS + bi;
     return bnd < g.nbands ? bnd * g.nsegs + seg : -1;
   }
-#endif
   return q;
 }
 
@@ -1535,7 +1530,7 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 #define PH(K_)
 #endif
 
-  const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs);
+  const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs, g.xcd);
   for (int slot_v = blockIdx.x; slot_v < nslots; slot_v += gridDim.x) {
     const int strip = strip_of_slot<ORIENT>(g, __builtin_amdgcn_readfirstlane(slot_v));
     if (strip < 0 || strip >= nstrips) continue;
@@ -1740,7 +1735,7 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
   if (threadIdx.x < WORK_SLOTS) wk[threadIdx.x] = 0u;
   __syncthreads();
 
-  const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs);      // (the XCD-aware order of orientation 1: strip_of_slot)
+  const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs, g.xcd);      // (the XCD-aware order of orientation 1: strip_of_slot)
   for (int slot_v = blockIdx.x; slot_v < nslots; slot_v += gridDim.x) {
     const int strip = strip_of_slot<ORIENT>(g, __builtin_amdgcn_readfirstlane(slot_v));
     if (strip < 0 || strip >= nstrips) continue;
@@ -2134,6 +2129,8 @@ static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int sh
   g.Ws = orient ? b->H : b->W;
   g.nbands = (g.Hs + shift_r + SH) / (SH + 1);
   g.nsegs = (g.Ws + shift_c + 63) / 64;
+  static const bool plain_order = PHMRF_DEV_ENV("PHMRF_NO_XCD_MAP") != nullptr;      // development: A/B of the strips' order
+  g.xcd = plain_order ? 0 : 1;
   return g;
 }
 
@@ -2168,7 +2165,7 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   // the fusion pass of a solve (proposals in labels_tmp) runs behind the exact filter (fusion_cols_kernel); the
   // single-label passes of the API and the coarse child problems keep strip_kernel.
   if (alpha < 0) {
-    int fgrid = strip_slots(orient, g.nbands, g.nsegs);
+    int fgrid = strip_slots(orient, g.nbands, g.nsegs, g.xcd);
     if (fgrid > (1 << 22)) fgrid = 1 << 22;
 #define PHMRF_LAUNCH_FUSION(O_)                                                                                       \
   hipLaunchKernelGGL((fusion_cols_kernel<O_>), dim3(fgrid), dim3(64), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,  \
@@ -2217,7 +2214,7 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
   // one workgroup per strip (orientation 1: per slot of the XCD-aware order, strip_of_slot) up to 4 M: the dispatcher hands a
   // free slot the next strip, which balances the uneven strips better than waves striding over them (measured against a cap
   // of 8 resident sets: -3 % on the rows cut)
-  int grid = strip_slots(orient, g.nbands, g.nsegs);
+  int grid = strip_slots(orient, g.nbands, g.nsegs, g.xcd);
   if (grid > (1 << 22)) grid = 1 << 22;
   const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
 #define PHMRF_LAUNCH_MULTI(O_)                                                                                        \

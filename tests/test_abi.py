@@ -52,7 +52,7 @@ def test_product_path_fails_loudly_without_a_gpu():
 
 DEV_KNOBS = ("PHMRF_PEEL_SWEEPS", "PHMRF_STRIP_DEBUG", "PHMRF_CHAIN_DEBUG", "PHMRF_COARSE_NO_GATE", "PHMRF_COARSE_NO_STAMP_GATE",
              "PHMRF_COARSE_BATCH", "PHMRF_NO_PIN_LOOK", "PHMRF_ENERGY_FULL", "PHMRF_ENERGY_CHECK", "PHMRF_CC_ROWS", "PHMRF_POST_TB",
-             "PHMRF_POST_GRID", "PHMRF_CHILD_COUNT", "PHMRF_MULTI_V", "PHMRF_FUSION_V")
+             "PHMRF_POST_GRID", "PHMRF_CHILD_COUNT", "PHMRF_MULTI_V", "PHMRF_FUSION_V", "PHMRF_NO_XCD_MAP")
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="libphmrf.so not built")
@@ -69,7 +69,7 @@ def test_product_library_has_no_development_knobs():
     dev = os.path.join(ROOT, "phylo_hmrf_amd", "libphmrf_dev.so")
     if os.path.exists(dev):
         dblob = open(dev, "rb").read()
-        for k in ("PHMRF_PEEL_SWEEPS", "PHMRF_COARSE_BATCH", "PHMRF_NO_PIN_LOOK", "PHMRF_COARSE_NO_STAMP_GATE"):
+        for k in ("PHMRF_PEEL_SWEEPS", "PHMRF_COARSE_BATCH", "PHMRF_NO_PIN_LOOK", "PHMRF_COARSE_NO_STAMP_GATE", "PHMRF_NO_XCD_MAP"):
             assert k.encode() in dblob, k
         L = ctypes.CDLL(dev)
         missing = [s for s in declared_symbols() if not hasattr(L, s)]

@@ -857,6 +857,30 @@ def test_coarse_shortcuts_leave_the_labellings_alone():
     assert runs[0][1] >= 3
 
 
+def test_xcd_aware_order_of_the_strips_leaves_the_labellings_alone():
+    """Round 5: in orientation 1 the workgroups of strip_cols_kernel / fusion_cols_kernel take the strips in an XCD-aware
+    order (groups of six adjacent bands dealt round-robin to the eight XCD labels, strip_of_slot in strip.hip) instead of the
+    strips' own -- a bijection onto the strips plus padding workgroups, and the strips of a launch are independent, so the
+    labelling cannot depend on it.  PHMRF_NO_XCD_MAP=1 (development library) runs them in their own order: with
+    PHMRF_DETERMINISTIC=1 the cold-start script (700 x 700 upper triangle: 117 bands = 20 groups, three rounds of the eight
+    labels with four padding groups) gives the same label hash, round count and energy either way, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "phylo_hmrf_amd", "libphmrf_dev.so")
+    assert os.path.exists(dev), "libphmrf_dev.so not built (make -C phylo_hmrf_amd/csrc)"
+    runs = []
+    for extra in ({}, {"PHMRF_LIB": dev}, {"PHMRF_NO_XCD_MAP": "1", "PHMRF_LIB": dev}):
+        env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", **extra)
+        out = subprocess.run([sys.executable, "-c", DET_SCRIPT.replace("range(3)", "range(1)")], capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        runs.append(eval(line[len("RESULT"):])[0])
+    assert runs[0] == runs[1] == runs[2], runs
+    assert runs[0][1] >= 3
+
+
 @pytest.mark.parametrize("H,W,diagonal", [(520, 610, False), (800, 800, True)])
 def test_energy_of_later_rounds_from_the_touched_nodes_equals_the_full_pass(H, W, diagonal):
     """From its second round on a solve of a large grid block adds the CHANGE of the energy on the nodes the round's moves
