@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prepare", action="store_true",
+                    help="A/B: do not queue the next E-step's connected components behind the M-step (phmrf_block_prepare_components)")
     ap.add_argument("--block-threads", type=int, default=14,
                     help="host threads driving blocks concurrently, each block on its own HIP stream (1 = sequential)")
     ap.add_argument("--mstep-workers", type=int, default=0,
@@ -379,7 +381,11 @@ def main():
                 b.save_labels(SLOT_LOCAL)
         t1 = time.time()
         u0 = untimed[0]
+        # the labels-only part of the next E-step's component passes, queued behind the host's M-step (the GPU is idle then)
+        ahead = runner.start(lambda i: blocks[i].prepare_components(), order) if (blocks and not a.no_prepare) else None
         mstep_all(stats, rng)
+        if ahead is not None:
+            ahead.results()
         t2 = time.time()
         t_e.append(t1 - t0)
         t_m.append(t2 - t1 - (untimed[0] - u0))
@@ -720,7 +726,8 @@ def main():
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
             "value_estep_only": n_norm * a.steps / float(np.sum(t_e_timed)),
-            "setup_s": setup_s, "block_threads": runner.n_threads, "kernels": kernels, "kernels_from": kernels_from,
+            "setup_s": setup_s, "block_threads": runner.n_threads, "components_prepared_behind_mstep": bool(blocks and not a.no_prepare),
+            "kernels": kernels, "kernels_from": kernels_from,
             "kernels_steps": inst_steps or a.steps, "roofline": roofline,
             "roofline_limiter": roofline_limiter,
         }

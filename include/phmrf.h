@@ -48,9 +48,9 @@ typedef struct phmrf_block* phmrf_block_t;
 /* ---- library ---------------------------------------------------------------------------------- */
 /* ABI version = major * 100 + minor.  110 (round 4): PHMRF_NUM_KERNEL_CLASSES is 10 and phmrf_block_get_timing takes the
  * capacity of the caller's arrays; phmrf_block_get_work writes 8 values; the resumable solve (phmrf_mrf_solve_begin ...
- * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
+ * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  121: phmrf_block_prepare_components.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
  * (phylo_hmrf_amd/_lib.py does). */
-#define PHMRF_VERSION 120
+#define PHMRF_VERSION 121
 PHMRF_API int phmrf_version(void);
 PHMRF_API const char* phmrf_last_error(void);
 PHMRF_API const char* phmrf_status_string(int status);
@@ -236,6 +236,13 @@ PHMRF_API int phmrf_block_tile_put_halo(phmrf_block_t b, const uint8_t* top_in, 
 PHMRF_API int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed);
 PHMRF_API int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* changed);
 PHMRF_API int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed);
+/* Optional scheduling hint: queue, on the block's stream, the part of the next component pass that depends on the labels
+ * alone (the connected components of equal label).  The EM driver calls it between two E-steps, where the GPU would
+ * otherwise wait for the host's M-step (/root/reference/base.py:399: the reference's M-step follows its E-step the same
+ * way); the next solve's first component pass checks ON THE DEVICE that the labels are still the ones prepared for and
+ * recomputes otherwise, so results never depend on whether, or when, this was called.  No-op before the block has
+ * labels and a graph; PHMRF_ERR_STATE while a solve is in progress. */
+PHMRF_API int phmrf_block_prepare_components(phmrf_block_t b);
 /* One pass of exact strip fusion moves.  orient 0: strips of 5 grid rows, 1: of 5 grid columns; shift_r in [0,5],
  * shift_c in [0,63] move the fixed separator rows/columns; alpha >= 0: every node may keep its label or take
  * alpha (strip alpha-expansion); alpha < 0: every node may keep its label or take its best alternative label. */

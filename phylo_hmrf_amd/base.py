@@ -88,6 +88,11 @@ class _BaseGraph(object):
     def _do_mstep(self, stats):
         raise NotImplementedError
 
+    def _prepare_next_estep(self):
+        """hook: queue device work of the next E-step that does not depend on the M-step's result; -> None or an object with
+        .results() that waits for the queueing (not for the device)"""
+        return None
+
     def _estep_region(self, region_id):
         """-> (stats dict, cost numerators[4] summed over the region's nodes).  Labels stay on the device."""
         raise NotImplementedError
@@ -253,7 +258,10 @@ class _BaseGraph(object):
                 break
             self._log("Maximization...")
             start = time.time()
+            ahead = self._prepare_next_estep()       # (device work that needs the labels only, queued behind the host's M-step)
             self._do_mstep(stats)
+            if ahead is not None:
+                ahead.results()
             self.timing_["mstep"].append(time.time() - start)
             self._log("maximization use time %d %s" % (it, time.time() - start))
             if self.checkpoint_path and (it + 1) % max(int(self.checkpoint_every), 1) == 0:

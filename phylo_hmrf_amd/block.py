@@ -203,6 +203,12 @@ class Block(object):
         check(self._L.phmrf_mrf_chain_sweep(self._h, float(beta), int(family), ctypes.byref(c)))
         return c.value
 
+    def prepare_components(self):
+        """Queue the labels-only part of the next component pass (connected components of equal label) on the block's
+        stream -- between two E-steps, while the host runs the M-step.  A hint: the pass checks on the device that the labels
+        are still the ones prepared for, so results never depend on it."""
+        check(self._L.phmrf_block_prepare_components(self._h))
+
     def component_pass(self, beta):
         c = ctypes.c_int64(0)
         check(self._L.phmrf_mrf_component_pass(self._h, float(beta), ctypes.byref(c)))

@@ -400,6 +400,8 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->comp_best);
   dev_free(b->comp_gain);
   dev_free(b->comp_move);
+  dev_free(b->cc_seen);
+  dev_free(b->cc_stale);
   dev_free(b->stamp);
   dev_free(b->memo);
   dev_free(b->chain_memo);
@@ -1022,6 +1024,13 @@ int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* cha
   PHMRF_TRY(read_counter(b, &ch));
   if (changed) *changed = ch;
   return PHMRF_OK;
+}
+
+int phmrf_block_prepare_components(phmrf_block_t b) {
+  PHMRF_CHECK(b, PHMRF_ERR_INVALID, "block is NULL");
+  PHMRF_CHECK(!b->ss, PHMRF_ERR_STATE, "a solve is in progress");
+  if (!b->has_labels || !b->has_graph) return PHMRF_OK;        // (nothing to prepare yet: the pass will do its own)
+  return launch_component_prepare(b);
 }
 
 int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {

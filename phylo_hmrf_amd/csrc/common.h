@@ -102,6 +102,9 @@ struct phmrf_block {
   int32_t* comp_best = nullptr;             // device [n]
   float* comp_gain = nullptr;               // device [n]
   uint8_t* comp_move = nullptr;             // device [n]
+  uint8_t* cc_seen = nullptr;               // device [n]: the labels the prepared components were computed from
+  int* cc_stale = nullptr;                  // device: 1 once cc_compare_kernel found other labels than cc_seen
+  bool cc_prepared = false;                 // launch_component_prepare has run and no component pass has used it yet
   // grid-native inputs of the strip kernels
   float4* fwd_w = nullptr;                  // device [n]: weights of the four forward grid edges (E, SW, S, SE)
   float* uT = nullptr;                      // device [K][n]: unary planes, uT[k][i] = -logprob[i][k]
@@ -253,6 +256,7 @@ int launch_energy_delta(const phmrf_block* b);        // -> accum[..] += the cha
 int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors);
 int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase);
 int launch_component_pass(phmrf_block* b, float beta);
+int launch_component_prepare(phmrf_block* b);
 int launch_grid_graph(const phmrf_block* b, int H, int W, int diagonal, int nn, double beta1);
 int launch_propose(phmrf_block* b, float beta);  // best alternative label per node -> labels_tmp
 int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r, int shift_c, int alpha,

@@ -209,7 +209,9 @@ __device__ __forceinline__ void load_row(const int32_t* __restrict__ nbr, int64_
 // (nearest lane at or below mine that is not linked left); a run that continues from the previous chunk points at
 // i-1 from the chunk's first lane.  This resolves long runs in O(1) per node instead of O(run) finds.
 __global__ __launch_bounds__(256) void cc_init_kernel(int32_t* __restrict__ comp, int64_t n, int D,
-                                                      const int32_t* __restrict__ nbr, const uint8_t* __restrict__ labels) {
+                                                      const int32_t* __restrict__ nbr, const uint8_t* __restrict__ labels,
+                                                      const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;      // (this labelling is already in place: launch_component_prepare)
   const int lane = threadIdx.x & 63;
   for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = base + lane;
@@ -269,7 +271,8 @@ __device__ __forceinline__ void cc_hook(int32_t* comp, int& ri, int i, int c) {
 }
 
 __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, const int32_t* __restrict__ nbr,
-                                const uint8_t* __restrict__ labels, int grid) {
+                                const uint8_t* __restrict__ labels, int grid, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;      // (this labelling is already in place: launch_component_prepare)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int l = labels[i];
     if (D <= 8) {
@@ -342,7 +345,8 @@ __global__ void cc_union_kernel(int32_t* __restrict__ comp, int64_t n, int D, co
 // (one byte of label each, rows of the label image the wave shares) instead of a 32-byte adjacency row per node.  Same
 // hooks as above, hence the same forest up to the order of the atomics and the same roots (a root is the smallest id).
 __global__ __launch_bounds__(256) void cc_init_grid_kernel(int32_t* __restrict__ comp, int64_t n, int W, int diagonal,
-                                                           const uint8_t* __restrict__ labels) {
+                                                           const uint8_t* __restrict__ labels, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;      // (this labelling is already in place: launch_component_prepare)
   const int lane = threadIdx.x & 63;
   for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += (int64_t)gridDim.x * blockDim.x) {
     const int64_t v = base + lane;
@@ -360,7 +364,8 @@ __global__ __launch_bounds__(256) void cc_init_grid_kernel(int32_t* __restrict__
 }
 
 __global__ void cc_union_grid_kernel(int32_t* __restrict__ comp, int64_t n, int W, int diagonal,
-                                     const uint8_t* __restrict__ labels) {
+                                     const uint8_t* __restrict__ labels, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;      // (this labelling is already in place: launch_component_prepare)
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
     int i, j;
     grid_coords(v, W, diagonal, &i, &j);
@@ -393,7 +398,8 @@ __device__ __forceinline__ void tab_add(float* tab, long long* tab64, int64_t id
 }
 
 __global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n, float* __restrict__ tab, int K,
-                                  uint8_t* __restrict__ move, long long* __restrict__ tab64) {
+                                  uint8_t* __restrict__ move, long long* __restrict__ tab64, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;      // (this labelling is already in place: launch_component_prepare)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int c = comp[i];
     int p = comp[c];
@@ -413,6 +419,23 @@ __global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n, float* 
       }
     }
   }
+}
+
+// The labelling the prepared components were computed from against the labelling now: *stale = 1 where they differ (the
+// prepare step left it 0), and the gated kernels above run after all.  16 labels per thread and trip.
+__global__ __launch_bounds__(256) void cc_compare_kernel(const uint8_t* __restrict__ labels, const uint8_t* __restrict__ seen,
+                                                         int64_t n, int* __restrict__ stale) {
+  bool differ = false;
+  const int64_t n16 = n >> 4;
+  const uint4* a = reinterpret_cast<const uint4*>(labels);
+  const uint4* c = reinterpret_cast<const uint4*>(seen);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 x = a[q], y = c[q];
+    differ = differ || x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n16 << 4) + threadIdx.x; i < n; i += blockDim.x) differ = differ || labels[i] != seen[i];
+  if (__any(differ) && (threadIdx.x & 63) == 0) *stale = 1;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -732,27 +755,67 @@ int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour
   return PHMRF_OK;
 }
 
-int launch_component_pass(phmrf_block* b, float beta) {
+// The part of the component pass that depends on the labels alone -- the connected components of equal label, flattened,
+// with the root rows of the move table cleared -- queued ahead of the solve that will use it (phmrf_block_prepare_components:
+// between two E-steps the GPU waits for the host's M-step).  It keeps a copy of the labels it saw; the next component pass
+// compares them with the labels it finds (cc_compare_kernel, on the device) and runs the three kernels again only if they
+// differ -- the warm start may have installed another labelling, a tile may have received a halo row --, so the result is
+// that of the unprepared pass whatever happened in between.
+static int launch_cc(phmrf_block* b, const int* gate) {
   const int64_t n = b->n;
-  const int K = b->K, Kp = padded_k(K), D = b->D;
-  PHMRF_TRY(ensure(&b->comp, (size_t)n));
-  if (b->deterministic) PHMRF_TRY(ensure(&b->comp_tab64, (size_t)n * K));
-  else PHMRF_TRY(ensure(&b->comp_tab, (size_t)n * K));
+  const int K = b->K, D = b->D;
+  hipStream_t st = b->stream;
+  const int g = grid1d(n);
   long long* const tab64 = b->deterministic ? b->comp_tab64 : nullptr;
+  static const bool cc_rows = PHMRF_DEV_ENV("PHMRF_CC_ROWS") != nullptr;       // development: the adjacency-row form on grid blocks
+  if (b->has_grid && b->grid_complete && b->num_neighbor == 8 && D == 8 && !cc_rows) {
+    hipLaunchKernelGGL(cc_init_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels, gate);
+    hipLaunchKernelGGL(cc_union_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels, gate);
+  } else {
+    hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, gate);
+    hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0, gate);
+  }
+  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move, tab64, gate);
+  return PHMRF_OK;
+}
+
+static int ensure_component_buffers(phmrf_block* b) {
+  const int64_t n = b->n;
+  PHMRF_TRY(ensure(&b->comp, (size_t)n));
+  if (b->deterministic) PHMRF_TRY(ensure(&b->comp_tab64, (size_t)n * b->K));
+  else PHMRF_TRY(ensure(&b->comp_tab, (size_t)n * b->K));
   PHMRF_TRY(ensure(&b->comp_best, (size_t)n));
   PHMRF_TRY(ensure(&b->comp_gain, (size_t)n));
   PHMRF_TRY(ensure(&b->comp_move, (size_t)n));
+  return PHMRF_OK;
+}
+
+int launch_component_prepare(phmrf_block* b) {
+  PHMRF_TRY(ensure_component_buffers(b));
+  PHMRF_TRY(ensure(&b->cc_seen, (size_t)b->n + 16));
+  PHMRF_TRY(ensure(&b->cc_stale, (size_t)1));
+  PHMRF_TRY(launch_cc(b, nullptr));
+  PHMRF_HIP(hipMemcpyAsync(b->cc_seen, b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
+  PHMRF_HIP(hipMemsetAsync(b->cc_stale, 0, sizeof(int), b->stream));
+  PHMRF_HIP(hipGetLastError());
+  b->cc_prepared = true;
+  return PHMRF_OK;
+}
+
+int launch_component_pass(phmrf_block* b, float beta) {
+  const int64_t n = b->n;
+  const int K = b->K, Kp = padded_k(K), D = b->D;
+  PHMRF_TRY(ensure_component_buffers(b));
+  long long* const tab64 = b->deterministic ? b->comp_tab64 : nullptr;
   hipStream_t st = b->stream;
   const int g = grid1d(n);
-  static const bool cc_rows = PHMRF_DEV_ENV("PHMRF_CC_ROWS") != nullptr;       // development: the adjacency-row form on grid blocks
-  if (b->has_grid && b->grid_complete && b->num_neighbor == 8 && D == 8 && !cc_rows) {
-    hipLaunchKernelGGL(cc_init_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels);
-    hipLaunchKernelGGL(cc_union_grid_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->W, b->diagonal, b->labels);
+  if (b->cc_prepared) {            // (once: whatever this pass moves makes the prepared labelling history)
+    b->cc_prepared = false;
+    hipLaunchKernelGGL(cc_compare_kernel, dim3(grid1d(n, 256 * 16, 2048)), dim3(256), 0, st, b->labels, b->cc_seen, n, b->cc_stale);
+    PHMRF_TRY(launch_cc(b, b->cc_stale));
   } else {
-    hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels);
-    hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0);
+    PHMRF_TRY(launch_cc(b, nullptr));
   }
-  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move, tab64);
   const bool grid_tables = b->has_grid && b->num_neighbor == 8 && D == 8 && b->fwd_w && b->uT && b->uT_valid;
   if (grid_tables) {
     const int TB = tile_threads(K);

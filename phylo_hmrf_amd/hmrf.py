@@ -437,6 +437,20 @@ class phyloHMRF(_BaseGraph):
         stats, costs, _ = b.posterior_stats(self.beta, self.estimate_type)
         return stats, costs
 
+    def _prepare_next_estep(self):
+        """While the host fits the K states (the reference's M-step follows its E-step the same way, base.py:399) the GPU has
+        nothing to do: the connected components of every whole block's labelling -- the part of the next solve's component
+        pass that needs the labels only -- are queued on the blocks' streams now (phmrf_block_prepare_components; the pass
+        checks on the device that the labels are still these, so nothing depends on it but the time)."""
+        regions = [r for r in self.my_regions if r in self.blocks]
+        if not regions:
+            return None
+        def hint(r):
+            fn = getattr(self.blocks[r], "prepare_components", None)      # (a hint: test doubles of Block need not have it)
+            if fn is not None:
+                fn()
+        return self.runner.start(hint, regions)
+
     def _estep_tiles(self):
         """The E-step of every row tile this rank holds (lockstep rounds with the ranks that hold the other tiles of the same
         blocks; runs on the calling thread while the whole blocks run on the runner's threads).

@@ -857,6 +857,68 @@ def test_coarse_shortcuts_leave_the_labellings_alone():
     assert runs[0][1] >= 3
 
 
+PREP_SCRIPT = r"""
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, os.environ["PHMRF_ROOT"])
+import torch
+from phylo_hmrf_amd import Block, synthetic
+from phylo_hmrf_amd.tree import PhyloTree
+K, S, N = 12, 4, 500
+mode = os.environ["PREP_MODE"]
+tree = PhyloTree(synthetic.tree_for(S)); rng = np.random.default_rng(4)
+P = synthetic.sample_ou_params(rng, tree, K); mu, cv = tree.mean_cov(P); cv = cv + 1e-3 * np.eye(S)
+P2 = np.clip(P * (1 + 0.15 * rng.standard_normal(P.shape)), 1e-3, 50); mu2, cv2 = tree.mean_cov(P2); cv2 = cv2 + 1e-3 * np.eye(S)
+P3 = np.clip(P2 * (1 + 0.05 * rng.standard_normal(P.shape)), 1e-3, 50); mu3, cv3 = tree.mean_cov(P3); cv3 = cv3 + 1e-3 * np.eye(S)
+dev = torch.device("cuda", 0)
+X = synthetic.device_observations(torch, dev, 2, N, N, True, K, mu, cv); torch.cuda.synchronize()
+n = N * (N + 1) // 2
+b = Block(n, S, K); b.set_observations_dev(X.data_ptr()); b.sync(); b.build_grid_graph(N, N, True, 8, 0.5)
+b.emission(mu2, cv2)
+b.solve(1.0, energy_tol_ppb=1000, init_mode=1)
+b.save_labels(1)
+out = []
+# a warm E-step as the EM driver runs it, with the hint (a) not given, (b) given, (c) given and the labels changed behind it
+if mode in ("hint", "hint_then_other_labels"):
+    b.prepare_components()
+if mode == "hint_then_other_labels":
+    lab = b.get_labels().copy(); lab[: n // 3] = (lab[: n // 3] + 1) % K
+    b.set_labels(lab)
+if mode == "other_labels":
+    lab = b.get_labels().copy(); lab[: n // 3] = (lab[: n // 3] + 1) % K
+    b.set_labels(lab)
+b.emission(mu3, cv3)
+res = b.solve(1.0, energy_tol_ppb=1000)
+out.append((hashlib.sha1(b.get_labels().tobytes()).hexdigest(), res["rounds"], repr(res["energy"])))
+# ... and a second warm E-step after it (the hint is used once: this one computes its own components)
+b.emission(mu2, cv2)
+res = b.solve(1.0, energy_tol_ppb=1000)
+out.append((hashlib.sha1(b.get_labels().tobytes()).hexdigest(), res["rounds"], repr(res["energy"])))
+print("RESULT", out)
+"""
+
+
+def test_prepared_components_change_nothing_but_the_time():
+    """phmrf_block_prepare_components (ABI 121) queues the connected components of the block's labels ahead of the solve
+    that uses them (the EM driver: behind the host's M-step, /root/reference/base.py:399 is where the reference's M-step
+    sits).  The next component pass compares, on the device, the labels it finds with the labels prepared for and
+    recomputes when they differ.  With PHMRF_DETERMINISTIC=1: a warm E-step gives the same labels, rounds and energy with
+    and without the hint; with the labels replaced between the hint and the solve it gives what the same replacement
+    gives without the hint."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("plain", "hint", "other_labels", "hint_then_other_labels"):
+        env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", PREP_MODE=mode)
+        out = subprocess.run([sys.executable, "-c", PREP_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res[mode] = eval([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1][len("RESULT"):])
+    assert res["plain"] == res["hint"], res
+    assert res["other_labels"] == res["hint_then_other_labels"], res
+    assert res["plain"] != res["other_labels"]            # (the replacement is not a no-op)
+
+
 def test_xcd_aware_order_of_the_strips_leaves_the_labellings_alone():
     """Round 5: in orientation 1 the workgroups of strip_cols_kernel / fusion_cols_kernel take the strips in an XCD-aware
     order (groups of six adjacent bands dealt round-robin to the eight XCD labels, strip_of_slot in strip.hip) instead of the
