@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 export PHMRF_TRACE_PERT=0.05
 rm -rf $O/gaps_kt
-rocprofv3 --kernel-trace --output-format csv -d $O/gaps_kt -- python3 tools/trace.py 20 4980 1000 > $O/gaps_trace.out 2> $O/gaps_trace.err
+rocprofv3 --kernel-trace --output-format csv -d $O/gaps_kt -- python3 tools/trace.py 20 ${GAPS_N:-4980} 1000 > $O/gaps_trace.out 2> $O/gaps_trace.err
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/gaps_kt/**/*kernel_trace.csv", recursive=True)[0]
@@ -37,5 +37,7 @@ for r in seg:
     by[r["Kernel_Name"].split("(")[0][-40:]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 for k, v in by.most_common(12):
     print("  %-42s %.3f ms" % (k, v / 1e6))
+import re
+print("launch by launch (us):", [((re.search(r"(\w+_kernel|fillBuffer|copyBuffer)", r["Kernel_Name"]) or [None, "?"])[1][:14], round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)) for r in seg])
 PY
 rm -rf $O/gaps_kt
