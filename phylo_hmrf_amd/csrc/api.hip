@@ -399,7 +399,6 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->comp_tab64);
   dev_free(b->comp_best);
   dev_free(b->comp_gain);
-  dev_free(b->comp_move);
   dev_free(b->cc_seen);
   dev_free(b->cc_stale);
   dev_free(b->stamp);

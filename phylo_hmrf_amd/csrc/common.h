@@ -101,7 +101,6 @@ struct phmrf_block {
   bool deterministic = false;               // PHMRF_DETERMINISTIC=1 at block creation: order-independent reductions
   int32_t* comp_best = nullptr;             // device [n]
   float* comp_gain = nullptr;               // device [n]
-  uint8_t* comp_move = nullptr;             // device [n]
   uint8_t* cc_seen = nullptr;               // device [n]: the labels the prepared components were computed from
   int* cc_stale = nullptr;                  // device: 1 once cc_compare_kernel found other labels than cc_seen
   bool cc_prepared = false;                 // launch_component_prepare has run and no component pass has used it yet

@@ -398,7 +398,7 @@ __device__ __forceinline__ void tab_add(float* tab, long long* tab64, int64_t id
 }
 
 __global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n, float* __restrict__ tab, int K,
-                                  uint8_t* __restrict__ move, long long* __restrict__ tab64, const int* __restrict__ gate) {
+                                  long long* __restrict__ tab64, const int* __restrict__ gate) {
   if (gate && *gate == 0) return;      // (this labelling is already in place: launch_component_prepare)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int c = comp[i];
@@ -408,7 +408,6 @@ __global__ void cc_flatten_kernel(int32_t* __restrict__ comp, int64_t n, float* 
       p = comp[c];
     }
     comp[i] = c;
-    move[i] = 0;
     if (c == (int)i) {
       if (tab64) {
         long long* row = tab64 + i * K;
@@ -629,7 +628,9 @@ __global__ void comp_decide_kernel(const float* __restrict__ tab, int64_t n, int
 
 // a candidate component is blocked when an adjacent candidate has a better (more negative) gain; ties by root id
 __global__ void comp_block_kernel(int64_t n, int D, const int32_t* __restrict__ nbr, const int32_t* __restrict__ comp,
-                                  const float* __restrict__ gain, uint8_t* __restrict__ blocked) {
+                                  const float* __restrict__ gain, int32_t* __restrict__ best) {
+  // (a blocked component loses its decision: best[root] = -1 -- nothing here reads `best`, and comp_apply then needs the
+  //  root's decision alone, not a second flag behind the same root: one dependent read fewer per node)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int ci = comp[i];
     const float gi = gain[ci];
@@ -643,7 +644,7 @@ __global__ void comp_block_kernel(int64_t n, int D, const int32_t* __restrict__ 
       for (int j = 0; j < 8; ++j) {
         if (cj[j] == ci) continue;
         const float gj = gain[cj[j]];
-        if (gj < gi || (gj == gi && cj[j] < ci)) blocked[ci] = 1;
+        if (gj < gi || (gj == gi && cj[j] < ci)) best[ci] = -1;
       }
       continue;
     }
@@ -654,18 +655,18 @@ __global__ void comp_block_kernel(int64_t n, int D, const int32_t* __restrict__ 
       const int cj = comp[c];
       if (cj == ci) continue;
       const float gj = gain[cj];
-      if (gj < gi || (gj == gi && cj < ci)) blocked[ci] = 1;
+      if (gj < gi || (gj == gi && cj < ci)) best[ci] = -1;
     }
   }
 }
 
 __global__ void comp_apply_kernel(int64_t n, const int32_t* __restrict__ comp, const int32_t* __restrict__ best,
-                                  const uint8_t* __restrict__ blocked, uint8_t* __restrict__ labels,
+                                  uint8_t* __restrict__ labels,
                                   unsigned long long* __restrict__ changed, uint16_t* __restrict__ stamp, int tick,
                                   const int32_t* __restrict__ nbr, int D) {
   unsigned int mine = 0;
-  // four nodes per thread and trip, their three dependent reads (root, its decision, its block flag) side by side: the
-  // kernel is three memory round trips per node and nothing else
+  // four nodes per thread and trip, their two dependent reads (root, its decision -- comp_block has withdrawn the decisions of
+  // blocked components) side by side: the kernel is two memory round trips per node and nothing else
   constexpr int U = 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
@@ -676,7 +677,7 @@ __global__ void comp_apply_kernel(int64_t n, const int32_t* __restrict__ comp, c
 #pragma unroll
     for (int u = 0; u < U; ++u) bk[u] = ci[u] >= 0 ? best[ci[u]] : -1;
 #pragma unroll
-    for (int u = 0; u < U; ++u) go[u] = bk[u] >= 0 && !blocked[ci[u]];
+    for (int u = 0; u < U; ++u) go[u] = bk[u] >= 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!go[u]) continue;
@@ -775,7 +776,7 @@ static int launch_cc(phmrf_block* b, const int* gate) {
     hipLaunchKernelGGL(cc_init_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, gate);
     hipLaunchKernelGGL(cc_union_kernel, dim3(g), dim3(256), 0, st, b->comp, n, D, b->nbr, b->labels, b->has_grid ? b->num_neighbor : 0, gate);
   }
-  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, b->comp_move, tab64, gate);
+  hipLaunchKernelGGL(cc_flatten_kernel, dim3(g), dim3(256), 0, st, b->comp, n, b->comp_tab, K, tab64, gate);
   return PHMRF_OK;
 }
 
@@ -786,7 +787,6 @@ static int ensure_component_buffers(phmrf_block* b) {
   else PHMRF_TRY(ensure(&b->comp_tab, (size_t)n * b->K));
   PHMRF_TRY(ensure(&b->comp_best, (size_t)n));
   PHMRF_TRY(ensure(&b->comp_gain, (size_t)n));
-  PHMRF_TRY(ensure(&b->comp_move, (size_t)n));
   return PHMRF_OK;
 }
 
@@ -838,8 +838,8 @@ int launch_component_pass(phmrf_block* b, float beta) {
   }
   hipLaunchKernelGGL(comp_decide_kernel, dim3(g), dim3(256), 0, st, b->comp_tab, n, K, b->labels, b->comp, b->comp_best,
                      b->comp_gain, tab64);
-  hipLaunchKernelGGL(comp_block_kernel, dim3(g), dim3(256), 0, st, n, D, b->nbr, b->comp, b->comp_gain, b->comp_move);
-  hipLaunchKernelGGL(comp_apply_kernel, dim3(g), dim3(256), 0, st, n, b->comp, b->comp_best, b->comp_move, b->labels,
+  hipLaunchKernelGGL(comp_block_kernel, dim3(g), dim3(256), 0, st, n, D, b->nbr, b->comp, b->comp_gain, b->comp_best);
+  hipLaunchKernelGGL(comp_apply_kernel, dim3(g), dim3(256), 0, st, n, b->comp, b->comp_best, b->labels,
                      b->counters + b->counter_slot, b->tick ? b->stamp : nullptr, b->tick, b->nbr, D);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
