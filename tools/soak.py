@@ -20,6 +20,7 @@ for rep in range(6):
         P2 = np.clip(P2 * (1 + 0.01 * rng.standard_normal(P.shape)), 1e-3, 50); m2, c2 = tree.mean_cov(P2)
         b.restore_labels(0); b.emission(m2, c2 + 1e-3 * np.eye(S)); b.solve_fast(1.0, energy_tol_ppb=1000)
         st, costs, _ = b.posterior_stats(1.0, 3); b.save_labels(0)
+        if it % 2 == 0: b.prepare_components()          # (every other E-step with the components prepared ahead)
     b.close(); torch.cuda.synchronize()
     free, total = torch.cuda.mem_get_info()
     if free0 is None: free0 = free
