@@ -476,7 +476,7 @@ def main():
         """per kernel class [stream ms, launches, algorithmic bytes] and the device-counted work, over this rank's blocks
         (first: only the launches of the FIRST round of every solve -- a warm start's full sweeps)"""
         agg_, work_ = {}, dict(units=0, cells=0, staged_cells=0, dp_steps=0, launches=0, swept_cells=0, label_cells=0,
-                               proposal_nodes=0)
+                               proposal_nodes=0, mask_label_cells=0, mask_strip_cells=0)
         for b in unit_blocks:
             for name, (ms, ln) in (b.timing_first() if first else b.timing()).items():
                 d = agg_.setdefault(name, [0.0, 0, 0.0])

@@ -48,9 +48,9 @@ typedef struct phmrf_block* phmrf_block_t;
 /* ---- library ---------------------------------------------------------------------------------- */
 /* ABI version = major * 100 + minor.  110 (round 4): PHMRF_NUM_KERNEL_CLASSES is 10 and phmrf_block_get_timing takes the
  * capacity of the caller's arrays; phmrf_block_get_work writes 8 values; the resumable solve (phmrf_mrf_solve_begin ...
- * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  121: phmrf_block_prepare_components.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
+ * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  121: phmrf_block_prepare_components.  122 (round 6): phmrf_block_get_work_ex.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
  * (phylo_hmrf_amd/_lib.py does). */
-#define PHMRF_VERSION 121
+#define PHMRF_VERSION 122
 PHMRF_API int phmrf_version(void);
 PHMRF_API const char* phmrf_last_error(void);
 PHMRF_API const char* phmrf_status_string(int status);
@@ -331,6 +331,14 @@ PHMRF_API int phmrf_block_get_work(phmrf_block_t b, int64_t* out /*[8]*/);
  * round is the full sweep of both orientations, the later rounds revisit the strips whose inputs changed -- the two kinds of
  * launch a roofline figure has to keep apart (bench.py: roofline.full_sweep / roofline.mop_up). */
 PHMRF_API int phmrf_block_get_work_first(phmrf_block_t b, int64_t* out /*[8]*/);
+/* ABI 122 (round 6): the same ten-entry form of both (first_round_only != 0: the _first part); min(capacity, 10) entries.
+ * Entries 0..7 as above.  Inside a solve strip_scan_kernel looks at a strip's stamps, memo row and SEED MASKS before the
+ * expansion launch (the per-node masks propose_grid_kernel writes: bit a = an improving expansion of label a could start
+ * here); a (strip, label) pair without a seed is settled there, exactly as the filter's first pass would settle it, and is
+ * NOT in out[0] / out[6]:
+ *   out[8] cells x labels settled by the seed masks (no unary term read)
+ *   out[9] cells of the strips whose every listed label was settled that way (never staged: not in out[5])  */
+PHMRF_API int phmrf_block_get_work_ex(phmrf_block_t b, int first_round_only, int capacity, int64_t* out /*[capacity]*/);
 /* The timed intervals of one kernel class on a time base common to all blocks of the calling thread's device
  * (phmrf_time_base_reset marks t = 0; call it before the timed region): out = [start_ms, end_ms] pairs, at most
  * `capacity` of them; *count = how many there are.  Blocks run on their own streams, so their intervals overlap:

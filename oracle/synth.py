@@ -73,3 +73,33 @@ def make_block(seed, H, W, S, K, diagonal, num_neighbor=8, noise=1.0, params=Non
     edges = R.grid_edges(X, H, W, diagonal, num_neighbor)
     return dict(X=X, edges=edges, labels_true=lab.astype(np.int32), params=params, means=means,
                 covars=covars, H=H, W=W, diagonal=bool(diagonal), tree=tree_for(S), num_neighbor=num_neighbor)
+
+
+def make_knn_block(seed, n, S, K, k=6, noise=1.0, cells=12):
+    """A labelling problem on a graph that is NOT the contact-map stencil (round 6: the general-graph boundary of
+    pygco.cut_general_graph, phylo_hmrf.py:496-498): n points uniform in the unit square, each tied to its k nearest
+    neighbours (undirected, id1 < id2, sorted like utility.py:1955-1960); ground-truth states constant on the cells of a
+    cells x cells checkerboard of random states; x_i ~ N(mu_{l_i}, Sigma_{l_i}) clipped at 0; edge distance
+    d_ij = |x_i - x_j|^2 / (|x_i| |x_j| + 1e-16) as utility.py:1935-1939.  Returns the dict of make_block (H = W = 0)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    tt = R.TreeTables(tree_for(S))
+    params = sample_ou_params(rng, tt, K)
+    means, covars = R.ou_params_to_means_covars(tt, params)
+    covars = covars + 1e-3 * np.eye(S)
+    pts = rng.random((n, 2))
+    board = rng.integers(0, K, (cells, cells))
+    lab = board[np.minimum((pts[:, 0] * cells).astype(np.int64), cells - 1), np.minimum((pts[:, 1] * cells).astype(np.int64), cells - 1)]
+    Lc = np.linalg.cholesky(covars)
+    z = rng.standard_normal((n, S))
+    X = np.maximum(means[lab] + noise * np.einsum("nij,nj->ni", Lc[lab], z), 0.0)
+    _, idx = cKDTree(pts).query(pts, k=k + 1)
+    a = np.repeat(np.arange(n), k)
+    b = idx[:, 1:].reshape(-1)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    pair = np.unique(lo * np.int64(n) + hi)
+    id1, id2 = pair // n, pair % n
+    d = np.sum((X[id1] - X[id2]) ** 2, axis=1) / (np.linalg.norm(X[id1], axis=1) * np.linalg.norm(X[id2], axis=1) + 1e-16)
+    edges = np.stack([id1.astype(np.float64), id2.astype(np.float64), d], axis=1)
+    return dict(X=X, edges=edges, labels_true=lab.astype(np.int32), params=params, means=means, covars=covars, H=0, W=0,
+                diagonal=False, tree=tree_for(S), points=pts)

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PHMRF_LIB") or os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
-ABI_VERSION = 121             # include/phmrf.h PHMRF_VERSION: checked against the library in load()
+ABI_VERSION = 122             # include/phmrf.h PHMRF_VERSION: checked against the library in load()
 NUM_KERNEL_CLASSES = 10
 KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose", "coarse", "fusion")
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "phmrf_block_reset_timing": [_vp],
     "phmrf_block_get_work": [_vp, _lp],
     "phmrf_block_get_work_first": [_vp, _lp],
+    "phmrf_block_get_work_ex": [_vp, _i, _i, _lp],
     "phmrf_time_base_reset": [],
     "phmrf_block_get_intervals": [_vp, _i, _dp, _i64, _lp],
 }

@@ -317,19 +317,20 @@ class Block(object):
         check(self._L.phmrf_block_get_timing_first(self._h, _lib.NUM_KERNEL_CLASSES, ms, ln))
         return {name: (ms[i], ln[i]) for i, name in enumerate(_lib.KERNEL_CLASSES)}
 
+    _WORK_KEYS = ("units", "cells", "staged_cells", "dp_steps", "launches", "swept_cells", "label_cells", "proposal_nodes",
+                  "mask_label_cells", "mask_strip_cells")
+
     def work(self):
-        """Device-counted work of the strip kernels since reset_timing."""
-        out = (ctypes.c_int64 * 8)()
-        check(self._L.phmrf_block_get_work(self._h, out))
-        return dict(units=out[0], cells=out[1], staged_cells=out[2], dp_steps=out[3], launches=out[4], swept_cells=out[5],
-                    label_cells=out[6], proposal_nodes=out[7])
+        """Device-counted work of the strip kernels since reset_timing (include/phmrf.h: phmrf_block_get_work_ex)."""
+        out = (ctypes.c_int64 * 10)()
+        check(self._L.phmrf_block_get_work_ex(self._h, 0, 10, out))
+        return dict(zip(self._WORK_KEYS, out))
 
     def work_first(self):
         """The part of work() done in the first round of every solve (a warm start's full sweeps) since reset_timing."""
-        out = (ctypes.c_int64 * 8)()
-        check(self._L.phmrf_block_get_work_first(self._h, out))
-        return dict(units=out[0], cells=out[1], staged_cells=out[2], dp_steps=out[3], launches=out[4], swept_cells=out[5],
-                    label_cells=out[6], proposal_nodes=out[7])
+        out = (ctypes.c_int64 * 10)()
+        check(self._L.phmrf_block_get_work_ex(self._h, 1, 10, out))
+        return dict(zip(self._WORK_KEYS, out))
 
     def intervals(self, kernel_class):
         """[start_ms, end_ms] of every timed interval of the class, on the device's common time base -> array [m,2]."""

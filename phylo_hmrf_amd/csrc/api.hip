@@ -389,6 +389,8 @@ int phmrf_block_destroy(phmrf_block_t b) {
   if (b->coarse_lab_host) (void)hipHostFree(b->coarse_lab_host);
   b->coarse_lab_host = nullptr;
   dev_free(b->sgain);
+  dev_free(b->seed);
+  dev_free(b->scan_out);
   for (int s = 0; s < 4; ++s) dev_free(b->saved[s]);
   dev_free(b->nbr);
   dev_free(b->wgt);
@@ -811,7 +813,7 @@ static int work_fetch_async(phmrf_block_t b) {
   return PHMRF_OK;
 }
 static void work_fold(phmrf_block_t b, bool first_round = false) {
-  static const int SLOT_OF[WORK_SLOTS] = {0, 1, 2, 3, 5, 6, 7};   // work[4] = launches (host-counted)
+  static const int SLOT_OF[WORK_SLOTS] = {0, 1, 2, 3, 5, 6, 7, 8, 9};   // work[4] = launches (host-counted)
   for (int k = 0; k < WORK_BANKS; ++k)
     for (int q = 0; q < WORK_SLOTS; ++q) {
       const int64_t v = (int64_t)b->work_host[k * WORK_SLOTS + q];
@@ -1286,6 +1288,7 @@ void solve_scope_exit(phmrf_block* b) {
   b->eval_tick = -1;
   b->counter_slot = 0;
   b->prop_tick = -1;
+  b->seed_tick = -1;
   delete s;
   b->ss = nullptr;
 }
@@ -1420,6 +1423,7 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
   b->tick = 1;
   b->eval_tick = -1;                   // (no energy evaluation in this solve yet: the first one is a full pass)
   b->prop_tick = -1;
+  b->seed_tick = -1;
   if (s->chains) {                       // segment memos of all families: one buffer, one memset
     size_t total = 0;
     for (auto& f : b->families)
@@ -1452,6 +1456,13 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
       b->memo_strips = max_strips;
     }
     PHMRF_HIP(hipMemsetAsync(b->memo, 0, (size_t)6 * b->memo_strips * (K + 1) * sizeof(uint16_t), b->stream));
+    // the two words per strip slot that strip_scan_kernel leaves for the strip launch behind it
+    const int64_t slots = strip_scan_slots(b);
+    if (!b->scan_out || b->scan_slots < slots) {
+      dev_free(b->scan_out);
+      PHMRF_TRY(dev_alloc(&b->scan_out, (size_t)2 * slots));
+      b->scan_slots = slots;
+    }
   }
   // One round runs every ACTIVE move type: chain families, ICM, component moves, strip fusion per orientation, strip
   // alpha-expansion per label.  A type stays active while it still changes labels.  When a round is quiet (at most
@@ -1537,22 +1548,33 @@ int solve_round_launch(phmrf_block_t b) {
   if (s->strips) {
     const int geom = s->geom;
     for (int orient = 0; orient < 2; ++orient) {
+      unsigned long long lmask = 0ull;
+      if (s->expansions)
+        for (int a = 0; a < K; ++a)
+          if (active[8 + a]) lmask |= 1ull << a;
       if (active[78 + orient]) {
         b->counter_slot = 78 + orient;
         ran[78 + orient] = 1;
         // the fusion pass runs on a cut of its own that moves with the expansions' (so that its memo of quiet strips
         // applies while the cut stays): the expansion cut shifted by half a band / half a segment
         PHMRF_TRY(strip_pass_nocount(b, bf, orient, (GEOM_R[geom] + 3) % 6, (GEOM_C[geom] + 31) % 64, -1, geom));
+      } else if (lmask && b->seed && b->has_grid && b->fwd_w && b->D == 8) {
+        // (development builds with PHMRF_SEED_MASKS=1 only: b->seed is never allocated otherwise) the proposals' launch also
+        // writes the expansions' seed masks (propose_grid_kernel): with the fusion pass at rest it runs for them alone
+        if (!b->uT_valid) {
+          tic(b, KC_PROPOSE);
+          PHMRF_TRY(launch_unary_planes(b));
+          toc(b, KC_PROPOSE, 1);
+        }
+        tic(b, KC_PROPOSE);
+        PHMRF_TRY(launch_propose(b, bf));
+        toc(b, KC_PROPOSE, 1);
       }
       if (s->expansions) {
         // every active label's expansion of the cut in ONE launch: a wave owns a strip, stages it once and runs the
         // labels back to back behind the exact filter (strip_cols_kernel)
-        unsigned long long lmask = 0ull;
         for (int a = 0; a < K; ++a)
-          if (active[8 + a]) {
-            lmask |= 1ull << a;
-            ran[8 + a] = 1;
-          }
+          if (active[8 + a]) ran[8 + a] = 1;
         if (lmask) {
           if (!b->uT_valid) {
             tic(b, KC_PROPOSE);
@@ -2187,7 +2209,7 @@ int phmrf_block_reset_timing(phmrf_block_t b) {
     b->ms[i] = b->ms_first[i] = 0;
     b->launches[i] = b->launches_first[i] = 0;
   }
-  for (int q = 0; q < 8; ++q) b->work[q] = b->work_first[q] = 0;
+  for (int q = 0; q < 10; ++q) b->work[q] = b->work_first[q] = 0;
   PHMRF_HIP(hipMemsetAsync(b->work_acc, 0, WORK_BANKS * WORK_SLOTS * sizeof(unsigned long long), b->stream));
   b->intervals.clear();
   return PHMRF_OK;
@@ -2213,6 +2235,12 @@ int phmrf_block_get_work(phmrf_block_t b, int64_t* out) {
 int phmrf_block_get_work_first(phmrf_block_t b, int64_t* out) {
   PHMRF_CHECK(b && out, PHMRF_ERR_INVALID, "NULL argument");
   for (int q = 0; q < 8; ++q) out[q] = b->work_first[q];
+  return PHMRF_OK;
+}
+
+int phmrf_block_get_work_ex(phmrf_block_t b, int first_round_only, int capacity, int64_t* out) {
+  PHMRF_CHECK(b && out, PHMRF_ERR_INVALID, "NULL argument");
+  for (int q = 0; q < 10 && q < capacity; ++q) out[q] = first_round_only ? b->work_first[q] : b->work[q];
   return PHMRF_OK;
 }
 

@@ -75,6 +75,10 @@ struct phmrf_block {
   uint8_t* labels_eval = nullptr;           // device [n]: the labels at a solve's last energy evaluation (launch_energy_delta)
   int eval_tick = -1;                       //   ... and the launch tick then (-1: no evaluation in this solve yet)
   float* sgain = nullptr;                   // device [n]: cost of switching a node alone to its fusion proposal (launch_propose)
+  unsigned long long* seed = nullptr;       // device [n]: bit a = "an improving expansion of label a could start at this node" (a superset
+                                            //   of the strip filter's seed test, formed by propose_grid_kernel; strip_scan_kernel ORs it over a strip)
+  unsigned long long* scan_out = nullptr;   // device [scan_slots][2]: per strip slot of the launch that follows (todo before / after the seed masks)
+  int64_t scan_slots = 0;
   uint8_t* saved[4] = {nullptr, nullptr, nullptr, nullptr};
   int labels_are_slot = 0;                  // bit k: the current labels equal snapshot k (set by save / restore; 0 after anything that may write labels)
   bool has_X = false, has_logprob = false, has_labels = false, has_graph = false, has_grid = false;
@@ -120,6 +124,7 @@ struct phmrf_block {
   unsigned long long* coarse_lab_host = nullptr;  //   ... its pinned host mirror
   char* coarse_arena = nullptr;             // ONE allocation behind the twelve child problems (labels, unary planes, weights, counters)
   int prop_tick = -1;                       // tick of the last proposal launch of this solve (-1: none)
+  int seed_tick = -1;                       // ... of the last one that also wrote the seed masks: seed[i] is current while stamp[i] <= seed_tick
   int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
   // change stamps: stamp[i] = tick of the launch that last changed the label of node i OR OF ONE OF ITS NEIGHBOURS
   // (0 = not since the solve began);
@@ -154,8 +159,8 @@ struct phmrf_block {
   int64_t launches[PHMRF_NUM_KERNEL_CLASSES] = {};
   double ms_first[PHMRF_NUM_KERNEL_CLASSES] = {};           // ... of the launches in the first round of a solve
   int64_t launches_first[PHMRF_NUM_KERNEL_CLASSES] = {};
-  int64_t work_first[8] = {};               //   ... the part of it done in the first round of each solve
-  int64_t work[8] = {};                     // strips staged, their cells, staged cells, DP steps, strip launches (since reset_timing)
+  int64_t work_first[10] = {};              //   ... the part of it done in the first round of each solve
+  int64_t work[10] = {};                    // strips staged, their cells, staged cells, DP steps, strip launches, ... (phmrf_block_get_work_ex)
   struct Interval { int kclass; float t0, t1; };
   std::vector<Interval> intervals;          // resolved timed intervals on the library's common time base (ms)
 
@@ -229,7 +234,7 @@ namespace phmrf {
 #endif
 constexpr int C2F_SCALE = 4;          // super-cells of the coarse-to-fine start (c2f.hip)
 constexpr int UT_PAD = 64;            // floats of slack before and after the unary planes (strip.hip: launch_unary_planes)
-constexpr int WORK_SLOTS = 7;         // see phmrf_block_get_work
+constexpr int WORK_SLOTS = 9;         // see phmrf_block_get_work / _ex (slots 7, 8: what the seed masks settled)
 constexpr int WORK_BANKS = 256;       // work_acc[WORK_BANKS][WORK_SLOTS]: strips staged, their cells, staged cells (with rim), DP
                                       // steps of the strip kernels, one bank per workgroup id mod 256 (no hot address)
 constexpr int ACCUM_DOUBLES = 8192;  // >= K*(1+S+S*S)+16 for every (K,S) the posterior / statistics kernel supports
@@ -274,6 +279,7 @@ int launch_c2f_graph(const phmrf_block* b, phmrf_block* child, int Hc, int Wc, i
 int launch_c2f_logprob(const phmrf_block* b, phmrf_block* child, int Wc, int s);
 int launch_c2f_prolong(const phmrf_block* b, const phmrf_block* child, int Wc, int s);
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
+int64_t strip_scan_slots(const phmrf_block* b);                                     // capacity of scan_out (strip_scan_kernel)
 // row tiles (tile.hip)
 constexpr float PIN_COST = 1.0e9f;      // unary term of every label but its own at a pinned node (<< f32 max: sums of a strip's
                                         // or a component's terms stay finite; >> any real term: no move takes it)

@@ -1491,6 +1491,117 @@ __device__ __forceinline__ int strip_of_slot(const StripGeom& g, int q) {
   return q;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// strip_scan_kernel (round 6): what every strip of the launch that follows has to do, decided BEFORE that launch by a light
+// kernel (no LDS slab, ~30 VGPRs, four strips per workgroup) instead of in the prologue of its 127-VGPR, 10 KB-LDS waves:
+//   * the memo test: the strip's newest change stamp against the ticks of its labels' last quiet runs (as before);
+//   * the SEED MASKS (expansions only): the OR over the strip's cells of the per-node masks propose_grid_kernel wrote.  A
+//     label none of whose bits is set has no seed on this strip in the filter's first pass, hence in no pass: it is quiet
+//     exactly as if the filter had run, gets its memo entry here, and the expansion kernel never loads its unary terms.  The
+//     masks are used only where no cell of the strip carries a stamp later than the proposals' launch (seed_tick): a label
+//     changed since then in or next to the strip makes every cell it touches carry one (dilated stamps).
+// out[2 slot] = the labels the memo leaves (what the strip falls back to after a move of its own: the masks are stale
+// then), out[2 slot + 1] = those that also have a seed -- 0: the launch's workgroup returns after one scalar load.
+// FUSION: the fusion pass's memo entry (slot K) alone; out[2 slot] = out[2 slot + 1] = 1 when the pass has to look.
+template <int ORIENT, bool FUSION>
+__global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, int K, unsigned long long label_mask,
+                                                         const uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo, int tick0,
+                                                         const unsigned long long* __restrict__ seed, int seed_tick,
+                                                         unsigned long long* __restrict__ out, unsigned long long* __restrict__ work) {
+  __shared__ unsigned int acc[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nstrips = g.nbands * g.nsegs;
+  const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs, g.xcd);
+  if (threadIdx.x < 2) acc[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int base = blockIdx.x * 4; base < nslots; base += gridDim.x * 4) {
+    const int slot = __builtin_amdgcn_readfirstlane(base + wv);
+    if (slot >= nslots) continue;
+    unsigned long long tf = 0ull, td = 0ull;
+    const int strip = strip_of_slot<ORIENT>(g, slot);
+    if (strip >= 0 && strip < nstrips) {
+      const int bnd = strip / g.nsegs;
+      const int seg = strip - bnd * g.nsegs;
+      const int rs0 = bnd * (SH + 1) - g.shift_r;
+      const int cs0 = seg * 64 - g.shift_c;
+      const int ca = cs0 > 0 ? cs0 : 0;
+      const int cb = (cs0 + SL < g.Ws) ? cs0 + SL : g.Ws;
+      const int ncols = cb > ca ? cb - ca : 0;
+      const bool empty = ncols <= 0 ||
+                         (g.diagonal && (ORIENT == 0 ? (rs0 > 0 ? rs0 : 0) > cb - 1 : ca > (rs0 + SH - 1 < g.Hs - 1 ? rs0 + SH - 1 : g.Hs - 1)));
+      if (!empty) {
+        int nd[SH];
+#pragma unroll
+        for (int r = 0; r < SH; ++r) nd[r] = lane < ncols ? strip_node(g, rs0 + r, ca + lane) : -1;
+        const uint16_t* mrow = memo + (int64_t)strip * (K + 1);
+        // every load of the wave before any use
+        int st[SH];
+        unsigned long long sm[SH];
+#pragma unroll
+        for (int r = 0; r < SH; ++r) st[r] = stamp[nd[r] >= 0 ? nd[r] : 0];
+        const int lq = FUSION ? (int)mrow[K] : (lane < K ? (int)mrow[lane] : 0);
+        if (!FUSION && seed) {
+#pragma unroll
+          for (int r = 0; r < SH; ++r) sm[r] = seed[nd[r] >= 0 ? nd[r] : 0];
+        }
+        int nw = 0;
+        unsigned int have = 0u;
+#pragma unroll
+        for (int r = 0; r < SH; ++r) {
+          nw = (nd[r] >= 0 && st[r] > nw) ? st[r] : nw;
+          have |= nd[r] >= 0 ? 1u : 0u;
+        }
+        unsigned int s0 = 0u, s1 = 0u;
+        if (!FUSION && seed) {
+#pragma unroll
+          for (int r = 0; r < SH; ++r) {
+            s0 |= nd[r] >= 0 ? (unsigned int)sm[r] : 0u;
+            s1 |= nd[r] >= 0 ? (unsigned int)(sm[r] >> 32) : 0u;
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const int o2 = __shfl_xor(nw, off, 64);
+          nw = o2 > nw ? o2 : nw;
+          if (!FUSION && seed) {
+            s0 |= (unsigned int)__shfl_xor((int)s0, off, 64);
+            s1 |= (unsigned int)__shfl_xor((int)s1, off, 64);
+          }
+        }
+        const bool any_node = __ballot(have != 0u) != 0ull;
+        if (any_node) {
+          if (FUSION) {
+            tf = td = (lq && nw < lq) ? 0ull : 1ull;
+          } else {
+            tf = label_mask & __ballot(lane < K && !(lq && nw < lq));
+            td = tf;
+            if (seed && nw <= seed_tick) {
+              td = tf & (((unsigned long long)s1 << 32) | (unsigned long long)s0);
+              const unsigned long long pruned = tf & ~td;
+              // quiet without the filter: the memo entry the filter would have written (lane <-> label)
+              if ((pruned >> lane) & 1ull) const_cast<uint16_t*>(mrow)[lane] = (uint16_t)(tick0 + lane);
+              if (lane == 0 && pruned) {
+                const unsigned int cells = (unsigned int)(ncols * SH);
+                atomicAdd(&acc[0], (unsigned int)__popcll(pruned) * cells);     // label cells settled by the masks
+                if (!td) atomicAdd(&acc[1], cells);                             // ... cells of strips settled entirely
+              }
+            }
+          }
+        }
+      }
+    }
+    if (lane == 0) {
+      out[2 * (int64_t)slot] = tf;
+      out[2 * (int64_t)slot + 1] = td;
+    }
+  }
+  __syncthreads();
+  if (work && threadIdx.x < 2) {
+    const unsigned int v = acc[threadIdx.x];
+    if (v) atomicAdd(work + (blockIdx.x & (WORK_BANKS - 1)) * WORK_SLOTS + 7 + threadIdx.x, (unsigned long long)v);
+  }
+}
+
 #ifndef PHMRF_COLS_WPE
 #define PHMRF_COLS_WPE 4
 #endif
@@ -1502,7 +1613,8 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
                                                                          float beta, unsigned long long label_mask,
                                                                          unsigned long long* __restrict__ changed,
                                                                          uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
-                                                                         int tick0, unsigned long long* __restrict__ work, int peel_max) {
+                                                                         int tick0, unsigned long long* __restrict__ work, int peel_max,
+                                                                         const unsigned long long* __restrict__ scan) {
   __shared__ ColsLds lds_pool;
   float* slabw = lds_pool.slabw;
   unsigned char* slabl = lds_pool.slabl;
@@ -1532,7 +1644,15 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 
   const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs, g.xcd);
   for (int slot_v = blockIdx.x; slot_v < nslots; slot_v += gridDim.x) {
-    const int strip = strip_of_slot<ORIENT>(g, __builtin_amdgcn_readfirstlane(slot_v));
+    const int slot_u = __builtin_amdgcn_readfirstlane(slot_v);
+    // (inside a solve strip_scan_kernel has looked at the strip's stamps, memo row and seed masks: two words per slot)
+    unsigned long long todo = label_mask, todo_full = label_mask;
+    if (scan) {
+      todo_full = scan[2 * (int64_t)slot_u];
+      todo = scan[2 * (int64_t)slot_u + 1];
+      if (!todo) continue;
+    }
+    const int strip = strip_of_slot<ORIENT>(g, slot_u);
     if (strip < 0 || strip >= nstrips) continue;
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
@@ -1551,14 +1671,13 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 
     // ---- column layout: lane c <-> strip column c; the node of row r is nodec[r] (-1: none)
     unsigned long long valid[SH];
-    unsigned long long todo = label_mask;
     uint16_t* mrow = memo ? memo + (int64_t)strip * (K + 1) : nullptr;
     {
       int nw = 0;
       int nd[SH];
 #pragma unroll
       for (int r = 0; r < SH; ++r) nd[r] = lane < ncols ? strip_node(g, rs0 + r, ca + lane) : -1;
-      if (mrow) {
+      if (mrow && !scan) {
 #pragma unroll
         for (int r = 0; r < SH; ++r) {
           const int st = stamp[nd[r] >= 0 ? nd[r] : 0];
@@ -1571,12 +1690,15 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
         }
         const int lq = lane < K ? (int)mrow[lane] : 0;
         todo &= __ballot(lane < K && !(lq && nw < lq));
+        todo_full = todo;
       }
 #pragma unroll
       for (int r = 0; r < SH; ++r) valid[r] = __ballot(nd[r] >= 0);
     }
     todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
            (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
+    todo_full = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo_full >> 32)) << 32) |
+                (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo_full);
     if (!todo || !(valid[0] | valid[1] | valid[2] | valid[3] | valid[4])) continue;
     bool staged = false;
 
@@ -1648,7 +1770,6 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
       }
 
       PH(2)
-      const unsigned long long todo_in = todo;       // (after a move every later label of this set is filtered again)
       todo = filter_phase<ORIENT>(g, lds, lane, rs0, ca, ncols, ncell, valid[0], valid[1], valid[2], valid[3], valid[4], todo, n, uT,
                                   mrow, tick0, peel_max);
       todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
@@ -1675,7 +1796,9 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 #ifdef PHMRF_COLS_RESTAGE
           staged = false;
 #endif
-          todo = todo_in & ~((2ull << alpha) - 1ull);
+          // (every later label the memo left -- those the seed masks had settled, too: the masks are those of the labels
+          //  before the move)
+          todo = todo_full & ~((2ull << alpha) - 1ull);
           break;
         }
       }
@@ -1723,7 +1846,8 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
                                                                           const float* __restrict__ sgain, float beta,
                                                                           unsigned long long* __restrict__ changed,
                                                                           uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
-                                                                          int tick, unsigned long long* __restrict__ work, int peel_max) {
+                                                                          int tick, unsigned long long* __restrict__ work, int peel_max,
+                                                                          const unsigned long long* __restrict__ scan) {
   __shared__ FusLds lds_pool;
   float* slabw = lds_pool.c.slabw;
   unsigned char* slabl = lds_pool.c.slabl;
@@ -1737,7 +1861,9 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
 
   const int nslots = strip_slots(ORIENT, g.nbands, g.nsegs, g.xcd);      // (the XCD-aware order of orientation 1: strip_of_slot)
   for (int slot_v = blockIdx.x; slot_v < nslots; slot_v += gridDim.x) {
-    const int strip = strip_of_slot<ORIENT>(g, __builtin_amdgcn_readfirstlane(slot_v));
+    const int slot_u = __builtin_amdgcn_readfirstlane(slot_v);
+    if (scan && !scan[2 * (int64_t)slot_u + 1]) continue;      // (strip_scan_kernel: the memo entry is newer than every stamp)
+    const int strip = strip_of_slot<ORIENT>(g, slot_u);
     if (strip < 0 || strip >= nstrips) continue;
     const int bnd = strip / g.nsegs;
     const int seg = strip - bnd * g.nsegs;
@@ -1756,7 +1882,7 @@ __global__ __launch_bounds__(64, PHMRF_FUSION_WPE) void fusion_cols_kernel(Strip
     uint16_t* mslot = memo ? memo + (int64_t)strip * (K + 1) + K : nullptr;
 #pragma unroll
     for (int r = 0; r < SH; ++r) ndx[r] = lane < ncols ? strip_node(g, rs0 + r, ca + lane) : -1;
-    if (mslot) {
+    if (mslot && !scan) {
       const int last_quiet = *mslot;
       if (last_quiet) {
         int nw = 0;
@@ -2007,7 +2133,8 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
                                                            int diagonal, const float4* __restrict__ fwd_w,
                                                            const uint8_t* __restrict__ labels, float beta,
                                                            uint8_t* __restrict__ prop, const uint16_t* __restrict__ stamp,
-                                                           int since, unsigned long long* __restrict__ work, float* __restrict__ sgain) {
+                                                           int since, unsigned long long* __restrict__ work, float* __restrict__ sgain,
+                                                           unsigned long long* __restrict__ seed) {
   extern __shared__ float tile[];
   const int TB = blockDim.x;
   unsigned int done = 0u;
@@ -2049,6 +2176,33 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
       }
       prop[v] = (uint8_t)bk;
       if (sgain) sgain[v] = bk != cur ? best - row[cur] : 1.0e30f;
+      if (seed) {
+        // SEED MASK (round 6): bit a = "an improving expansion of label a on a strip could start at this node".  The strip
+        // filter (peel_row) calls cell i a seed of label a when  s_i(a) < cap_i / 2,  s_i(a) = u_i(a) - u_i(l) + beta (h(l) - h(a))
+        // = row[a] - row[l] here, cap_i = the discounts w (2 - [l != l_j]) of i's in-strip neighbours still in U.  cap_i is at
+        // most V = sum over ALL eight neighbours, so  row[a] - row[l] < V / 2  is implied by the filter's test whatever the
+        // strip, the cut and the pass; the margins (1.0002 V + 4e-5 against the filter's 1.0001 cap + 2e-5; 2e-6 of the
+        // magnitudes against the <= 19 roundings of the two sums) keep that true in f32.  A (strip, label) pair none of
+        // whose cells has the bit is quiet without a look at the label's unary terms (strip_scan_kernel).
+        float vtot = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const float bw = beta * nw[d];
+          vtot += nl[d] == cur ? bw + bw : bw;
+        }
+        const float rc = row[cur];
+        const float lim = rc + 0.5f * __builtin_fmaf(vtot, 1.0002f, 4e-5f) + 2e-6f * (fabsf(rc) + 2.f * vtot);
+        unsigned int mlo = 0u, mhi = 0u;
+        for (int k = 0; k < K && k < 32; ++k) {
+          const float x = row[k];
+          mlo |= (k != cur && __builtin_fmaf(fabsf(x), -2e-6f, x) < lim) ? (1u << k) : 0u;
+        }
+        for (int k = 32; k < K; ++k) {
+          const float x = row[k];
+          mhi |= (k != cur && __builtin_fmaf(fabsf(x), -2e-6f, x) < lim) ? (1u << (k - 32)) : 0u;
+        }
+        seed[v] = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
+      }
     }
   }
   {   // nodes recomputed by this workgroup (per-thread counts -> one add per wave)
@@ -2062,34 +2216,6 @@ __global__ __launch_bounds__(256) void propose_grid_kernel(const float* __restri
 inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 }  // namespace
-
-int launch_propose(phmrf_block* b, float beta) {
-  const int since = b->tick ? b->prop_tick : -1;
-  if (!b->sgain) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->sgain), (size_t)b->n * sizeof(float)));
-  const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
-  const size_t lds = (size_t)TB * Kp * sizeof(float);
-  int64_t g64 = (b->n + TB - 1) / TB;
-  const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
-  if (b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->D == 8) {
-    hipLaunchKernelGGL(propose_grid_kernel, dim3(grid), dim3(TB), lds, b->stream, b->uT, b->n, K, Kp, b->H, b->W, b->diagonal,
-                       b->fwd_w, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc, b->sgain);
-    PHMRF_HIP(hipGetLastError());
-    b->prop_tick = b->tick ? b->tick : -1;
-    return PHMRF_OK;
-  }
-#define PHMRF_LAUNCH_PROP(VEC_)                                                                                     \
-  hipLaunchKernelGGL((propose_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
-                     b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc, b->sgain)
-  switch (vec_of(K)) {
-    case 4: PHMRF_LAUNCH_PROP(4); break;
-    case 2: PHMRF_LAUNCH_PROP(2); break;
-    default: PHMRF_LAUNCH_PROP(1); break;
-  }
-#undef PHMRF_LAUNCH_PROP
-  PHMRF_HIP(hipGetLastError());
-  b->prop_tick = b->tick ? b->tick : -1;
-  return PHMRF_OK;
-}
 
 // Development knobs (read from the environment) exist only in builds with -DPHMRF_DEV (tools/variant.sh): the product
 // library has none that can change or break a labelling.
@@ -2112,10 +2238,60 @@ static int peel_sweeps() {   // PHMRF_PEEL_SWEEPS=0 switches the filter off (tim
   }
   return v;
 }
+static bool scan_enabled() {        // PHMRF_SCAN=1: strip_scan_kernel in front of every strip launch of a solve (a measured negative,
+  static const bool on = PHMRF_DEV_ENV("PHMRF_SCAN") != nullptr || PHMRF_DEV_ENV("PHMRF_SEED_MASKS") != nullptr;   // DESIGN.md 3.3 round 6)
+  return on;
+}
+static int mopup_grid() {           // PHMRF_MOPUP_GRID=n: workgroups of a strip launch in the rounds after a solve's first (0: one per slot)
+  static int v = -2;
+  if (v == -2) {
+    const char* e = PHMRF_DEV_ENV("PHMRF_MOPUP_GRID");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+static bool seed_masks_enabled() {  // PHMRF_SEED_MASKS=1: the scan also uses the seed masks (a measured negative, DESIGN.md 3.3: kept
+  static const bool on = PHMRF_DEV_ENV("PHMRF_SEED_MASKS") != nullptr;   // for the A/B -- the labellings must not differ)
+  return on;
+}
 #else
 static constexpr int strip_debug() { return 0; }
 static constexpr int peel_sweeps() { return PEEL_MAX; }
+static constexpr bool scan_enabled() { return false; }
+static constexpr int mopup_grid() { return -1; }
+static constexpr bool seed_masks_enabled() { return false; }
 #endif
+
+int launch_propose(phmrf_block* b, float beta) {
+  const int since = b->tick ? b->prop_tick : -1;
+  if (!b->sgain) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->sgain), (size_t)b->n * sizeof(float)));
+  if (!b->seed && seed_masks_enabled()) PHMRF_HIP(hipMalloc(reinterpret_cast<void**>(&b->seed), (size_t)b->n * sizeof(unsigned long long)));
+  const int K = b->K, TB = tile_threads(K), Kp = padded_k(K);
+  const size_t lds = (size_t)TB * Kp * sizeof(float);
+  int64_t g64 = (b->n + TB - 1) / TB;
+  const int grid = (int)(g64 > 256 * 16 ? 256 * 16 : g64);
+  if (b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->D == 8) {
+    hipLaunchKernelGGL(propose_grid_kernel, dim3(grid), dim3(TB), lds, b->stream, b->uT, b->n, K, Kp, b->H, b->W, b->diagonal,
+                       b->fwd_w, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc, b->sgain, b->seed);
+    PHMRF_HIP(hipGetLastError());
+    b->prop_tick = b->tick ? b->tick : -1;
+    b->seed_tick = b->prop_tick;             // (the masks are those of the labelling at this tick; -1: not inside a solve)
+    return PHMRF_OK;
+  }
+#define PHMRF_LAUNCH_PROP(VEC_)                                                                                     \
+  hipLaunchKernelGGL((propose_kernel<VEC_>), dim3(grid), dim3(TB), lds, b->stream, b->logprob, b->n, K, Kp, b->D, b->nbr, \
+                     b->wgt, b->labels, beta, b->labels_tmp, b->stamp, since, b->work_acc, b->sgain)
+  switch (vec_of(K)) {
+    case 4: PHMRF_LAUNCH_PROP(4); break;
+    case 2: PHMRF_LAUNCH_PROP(2); break;
+    default: PHMRF_LAUNCH_PROP(1); break;
+  }
+#undef PHMRF_LAUNCH_PROP
+  PHMRF_HIP(hipGetLastError());
+  b->prop_tick = b->tick ? b->tick : -1;
+  b->seed_tick = -1;                         // (the adjacency form writes no seed masks)
+  return PHMRF_OK;
+}
 
 static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int shift_c) {
   StripGeom g;
@@ -2132,6 +2308,19 @@ static StripGeom make_geom(const phmrf_block* b, int orient, int shift_r, int sh
   static const bool plain_order = PHMRF_DEV_ENV("PHMRF_NO_XCD_MAP") != nullptr;      // development: A/B of the strips' order
   g.xcd = plain_order ? 0 : 1;
   return g;
+}
+
+// how many strip slots a launch on this block can have at most (either orientation, any cut): the size of scan_out
+int64_t strip_scan_slots(const phmrf_block* b) {
+  int64_t m = 0;
+  for (int orient = 0; orient < 2; ++orient) {
+    const int Hs = orient ? b->W : b->H, Ws = orient ? b->H : b->W;
+    const int nbands = (Hs + 5 + SH) / (SH + 1), nsegs = (Ws + 63 + 63) / 64;
+    const int64_t a = strip_slots(orient, nbands, nsegs, 1), c = (int64_t)nbands * nsegs;
+    m = a > m ? a : m;
+    m = c > m ? c : m;
+  }
+  return m;
 }
 
 int launch_unary_planes(phmrf_block* b) {
@@ -2165,14 +2354,27 @@ int launch_strip_pass(const phmrf_block* b, float beta, int orient, int shift_r,
   // the fusion pass of a solve (proposals in labels_tmp) runs behind the exact filter (fusion_cols_kernel); the
   // single-label passes of the API and the coarse child problems keep strip_kernel.
   if (alpha < 0) {
-    int fgrid = strip_slots(orient, g.nbands, g.nsegs, g.xcd);
+    const int fslots = strip_slots(orient, g.nbands, g.nsegs, g.xcd);
+    int fgrid = fslots;
     if (fgrid > (1 << 22)) fgrid = 1 << 22;
+    if (b->ss && b->ss->rounds > 0 && mopup_grid() > 0 && fgrid > mopup_grid()) fgrid = mopup_grid();
+    uint16_t* const fmemo = use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr;
+    // inside a solve the strips' stamps and memo entries are looked at by a light kernel of their own (strip_scan_kernel)
+    const bool use_scan = use_memo && b->scan_out && (int64_t)fslots <= b->scan_slots && scan_enabled();
+    if (use_scan) {
+#define PHMRF_LAUNCH_FSCAN(O_)                                                                                        \
+  hipLaunchKernelGGL((strip_scan_kernel<O_, true>), dim3((fslots + 3) / 4), dim3(256), 0, b->stream, g, b->K, 0ull, b->stamp, fmemo, \
+                     b->tick, static_cast<const unsigned long long*>(nullptr), -1, b->scan_out, b->work_acc)
+      if (orient) PHMRF_LAUNCH_FSCAN(1);
+      else PHMRF_LAUNCH_FSCAN(0);
+#undef PHMRF_LAUNCH_FSCAN
+      PHMRF_HIP(hipGetLastError());
+    }
 #define PHMRF_LAUNCH_FUSION(O_)                                                                                       \
   hipLaunchKernelGGL((fusion_cols_kernel<O_>), dim3(fgrid), dim3(64), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w,  \
                      b->uT, b->labels, b->labels_tmp, b->sgain, beta, b->counters + b->counter_slot,                   \
-                     b->tick ? b->stamp : nullptr,                                                                    \
-                     use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr, b->tick, \
-                     b->work_acc, peel_sweeps())
+                     b->tick ? b->stamp : nullptr, fmemo, b->tick, b->work_acc, peel_sweeps(),                        \
+                     use_scan ? b->scan_out : static_cast<const unsigned long long*>(nullptr))
     if (orient) PHMRF_LAUNCH_FUSION(1);
     else PHMRF_LAUNCH_FUSION(0);
 #undef PHMRF_LAUNCH_FUSION
@@ -2214,14 +2416,31 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
   // one workgroup per strip (orientation 1: per slot of the XCD-aware order, strip_of_slot) up to 4 M: the dispatcher hands a
   // free slot the next strip, which balances the uneven strips better than waves striding over them (measured against a cap
   // of 8 resident sets: -3 % on the rows cut)
-  int grid = strip_slots(orient, g.nbands, g.nsegs, g.xcd);
+  const int nslots = strip_slots(orient, g.nbands, g.nsegs, g.xcd);
+  int grid = nslots;
   if (grid > (1 << 22)) grid = 1 << 22;
-  const bool use_memo = b->tick && geom >= 0 && (int64_t)nstrips <= b->memo_strips;
+  if (b->ss && b->ss->rounds > 0 && mopup_grid() > 0 && grid > mopup_grid()) grid = mopup_grid();
+  const bool use_memo = b->tick && geom >= 0 && b->memo && (int64_t)nstrips <= b->memo_strips;
+  uint16_t* const mmemo = use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr;
+  // inside a solve: strip_scan_kernel first -- stamps against the memo, and the seed masks of the proposals' launch where
+  // they are current (b->seed_tick: launch_propose on a grid block in this solve)
+  const bool use_scan = use_memo && b->scan_out && (int64_t)nslots <= b->scan_slots && scan_enabled();
+  if (use_scan) {
+    const bool masks = b->seed && b->seed_tick >= 0 && seed_masks_enabled();
+#define PHMRF_LAUNCH_SCAN(O_)                                                                                         \
+  hipLaunchKernelGGL((strip_scan_kernel<O_, false>), dim3((nslots + 3) / 4), dim3(256), 0, b->stream, g, b->K, label_mask, b->stamp, \
+                     mmemo, b->tick, masks ? b->seed : static_cast<const unsigned long long*>(nullptr), b->seed_tick,   \
+                     b->scan_out, b->work_acc)
+    if (orient) PHMRF_LAUNCH_SCAN(1);
+    else PHMRF_LAUNCH_SCAN(0);
+#undef PHMRF_LAUNCH_SCAN
+    PHMRF_HIP(hipGetLastError());
+  }
 #define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
   hipLaunchKernelGGL((strip_cols_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
-                     b->uT, b->labels, beta, label_mask, b->counters + 8, b->tick ? b->stamp : nullptr,               \
-                     use_memo ? b->memo + ((int64_t)(orient * 3 + geom) * b->memo_strips) * (b->K + 1) : nullptr,      \
-                     b->tick, b->work_acc, peel_sweeps())
+                     b->uT, b->labels, beta, label_mask, b->counters + 8, b->tick ? b->stamp : nullptr, mmemo,          \
+                     b->tick, b->work_acc, peel_sweeps(),                                                             \
+                     use_scan ? b->scan_out : static_cast<const unsigned long long*>(nullptr))
   if (orient) PHMRF_LAUNCH_MULTI(1);
   else PHMRF_LAUNCH_MULTI(0);
 #undef PHMRF_LAUNCH_MULTI

@@ -442,6 +442,52 @@ def test_energy_parity_with_live_gco_on_synthetic_blocks(seed, N, K, diagonal, p
     b.close()
 
 
+KNN_GCO_CASES = [(21, 50000, 10, 6, 0.0), (22, 30000, 20, 8, 0.1), (23, 8000, 6, 4, 0.2)]
+
+
+@pytest.mark.parametrize("seed,n,K,k,perturb", KNN_GCO_CASES)
+def test_energy_parity_with_gco_on_graphs_that_are_no_grid(seed, n, K, k, perturb):
+    """The boundary is pygco.cut_general_graph on a GENERAL graph (phylo_hmrf.py:496-498, GCoptimization.h:551-597): the
+    same energy bar off the contact-map stencil.  Seeded k-nearest-neighbour graphs of random points
+    (oracle/synth.make_knn_block: 50,000 nodes / 176,382 edges / K = 10 and two smaller ones), uniformly random initial
+    labels, gco's swap run in the build container under pygco's quantisation and under the finest one
+    (tests/golden/make_golden_knn_gco.py -> knn_gco_energies.json; run live as well where oracle/_ref is present).  The GPU
+    labelling -- ICM, component moves and the path moves of general graphs (exact chain DP along induced paths) -- must be at
+    or below what the reference computes, strictly, scored by the same float64 function."""
+    import json
+    from oracle import gco_ref
+    blk = synth.make_knn_block(seed, n, 4, K, k=k)
+    X = blk["X"]
+    w, eid = R.edge_weights_from_distance(blk["edges"], 0.5)
+    means = blk["means"] + perturb * np.random.default_rng(seed + 1).standard_normal(blk["means"].shape)
+    lp = R.log_multivariate_normal_density_full(X, means, blk["covars"])
+    init = np.random.default_rng(seed + 7).integers(0, K, n)
+    V = R.potts_matrix(K, 1.0)
+    rec = [c for c in json.load(open(os.path.join(G, "knn_gco_energies.json")))["cases"]
+           if (c["seed"], c["n"], c["K"], c["k"], c["perturb"]) == (seed, n, K, k, perturb)]
+    assert len(rec) == 1, "no recorded gco energies for this case: run tests/golden/make_golden_knn_gco.py"
+    np.testing.assert_allclose(R.mrf_energy(init, lp, eid, w, 1.0)[0], rec[0]["e_init"], rtol=1e-12)    # same inputs
+    e_ref = {"pygco": rec[0]["e_pygco"], "fine": rec[0]["e_fine"]}
+    if gco_ref.available():
+        for q in ("pygco", "fine"):
+            lab = gco_ref.cut_general_graph(eid, w, -lp, V, n_iter=5000, algorithm="swap", init_labels=init, quant=q)
+            np.testing.assert_allclose(R.mrf_energy(lab, lp, eid, w, 1.0)[0], e_ref[q], rtol=1e-12)
+    b = _block(n, 4, K)
+    b.set_graph(eid, w)
+    b.set_logprob(lp)
+    for tol_ppb in (0, 1000):
+        b.set_labels(init)
+        res = b.solve(1.0, energy_tol_ppb=tol_ppb)
+        e_mine = R.mrf_energy(b.get_labels(), lp, eid, w, 1.0)[0]
+        print("knn n %d K %d tol %d ppb: energy GPU %.3f  swap via pygco %.3f (GPU %+.2e)  swap fine %.3f (GPU %+.2e)  rounds %d"
+              % (n, K, tol_ppb, e_mine, e_ref["pygco"], (e_mine - e_ref["pygco"]) / abs(e_ref["pygco"]), e_ref["fine"],
+                 (e_mine - e_ref["fine"]) / abs(e_ref["fine"]), res["rounds"]))
+        assert res["converged"]
+        assert e_mine <= e_ref["pygco"], (tol_ppb, e_mine, e_ref)
+        assert e_mine <= e_ref["fine"] + (1e-5 * abs(e_ref["fine"]) if tol_ppb else 0.0), (tol_ppb, e_mine, e_ref)
+    b.close()
+
+
 def test_energy_parity_chain_graph_without_geometry():
     g = np.load(os.path.join(G, "gco_chain.npz"))
     K = int(g["K"])
@@ -855,6 +901,68 @@ def test_coarse_shortcuts_leave_the_labellings_alone():
         runs.append(eval(line[len("RESULT"):])[0])
     assert runs[0] == runs[1] == runs[2], runs
     assert runs[0][1] >= 3
+
+
+SEED_SCRIPT = r"""
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, os.environ["PHMRF_ROOT"])
+import torch
+from phylo_hmrf_amd import Block, synthetic
+from phylo_hmrf_amd.tree import PhyloTree
+K, S, N = 12, 4, 700
+tree = PhyloTree(synthetic.tree_for(S)); rng = np.random.default_rng(4)
+P = synthetic.sample_ou_params(rng, tree, K); mu, cv = tree.mean_cov(P); cv = cv + 1e-3 * np.eye(S)
+P2 = np.clip(P * (1 + 0.15 * rng.standard_normal(P.shape)), 1e-3, 50); mu2, cv2 = tree.mean_cov(P2); cv2 = cv2 + 1e-3 * np.eye(S)
+P3 = np.clip(P2 * (1 + 0.05 * rng.standard_normal(P.shape)), 1e-3, 50); mu3, cv3 = tree.mean_cov(P3); cv3 = cv3 + 1e-3 * np.eye(S)
+dev = torch.device("cuda", 0)
+X = synthetic.device_observations(torch, dev, 2, N, N, True, K, mu, cv); torch.cuda.synchronize()
+n = N * (N + 1) // 2
+b = Block(n, S, K); b.set_observations_dev(X.data_ptr()); b.sync(); b.build_grid_graph(N, N, True, 8, 0.5)
+b.enable_timing(True); b.reset_timing()
+out = []
+b.emission(mu2, cv2)
+res = b.solve(1.0, energy_tol_ppb=1000, init_mode=1)              # cold
+out.append((hashlib.sha1(b.get_labels().tobytes()).hexdigest(), res["rounds"], repr(res["energy"])))
+b.emission(mu3, cv3)
+res = b.solve(1.0, energy_tol_ppb=1000)                           # warm, as an EM iteration's E-step
+out.append((hashlib.sha1(b.get_labels().tobytes()).hexdigest(), res["rounds"], repr(res["energy"])))
+res = b.solve(1.0, energy_tol_ppb=0)                              # to the exact fixed point of every move type
+out.append((hashlib.sha1(b.get_labels().tobytes()).hexdigest(), res["rounds"], repr(res["energy"])))
+w = b.work()
+print("RESULT", (out, w["mask_label_cells"], w["mask_strip_cells"], w["label_cells"]))
+"""
+
+
+def test_strip_scan_and_seed_masks_leave_the_labellings_alone():
+    """Round 6: strip_scan_kernel looks at every strip's stamps and memo row BEFORE the strip launch (two words per strip
+    slot; the launch's workgroup returns after one scalar load where there is nothing to do).  Exact: with
+    PHMRF_DETERMINISTIC=1 a cold solve, a warm solve and a solve to the exact fixed point give the same label hashes, round
+    counts and energies (a) as shipped -- every strip reading its own stamps and memo row --, (b) with the scan in front of
+    every strip launch (PHMRF_SCAN=1) and (c) with the SEED MASKS on top of the scan (PHMRF_SEED_MASKS=1): per-node bits "an improving
+    expansion of label a could start here" written by the proposals' launch, a superset of the filter's own first-pass seed
+    test, OR-ed over a strip by the scan.  (c) is exact, too, but settles little -- the fusion pass and the other orientation's
+    expansions run between the proposals' launch and the strip launch and leave a stamp in nearly every strip, which voids
+    the strip's masks; and (b) costs what it saves, the floor of a mop-up launch being one wave's walk through its strip's
+    labels, not the look at the stamps -- so both are development options, off in the product."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "phylo_hmrf_amd", "libphmrf_dev.so")      # (the knobs exist in the -DPHMRF_DEV build only)
+    assert os.path.exists(dev), "libphmrf_dev.so not built (make -C phylo_hmrf_amd/csrc)"
+    runs = []
+    for extra in ({}, {"PHMRF_SCAN": "1", "PHMRF_LIB": dev}, {"PHMRF_SEED_MASKS": "1", "PHMRF_LIB": dev}):
+        env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", **extra)
+        out = subprocess.run([sys.executable, "-c", SEED_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        runs.append(eval(line[len("RESULT"):]))
+    assert runs[0][0] == runs[1][0] == runs[2][0], runs
+    assert runs[0][1] == 0 and runs[1][1] == 0                       # no masks: nothing settled by them
+    assert runs[0][3] == runs[1][3]                                  # the same (strip, label) pairs went through the filter
+    settled, examined = runs[2][1], runs[2][3]
+    # the same pairs, decided one way or the other (a label the masks settled is looked at again after a move on its strip)
+    assert settled > 0 and runs[0][3] <= settled + examined <= 1.05 * runs[0][3], runs
 
 
 PREP_SCRIPT = r"""
