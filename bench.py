@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one process, one GPU: build and time only what rank --emulate-rank of a run on this many GPUs holds")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--no-through-fit", action="store_true",
+                    help="skip `fit_surface`: the same EM iterations once more THROUGH THE PRODUCT'S OWN SURFACE -- a phyloHMRF "
+                         "object's fit_accumulate_test (phylo_hmrf_amd/base.py <-> reference base.py:301-455), what the CLI's "
+                         "run() calls -- timed by the loop's own clocks (one GPU only; not part of `value`)")
     ap.add_argument("--no-fit", action="store_true",
                     help="skip the whole-fit measurement after the timed region (the `fit` object of the JSON line)")
     ap.add_argument("--warm-start", default="best", choices=["best", "local"],
@@ -267,6 +271,7 @@ def main():
     # EM starts from perturbed parameters; first labels = argmax_k logprob + one ICM sweep -> labels_local
     params_cur = np.clip(params_true * (1.0 + 0.15 * rng.standard_normal(params_true.shape)), 1e-3, 50.0)
     init_ou = params_cur.copy()
+    rng_state_at_start = rng.bit_generator.state               # (fit_surface replays the same M-step draws)
     means, covars = tree.mean_cov(params_cur)
     covars = covars + 1e-3 * np.eye(S)
     SLOT_INIT = 3
@@ -382,7 +387,8 @@ def main():
         t1 = time.time()
         u0 = untimed[0]
         # the labels-only part of the next E-step's component passes, queued behind the host's M-step (the GPU is idle then)
-        ahead = runner.start(lambda i: blocks[i].prepare_components(), order) if (blocks and not a.no_prepare) else None
+        ahead = (runner.start(lambda i: blocks[i].prepare_components(), order)
+                 if (blocks and not a.no_prepare and solver["use_components"]) else None)
         mstep_all(stats, rng)
         if ahead is not None:
             ahead.results()
@@ -456,6 +462,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     t_e_timed, t_m_timed = list(t_e), list(t_m)
+    # every rank's own clocks on the line (round 6: a first run on a multi-GPU node should say WHICH rank is slow and in what):
+    # mean E-step / M-step per step, the slowest E-step, nodes and units held, and the tile rounds' exchange
+    per_rank = None
+    mine = np.zeros((world, 7))
+    mine[rank] = [np.mean(t_e_timed) * 1e3 if t_e_timed else 0.0, np.mean(t_m_timed) * 1e3 if t_m_timed else 0.0,
+                  np.max(t_e_timed) * 1e3 if t_e_timed else 0.0, n_local, len(unit_blocks),
+                  (tile_rounds or {}).get("tile_round_exchange_us", 0.0), (tile_rounds or {}).get("rounds_per_solve", 0.0)]
+    if use_dist:
+        tpr = torch.from_numpy(mine).to(coll_dev)
+        dist.all_reduce(tpr)
+        mine = tpr.cpu().numpy()
+    per_rank = {"estep_ms": [round(float(x), 3) for x in mine[:, 0]], "mstep_ms": [round(float(x), 3) for x in mine[:, 1]],
+                "estep_ms_max": [round(float(x), 3) for x in mine[:, 2]], "nodes": [int(x) for x in mine[:, 3]],
+                "units": [int(x) for x in mine[:, 4]], "exchange_us": [round(float(x), 1) for x in mine[:, 5]],
+                "tile_rounds_per_solve": [round(float(x), 2) for x in mine[:, 6]],
+                "note": "one entry per rank, this rank's own host clocks over the timed steps: E-step (its blocks and tiles, to the "
+                        "all-reduce of the statistics), M-step (its share of the K states + the all-reduce of the rows), "
+                        "exchange_us = host time per lockstep round of its split blocks"}
 
     # ---- per-kernel-class device time (HIP events recorded on the blocks' streams during the timed region) ----
     def union_ms(iv):
@@ -598,6 +622,84 @@ def main():
         fit = run_fit(a.warm_start)
         fit_ref = fit if a.warm_start == "local" else run_fit("local")
 
+    # ---- `fit_surface` (not part of `value`): the same warm-up + timed EM iterations, from the same start and with the same
+    #      M-step draws, THROUGH THE PRODUCT: a phyloHMRF object (host observations in, device graph, blocks dealt to its own
+    #      runner) whose fit_accumulate_test runs the loop -- E-steps by _estep_region, the statistics through the Reducer, the
+    #      bookkeeping of base.py:402-435, _do_mstep, the components prepared behind it.  What the reference's run()
+    #      (phylo_hmrf.py:1738) would call; `value` above is measured around the same library calls without that object.
+    def through_fit():
+        from phylo_hmrf_amd.base import _BaseGraph
+        from phylo_hmrf_amd.hmrf import phyloHMRF
+        t_build = time.time()
+        parts, len_vec, s0 = [], [], 0
+        for bi, (H, W, diag) in enumerate(all_blocks):
+            Xd = synthetic.device_observations(torch, dev, a.seed * 1000 + bi, H, W, diag, K, means_true, cov_true,
+                                               mean_run=a.mean_run, noise=a.noise)
+            parts.append(Xd.cpu().numpy().astype(np.float64))          # the reference hands float64 samples over (utility.py:332)
+            del Xd
+            nb = parts[-1].shape[0]
+            len_vec.append([nb, s0, s0 + nb, H, W, 0, 0, bi, 1 if diag else 0, bi + 1])      # utility.py:455-456, :528
+            s0 += nb
+        Xh = np.concatenate(parts, axis=0)
+        del parts
+        torch.cuda.empty_cache()
+
+        class FromTheBenchStart(phyloHMRF):
+            """phyloHMRF with the bench's start instead of the k-means initialisation (phylo_hmrf.py:205-264): the perturbed
+            true parameters, first labels = argmax_k logprob + one ICM sweep -> labels_local; the generator of the M-step's
+            restarts in the state the bench's was in.  Nothing of the timed loop is touched."""
+
+            def _init(self, X, lengths=None):
+                _BaseGraph._init(self, X, lengths=lengths)
+                self.params_vec1 = params_cur.copy()
+                self.init_ou_params = init_ou.copy()
+                self.means_, self._covars_ = means.copy(), covars.copy()
+                self.rng = np.random.default_rng(0)
+                self.rng.bit_generator.state = rng_state_at_start
+                for b, _, _, _ in self._local_units():
+                    b.emission(self.means_, self._covars_)
+                    b.solve_fast(self.beta, max_rounds=1, use_chains=False, use_components=False, use_strips=False,
+                                 use_expansion=False, init_mode=1)
+                    b.save_labels(SLOT_LOCAL)
+                    b.sync()
+
+        B = tree.branch_dim
+        m = FromTheBenchStart(n_components=K, run_id=0, n_samples=Xh.shape[0], n_features=S, observation=Xh,
+                              edge_list=synthetic.tree_for(S), len_vec=len_vec, type_id=1, branch_list=[1.0] * B,
+                              edge_list_1=[None] * len(all_blocks), cons_param=1.0, beta=a.beta, beta1=a.beta1, initial_mode=0,
+                              initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, estimate_type=3, num_neighbor=nn,
+                              random_state=a.seed, quiet=True, mstep_workers=workers, device_graph=True,
+                              block_threads=a.block_threads, warm_start=a.warm_start, solver_opts=dict(solver))
+        build_s = time.time() - t_build
+        try:
+            torch.cuda.synchronize()
+            t_fit = time.time()
+            res = m.fit_accumulate_test(Xh, len_vec, 0.0, "bench", a.warmup + a.steps)     # threshold 0: no early stop
+            torch.cuda.synchronize()
+            fit_s = time.time() - t_fit
+            it_ms = np.asarray(m.timing_["iteration"]) * 1e3
+            e_ms, m_ms = np.asarray(m.timing_["estep"]) * 1e3, np.asarray(m.timing_["mstep"]) * 1e3
+            w = a.warmup if len(it_ms) > a.warmup else 0
+            ms_step = float(np.mean(it_ms[w:]))
+            return {"ms_per_step": round(ms_step, 3), "value": n_global / (ms_step * 1e-3), "unit": "node-iterations/s",
+                    "estep_ms": round(float(np.mean(e_ms[w:])), 3), "mstep_ms": round(float(np.mean(m_ms[w:])), 3),
+                    "iterations_timed": int(len(it_ms) - w), "warmup": int(w),
+                    "ms_per_step_by_iteration": [round(float(x), 1) for x in it_ms],
+                    "cost1": [round(float(c), 6) for c in np.asarray(res[5])[-min(len(res[5]), 8):, 3]],
+                    "build_s": round(build_s, 2), "fit_wall_s": round(fit_s, 3),
+                    "how": "phyloHMRF(observation = the workload's host float64 samples, device_graph=True, block_threads=%d, "
+                           "warm_start=%r).fit_accumulate_test(X, len_vec, 0.0, 'bench', warmup + steps) from the bench's start "
+                           "(same parameters, first labelling and M-step draws as the timed region); ms_per_step = mean of the "
+                           "loop's own per-iteration clock (model.timing_['iteration']: E-step, reduction, bookkeeping, M-step) over "
+                           "the iterations after the warm-up" % (a.block_threads, a.warm_start)}
+        finally:
+            m.close()
+
+    fit_surface = None
+    if not a.no_through_fit and world == 1 and not emulating and a.scaling == "strong":
+        fit_surface = through_fit()
+        fit_surface["ratio_to_ms_per_step"] = round(fit_surface["ms_per_step"] / (elapsed / a.steps * 1e3), 4)
+
     roofline = roofline_limiter = None
     # the dominant class among those with a byte model (the coarse expansions' gathers have none)
     with_model = {k: v for k, v in agg.items() if v[2] > 0}
@@ -722,7 +824,9 @@ def main():
             "cold_first_iteration_ms": cold_first_ms,
             "fit": fit,
             "fit_reference_start": fit_ref,
+            "fit_surface": fit_surface,
             "tile_rounds": tile_rounds,
+            "per_rank": per_rank,
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
             "value_estep_only": n_norm * a.steps / float(np.sum(t_e_timed)),

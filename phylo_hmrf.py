@@ -233,13 +233,17 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
             ref_filename = "%s/%s.chrom.sizes" % (data_path, str(ref_species))
             quantile = int(quantile)
             qfile = "chrom_quantile_test.txt"                               # :1648-1664
-            if quantile == 0 and os.path.exists(qfile):
-                x_max = float(np.median(np.atleast_2d(np.loadtxt(qfile, delimiter="\t"))[:, 6]))
+            # (rank 0 looks, everybody follows -- as for the cache files: no rank may find the file half written by another;
+            #  the file appears by rename, and x_max itself is rank 0's on every rank)
+            if quantile == 0 and all_ranks_agree(os.path.exists(qfile)):
+                x_max = float(np.median(np.atleast_2d(np.loadtxt(qfile, delimiter="\t"))[:, 6])) if rank == 0 else 0.0
             else:
                 m_vec_list = preprocess.quantile_contact_vec(chrom_vec, resolution, ref_filename, filename_list, species)
                 if rank == 0:
-                    np.savetxt(qfile, m_vec_list, fmt="%.4f", delimiter="\t")
+                    np.savetxt(qfile + ".tmp", m_vec_list, fmt="%.4f", delimiter="\t")
+                    os.replace(qfile + ".tmp", qfile)
                 x_max = float(np.median(m_vec_list[:, 6]))
+            x_max = float(all_ranks_agree(x_max))
             print(x_max)
             samples, len_vec, edge_list_vec = preprocess.load_data_chromosome2(
                 chrom_vec, x_max, 0, resolution, num_neighbor, int(filter_mode), float(filter_sigma), int(diagonal_type),

@@ -118,7 +118,7 @@ class _BaseGraph(object):
                  min_cost1=np.asarray(loop["min_cost1"], dtype=np.float64), params_vec_best=loop["params_vec"],
                  params_vec1_best=loop["params_vec1"], pre=np.asarray(loop["pre"], dtype=np.float64),
                  have_t_labels=int(loop["have_t_labels"]), rng_state=json.dumps(self.rng.bit_generator.state),
-                 len_vec=np.asarray(self.len_vec))
+                 len_vec=np.asarray(self.len_vec), model_key=json.dumps(self._checkpoint_key(), sort_keys=True))
         if self.checkpoint_labels:
             self._snapshot_labels(SLOT_CURRENT)
             d["labels_current"] = self._gather_labels(SLOT_CURRENT).astype(np.uint8)
@@ -130,6 +130,22 @@ class _BaseGraph(object):
             np.savez(tmp, **d)
             os.replace(tmp, self.checkpoint_path)
 
+    def _checkpoint_key(self):
+        """what the saved cost bookkeeping (cost_vec, min_cost, the stopping rules) is only meaningful under: the energy's
+        coefficients, the cost variant, the start policy and solver options, and a cheap fingerprint of the observations
+        (a checkpoint of the same block sizes but other data or another beta must not be resumed silently)"""
+        key = {}
+        for name in ("beta", "beta1", "estimate_type", "num_neighbor", "warm_start", "lambda_0", "min_covar"):
+            v = getattr(self, name, None)
+            key[name] = v if isinstance(v, (str, type(None))) else float(v)
+        key["solver_opts"] = {k: (v if isinstance(v, (str, bool)) else float(v)) for k, v in sorted(getattr(self, "solver_opts", {}).items())}
+        X = getattr(self, "observation", None)
+        if X is not None:
+            X = np.asarray(X)
+            idx = np.linspace(0, X.shape[0] - 1, num=min(X.shape[0], 4096)).astype(np.int64)
+            key["observation"] = [int(X.shape[0]), int(X.shape[1]), repr(float(np.asarray(X[idx], dtype=np.float64).sum()))]
+        return key
+
     def _read_checkpoint(self, path, loop):
         """-> the iteration to continue with; fills `loop` and the model from the file, puts the labellings back on the device"""
         import json
@@ -139,6 +155,13 @@ class _BaseGraph(object):
         if int(z["n_components"]) != self.n_components or int(z["n_features"]) != self.n_features or \
                 not np.array_equal(np.asarray(z["len_vec"]), np.asarray(self.len_vec)):
             raise ValueError("checkpoint %s belongs to another model or data set (states, species or len_vec differ)" % path)
+        if "model_key" in z.files:           # (files of round 5 carry none: nothing to compare)
+            saved, now = json.loads(str(z["model_key"])), json.loads(json.dumps(self._checkpoint_key(), sort_keys=True))
+            diff = sorted(k for k in set(saved) | set(now) if saved.get(k) != now.get(k))
+            if diff:
+                raise ValueError("checkpoint %s was written under another model or data (%s differ: saved %s, now %s): its cost "
+                                 "bookkeeping and stopping state do not carry over -- start a new fit"
+                                 % (path, ", ".join(diff), {k: saved.get(k) for k in diff}, {k: now.get(k) for k in diff}))
         if "labels_local" not in z.files:
             raise ValueError("checkpoint %s was written without the labellings (checkpoint_labels=False): parameters can be "
                              "read from it, a fit cannot resume from it" % path)
@@ -191,7 +214,7 @@ class _BaseGraph(object):
         params_vecList = []
         have_t_labels = False
         K, S = self.n_components, self.n_features
-        self.timing_ = {"estep": [], "mstep": []}
+        self.timing_ = {"estep": [], "mstep": [], "iteration": []}       # seconds; "iteration": the whole loop body, bookkeeping included
 
         if self.resume_from:
             loop = resumed
@@ -207,6 +230,7 @@ class _BaseGraph(object):
             self.em_iteration_ = it
             stats = self._initialize_sufficient_statistics()
             start = time.time()
+            t_iteration = start
             # E-step of the regions this rank owns; un-normalised cost sums travel with the statistics
             local = np.zeros(K * (1 + S + S * S) + 5)
             by_size = sorted(self.my_regions, key=lambda r: -int(len_vec[r][0]))          # largest block first
@@ -251,10 +275,13 @@ class _BaseGraph(object):
                 have_t_labels = True
                 self._log("another temp min from iteration 3")
             if ((t_difference1 < threshold1 and t_difference2 < threshold2) or (t_difference3 < threshold1)) and (it > 5):
+                self.timing_["iteration"].append(time.time() - t_iteration)
                 break                                                      # base.py:428-429
             if it > max_iter:
+                self.timing_["iteration"].append(time.time() - t_iteration)
                 break
             if it - min_cost1[0] > max_iter1:                              # base.py:434-435
+                self.timing_["iteration"].append(time.time() - t_iteration)
                 break
             self._log("Maximization...")
             start = time.time()
@@ -263,6 +290,7 @@ class _BaseGraph(object):
             if ahead is not None:
                 ahead.results()
             self.timing_["mstep"].append(time.time() - start)
+            self.timing_["iteration"].append(time.time() - t_iteration)
             self._log("maximization use time %d %s" % (it, time.time() - start))
             if self.checkpoint_path and (it + 1) % max(int(self.checkpoint_every), 1) == 0:
                 self._write_checkpoint(it + 1, dict(cost_vec=cost_vec, params_vecList=params_vecList, min_cost=min_cost,

@@ -1330,18 +1330,30 @@ static int c2f_start(phmrf_block_t b, double beta, const phmrf_solve_opts& o, bo
     Geometry gc(Hc, Wc, b->diagonal);
     phmrf_block_t c = nullptr;
     PHMRF_TRY(phmrf_block_create(gc.count(), 1, b->K, &c));
+    // the child becomes b->c2f only once it is complete: a failure on the way destroys it, and the next cold solve starts over
+    // (a half-built child -- no graph, no grid tables -- must never be solved on)
+    auto build = [&]() -> int {
+      c->stream = b->stream;                    // (the child's kernels read the parent's logprob and write its labels)
+      PHMRF_TRY(dev_alloc(&c->nbr, (size_t)c->n * 8));
+      PHMRF_TRY(dev_alloc(&c->wgt, (size_t)c->n * 8));
+      c->D = 8;
+      PHMRF_TRY(launch_c2f_graph(b, c, Hc, Wc, s));
+      if (!c->colour_nodes) PHMRF_TRY(dev_alloc(&c->colour_nodes, (size_t)c->n));
+      c->has_graph = true;
+      PHMRF_TRY(setup_grid_tables(c, gc, 8));
+      c->grid_complete = true;
+      return PHMRF_OK;
+    };
+    const int st = build();
+    if (st != PHMRF_OK) {
+      (void)hipStreamSynchronize(b->stream);    // (its kernels were queued on the parent's stream)
+      c->stream = c->own_stream;
+      (void)phmrf_block_destroy(c);
+      return st;
+    }
     b->c2f = c;
     b->c2f_Hc = Hc;
     b->c2f_Wc = Wc;
-    c->stream = b->stream;                      // (the child's kernels read the parent's logprob and write its labels)
-    PHMRF_TRY(dev_alloc(&c->nbr, (size_t)c->n * 8));
-    PHMRF_TRY(dev_alloc(&c->wgt, (size_t)c->n * 8));
-    c->D = 8;
-    PHMRF_TRY(launch_c2f_graph(b, c, Hc, Wc, s));
-    if (!c->colour_nodes) PHMRF_TRY(dev_alloc(&c->colour_nodes, (size_t)c->n));
-    c->has_graph = true;
-    PHMRF_TRY(setup_grid_tables(c, gc, 8));
-    c->grid_complete = true;
   }
   phmrf_block* c = b->c2f;
   c->stream = b->stream;

@@ -59,6 +59,17 @@ class Reducer(object):
         dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
         return self._buf.cpu().numpy().copy()
 
+    def allreduce_bytes(self, arr):
+        """all-reduce(sum) of a uint8 array (label gathers: each position is written by exactly one rank)"""
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        if self.world == 1:
+            return arr
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(arr.copy()).to(self.device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
     def broadcast(self, vec, src=0):
         vec = np.ascontiguousarray(vec, dtype=np.float64)
         if self.world == 1:

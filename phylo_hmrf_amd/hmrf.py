@@ -344,12 +344,16 @@ class phyloHMRF(_BaseGraph):
             b.save_labels(slot)
 
     def _gather_labels(self, slot):
-        out = np.zeros(self.n_samples)
+        """the labelling of all samples from the blocks' snapshot `slot`, as float64 like the reference's `labels`
+        (base.py:381, :394).  One byte per label until the last line (K <= 64): with several ranks the exchange is an
+        all-reduce of n_samples BYTES -- every position is written by exactly one rank, the others add zeros -- where it was one
+        of n_samples doubles (710 MB at the whole-genome workload's 88.8 M nodes)."""
+        out = np.zeros(self.n_samples, dtype=np.uint8)
         for b, own, own_local, _ in self._local_units():
             out[own] = b.get_saved_labels(slot)[own_local]
         if self.world > 1:
-            out = self.reducer.allreduce(out)
-        return out
+            out = self.reducer.allreduce_bytes(out)
+        return out.astype(np.float64)
 
     # ---- b1 --------------------------------------------------------------------------------------
     def _compute_log_likelihood(self, X):
@@ -375,15 +379,17 @@ class phyloHMRF(_BaseGraph):
 
     def _predict_tiled(self, region_id):
         """predict() of a region that is cut into row tiles: a collective of THE RANKS THAT HOLD ITS TILES (the tile group's
-        communicator -- a rank that holds none of them returns zeros at once and takes part in nothing, so the holders may
-        call it on their own); every holder returns the whole region's labels and log-likelihoods, the other holders' rows
-        arrive by an all-reduce over the group"""
+        communicator -- a rank that holds none of them raises KeyError naming the holders and takes part in nothing, so the
+        holders may call it on their own); every holder returns the whole region's labels and log-likelihoods, the other
+        holders' rows arrive by an all-reduce over the group"""
         from .tiles import Conductor
         n = self.len_vec[region_id][0]
-        labels, logprob = np.zeros(n, dtype=np.int64), np.zeros((n, self.n_components))
         grp = self.tile_groups.get(region_id)
-        if grp is None:
-            return labels.astype(np.int32), logprob
+        if grp is None:                          # (like _whole_block: a region this rank does not hold is an error, not zeros)
+            holders = sorted(set(int(self.unit_owner[i]) for i, u in enumerate(self.units) if u["block"] == region_id))
+            raise KeyError("region %d is cut into row tiles held by ranks %s, none of them by this rank (%d of %d)"
+                           % (region_id, holders, self.rank, self.world))
+        labels, logprob = np.zeros(n, dtype=np.int64), np.zeros((n, self.n_components))
 
         def prepare(tl):
             tl.b.restore_labels(SLOT_LOCAL)
@@ -443,7 +449,7 @@ class phyloHMRF(_BaseGraph):
         pass that needs the labels only -- are queued on the blocks' streams now (phmrf_block_prepare_components; the pass
         checks on the device that the labels are still these, so nothing depends on it but the time)."""
         regions = [r for r in self.my_regions if r in self.blocks]
-        if not regions:
+        if not regions or not self.solver_opts.get("use_components", True):
             return None
         def hint(r):
             fn = getattr(self.blocks[r], "prepare_components", None)      # (a hint: test doubles of Block need not have it)

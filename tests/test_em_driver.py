@@ -97,6 +97,25 @@ def test_the_reference_trace_survives_a_checkpoint_and_a_resume(tmp_path):
     np.testing.assert_allclose(m.means_, g["final_means"], rtol=1e-12)
 
 
+@pytest.mark.skipif(not gco_ref.available(), reason="needs the reference gco (oracle/_ref)")
+def test_a_checkpoint_of_another_model_is_refused(tmp_path):
+    """The cost bookkeeping a checkpoint carries (cost_vec, min_cost, the stopping rule's previous costs) belongs to ONE
+    energy: a resume under another beta -- same states, species and block sizes -- or on other observations of the same shape
+    must say so instead of mixing two energies in one cost_vec."""
+    g = np.load(os.path.join(G, "em_trace.npz"))
+    ck = str(tmp_path / "trace.ckpt.npz")
+    m = make_model(g, checkpoint_path=ck)
+    m.fit_accumulate_test(g["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", 3)
+    g2 = {k: g[k] for k in g.files}
+    g2["beta"] = np.asarray(float(g["beta"]) * 2.0)
+    with pytest.raises(ValueError, match="another model or data.*beta"):
+        make_model(g2, resume_from=ck).fit_accumulate_test(g["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", 5)
+    g3 = {k: g[k] for k in g.files}
+    g3["X"] = g["X"] + 0.25
+    with pytest.raises(ValueError, match="another model or data.*observation"):
+        make_model(g3, resume_from=ck).fit_accumulate_test(g3["X"], g["len_vec"].tolist(), float(g["threshold"]), "golden", 5)
+
+
 def test_lpt_assignment_balances_and_is_deterministic():
     from phylo_hmrf_amd.dist import lpt_assign
     sizes = [12402690, 11729746, 1630146, 2059870, 1773136, 9046815, 7283121, 165600, 1300000]

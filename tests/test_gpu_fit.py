@@ -267,3 +267,43 @@ def test_checkpoint_and_resume_continue_the_fit_exactly(tmp_path, monkeypatch):
     with pytest.raises(ValueError):
         m.fit_accumulate_test(X, lens, 1e-12, "t", 6)
     m.close()
+
+
+def test_fit_surface_at_the_chr1_block_size():
+    """Row b4 at the headline size of ONE block: the product's own surface -- a phyloHMRF object built from host float64
+    samples, fit_accumulate_test driving the EM loop (phylo_hmrf_amd/base.py <-> reference base.py:301-455) -- on a
+    4,980-bin diagonal block (12,402,690 nodes: the chr1 block of the whole-genome 50 kb workload), K = 20, S = 4, graph
+    built on the device.  Five iterations: the return tuple has the reference's shapes, every cost is finite, t_labels (set
+    from iteration 3 on, base.py:422-426) comes back as float64 labels in [0, K) through the one-byte-per-label gather, and
+    the loop's own clocks say a warm EM iteration of this block stays under a quarter of a second (measured: ~15 ms)."""
+    import torch
+    from phylo_hmrf_amd import synthetic
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    from phylo_hmrf_amd.tree import PhyloTree
+    K, S, N = 20, 4, 4980
+    tree = PhyloTree(synthetic.tree_for(S))
+    rng = np.random.default_rng(0)
+    P = synthetic.sample_ou_params(rng, tree, K)
+    mu, cv = tree.mean_cov(P)
+    cv = cv + 1e-3 * np.eye(S)
+    Xd = synthetic.device_observations(torch, torch.device("cuda", 0), 1, N, N, True, K, mu, cv)
+    X = Xd.cpu().numpy().astype(np.float64)
+    del Xd
+    torch.cuda.empty_cache()
+    n = N * (N + 1) // 2
+    assert X.shape == (n, S)
+    len_vec = [[n, 0, n, N, N, 0, 0, 0, 1, 1]]
+    m = phyloHMRF(n_components=K, run_id=0, n_samples=n, n_features=S, observation=X, edge_list=synthetic.tree_for(S),
+                  len_vec=len_vec, type_id=1, branch_list=[1.0] * tree.branch_dim, edge_list_1=[None], cons_param=1.0, beta=1.0,
+                  beta1=0.5, initial_mode=0, initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, estimate_type=3,
+                  random_state=3, quiet=True, device_graph=True, init_method="device")
+    try:
+        params_vec, params_vec1, params_vecList, it1, it2, cost_vec, t_labels = m.fit_accumulate_test(X, len_vec, 0.0, "t", 5)
+        assert params_vec.shape == (K, tree.n_params) and params_vecList.shape == (5, K, tree.n_params)
+        assert cost_vec.shape == (5, 4) and np.all(np.isfinite(cost_vec))
+        assert t_labels.shape == (n,) and t_labels.dtype == np.float64
+        assert t_labels.min() >= 0 and t_labels.max() < K and len(np.unique(t_labels)) > K // 2
+        it_ms = np.asarray(m.timing_["iteration"]) * 1e3
+        assert len(it_ms) == 5 and np.all(it_ms[2:] < 250.0), it_ms
+    finally:
+        m.close()

@@ -203,3 +203,24 @@ def test_two_split_blocks_on_disjoint_rank_pairs_of_a_world_of_four(tmp_path):
             assert np.array_equal(got[bi][t], want[bi][1][t])
     # every member reported its block's energy: each block twice
     np.testing.assert_allclose(sums, [2 * (want[0][0]["energy"] + want[1][0]["energy"])] * 4, rtol=1e-12)
+
+
+def test_rccl_selftest_runs_over_gloo_with_forced_tile_groups():
+    """tools/rccl_selftest.py -- the first thing to run on a multi-GPU node -- on two gloo ranks here: the world's three
+    message shapes, and the tile sub-groups of cfg3 with blocks above 0.2 of a rank's share cut (so that groups exist at
+    world size 2); every rank finishes and rank 0's JSON line names the groups."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PHMRF_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "tools", "rccl_selftest.py"), "--rounds", "3", "--workloads", "cfg3",
+           "--split-above", "0.2"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rep["ranks_that_finished"] == 2 and rep["backend"] == "gloo"
+    assert any("E-step statistics" in k for k in rep["messages"]) and any("tile round" in k for k in rep["messages"])
+    g = rep["tile_groups"]["cfg3"]
+    assert g["split_blocks"] >= 1 and all(len(x["ranks"]) >= 1 for x in g["groups"])
