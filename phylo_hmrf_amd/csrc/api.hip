@@ -7,6 +7,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <random>
 
 #include "common.h"
 
@@ -268,6 +269,130 @@ int setup_grid_tables(phmrf_block* b, const Geometry& g, int num_neighbor) {
   b->num_neighbor = num_neighbor;
   b->has_grid = true;
   return launch_fwd_weights(b);          // grid-native edge weights of the strip kernels
+}
+
+// ---- path moves on a graph that is no grid (round 6) ------------------------------------------------------------------
+// The exact 1-D move of chain_kernel -- all K labels of <= 63 consecutive nodes, everything else fixed -- needs nothing of
+// a grid but two properties of its chains: inside a chain a node's only neighbours are its predecessor and its successor
+// (an INDUCED path), and chains that move at the same time share no edge.  On a general graph both are had by
+// construction: a path grows from a seed at either end by a neighbour that has exactly ONE neighbour among the nodes
+// already taken by this colour's paths (the end it is attached to); a seed has none.  `cnt` counts those neighbours, so a
+// path is induced and two paths of a colour are never adjacent.  Colours are filled one after the other, seeds and
+// extensions prefer nodes no earlier colour has covered, until every node is covered or MAX_PATH_COLOURS are full (what is
+// left keeps ICM and the component moves).  Four independent decompositions (fixed seeds: the tables are the same in every
+// run) fill the two cut phases of two pairs of chain families: a node meets four different paths per round pair.
+// Host-side, once per graph (O(colours x edges)); general graphs are not the reference's case -- its edge builders only
+// emit the contact-map stencil (utility.py:1871-2053) -- but they are what pygco.cut_general_graph accepts
+// (phylo_hmrf.py:496-498).
+constexpr int MAX_PATH_COLOURS = 6;          // per decomposition: two ChainFamily objects of three colours
+
+struct PathSet {
+  std::vector<int32_t> nodes;                // path after path
+  std::vector<int32_t> start, len, colour;   // per path
+};
+
+static void decompose_paths(int64_t n, int D, const std::vector<int32_t>& nbr, unsigned seed, PathSet* out) {
+  std::mt19937 gen(seed);
+  std::vector<char> covered(n, 0), inp(n, 0);
+  std::vector<int32_t> cnt(n, 0), order;
+  std::vector<int32_t> path, cand;
+  int64_t n_cov = 0;
+  for (int colour = 0; colour < MAX_PATH_COLOURS && n_cov < n; ++colour) {
+    std::fill(cnt.begin(), cnt.end(), 0);
+    std::fill(inp.begin(), inp.end(), 0);
+    order.clear();
+    for (int64_t v = 0; v < n; ++v)
+      if (!covered[v]) order.push_back((int32_t)v);
+    std::shuffle(order.begin(), order.end(), gen);
+    auto take = [&](int32_t v) {
+      inp[v] = 1;
+      const int32_t* c = &nbr[(size_t)v * D];
+      for (int x = 0; x < D && c[x] >= 0; ++x) ++cnt[c[x]];
+    };
+    for (int32_t s0 : order) {
+      if (inp[s0] || cnt[s0] != 0) continue;
+      path.assign(1, s0);
+      take(s0);
+      for (int side = 0; side < 2; ++side) {
+        while ((int)path.size() < 63) {
+          const int32_t e = side == 0 ? path.back() : path.front();
+          const int32_t* c = &nbr[(size_t)e * D];
+          cand.clear();
+          bool any_new = false;
+          for (int x = 0; x < D && c[x] >= 0; ++x)
+            if (!inp[c[x]] && cnt[c[x]] == 1) {
+              if (!covered[c[x]] && !any_new) {
+                cand.clear();
+                any_new = true;
+              }
+              if (!any_new || !covered[c[x]]) cand.push_back(c[x]);
+            }
+          if (cand.empty()) break;
+          const int32_t v = cand[gen() % cand.size()];
+          take(v);
+          if (side == 0) path.push_back(v);
+          else path.insert(path.begin(), v);
+        }
+      }
+      out->start.push_back((int32_t)out->nodes.size());
+      out->len.push_back((int32_t)path.size());
+      out->colour.push_back(colour);
+      for (int32_t v : path) {
+        out->nodes.push_back(v);
+        if (!covered[v]) {
+          covered[v] = 1;
+          ++n_cov;
+        }
+      }
+    }
+  }
+}
+
+int setup_path_families(phmrf_block* b) {
+  const int64_t n = b->n;
+  const int D = b->D;
+  std::vector<int32_t> nbr((size_t)n * D);
+  PHMRF_TRY(download(nbr.data(), b->nbr, nbr.size() * sizeof(int32_t), b->stream));
+  PHMRF_HIP(hipStreamSynchronize(b->stream));
+  for (auto& f : b->families) free_family(f);
+  b->families.clear();
+  for (int pair = 0; pair < 2; ++pair) {                 // decompositions (2 pair, 2 pair + 1) = cut phases 0 and 1 of families 2 pair, 2 pair + 1
+    PathSet ps[2];
+    for (int phase = 0; phase < 2; ++phase) decompose_paths(n, D, nbr, 0x9E3779B9u + 7919u * (unsigned)(2 * pair + phase), &ps[phase]);
+    for (int half = 0; half < 2; ++half) {               // colours 3 half .. 3 half + 2 of both decompositions
+      ChainFamily f;
+      f.n_colours = 3;
+      std::vector<int32_t> order;
+      std::vector<int32_t> ss[2][3], sl[2][3];
+      for (int phase = 0; phase < 2; ++phase)
+        for (size_t q = 0; q < ps[phase].start.size(); ++q) {
+          const int col = ps[phase].colour[q] - 3 * half;
+          if (col < 0 || col > 2 || ps[phase].len[q] < 2) continue;      // (a path of one node is an ICM step)
+          ss[phase][col].push_back((int32_t)order.size());
+          sl[phase][col].push_back(ps[phase].len[q]);
+          order.insert(order.end(), ps[phase].nodes.begin() + ps[phase].start[q],
+                       ps[phase].nodes.begin() + ps[phase].start[q] + ps[phase].len[q]);
+          f.max_len = std::max(f.max_len, (int)ps[phase].len[q]);
+          ++f.n_chains;
+        }
+      if (order.empty()) order.push_back(0);
+      PHMRF_TRY(dev_alloc(&f.nodes, order.size()));
+      PHMRF_TRY(upload(f.nodes, order.data(), order.size() * sizeof(int32_t), b->stream));
+      for (int phase = 0; phase < 2; ++phase)
+        for (int col = 0; col < 3; ++col) {
+          f.nseg[phase][col] = (int)ss[phase][col].size();
+          PHMRF_TRY(dev_alloc(&f.seg_start[phase][col], ss[phase][col].size()));
+          PHMRF_TRY(dev_alloc(&f.seg_len[phase][col], sl[phase][col].size()));
+          if (!ss[phase][col].empty()) {
+            PHMRF_TRY(upload(f.seg_start[phase][col], ss[phase][col].data(), ss[phase][col].size() * sizeof(int32_t), b->stream));
+            PHMRF_TRY(upload(f.seg_len[phase][col], sl[phase][col].data(), sl[phase][col].size() * sizeof(int32_t), b->stream));
+          }
+        }
+      PHMRF_HIP(hipStreamSynchronize(b->stream));         // (the host vectors go out of scope)
+      b->families.push_back(f);
+    }
+  }
+  return PHMRF_OK;
 }
 
 }  // namespace
@@ -1404,7 +1529,9 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
     PHMRF_TRY(energy_now(b, beta, &s->eu0, &s->ep0));
     s->have_init_energy = true;
   }
-  s->chains = o.use_chains && b->has_grid;
+  // a graph without grid geometry gets its path families at its first solve (setup_path_families: once per graph)
+  if (o.use_chains && !b->has_grid && b->families.empty() && b->nbr && b->n >= 2) PHMRF_TRY(setup_path_families(b));
+  s->chains = o.use_chains && (b->has_grid || !b->families.empty());
   s->strips = o.use_strips && b->has_grid;
   s->tol = o.min_changed > 0 ? o.min_changed : 0;
   const int K = b->K;
@@ -1519,7 +1646,7 @@ int solve_round_launch(phmrf_block_t b) {
     // K=10 cold start even ends 2e-4 LOWER and in 12 rounds instead of 32 (1-D moves leave row / column streaks that
     // the 2-D moves then have to undo) -- and they were 14 % of the device time.  Without strip expansions (general
     // graphs have no chains at all; `use_expansion = 0`) rows and columns run in every round as before.
-    const int n_ord_fams = s->expansions ? 0 : 2;
+    const int n_ord_fams = s->expansions ? 0 : (b->has_grid ? 2 : s->n_fam);     // (path families of a general graph: all of them)
     int n_chain = 0;
     for (int f = 0; f < s->n_fam; ++f)
       if (active[72 + f] && (f < n_ord_fams || verifying)) n_chain += b->families[f].n_colours;
@@ -1531,14 +1658,16 @@ int solve_round_launch(phmrf_block_t b) {
           ran[72 + f] = 1;
           // cut phase 0 in ordinary rounds (so the segment memo applies from the second round on); the other set of
           // separators is used by the verification rounds
-          PHMRF_TRY(chain_sweep_nocount(b, bf, f, verifying ? 1 : 0, false));
+          // (the path families of a general graph hold two independent decompositions as their two phases: they take
+          //  turns round by round, so the round that verifies a quiet one always looks along the other set of paths)
+          PHMRF_TRY(chain_sweep_nocount(b, bf, f, b->has_grid ? (verifying ? 1 : 0) : (s->rounds & 1), false));
         }
       toc(b, KC_CHAIN, n_chain);
     }
   }
   // single-site ICM: every strip cell and every chain node is already optimal given the rest, so ICM only earns its
   // launches on the fixed separator cells; it runs in verification rounds and on graphs without grid moves
-  if (active[76] && (verifying || !(s->chains || s->strips))) {
+  if (active[76] && (verifying || !(s->chains || s->strips) || !b->has_grid)) {
     b->counter_slot = 76;
     ran[76] = 1;
     PHMRF_TRY(icm_sweep_nocount(b, bf));
@@ -1547,7 +1676,7 @@ int solve_round_launch(phmrf_block_t b) {
   // blocks they run in a solve's first round, after a round that moved the labelling at large, and in verification
   // rounds; the mop-up rounds in between (a few hundred changed labels, of which the pass would take a dozen) skip
   // them.  On general graphs, where they are one of two move types, they run in every round.
-  const bool comp_round = s->rounds == 0 || verifying || s->prev_moving || !(s->chains || s->strips);
+  const bool comp_round = s->rounds == 0 || verifying || s->prev_moving || !(s->chains || s->strips) || !b->has_grid;
   // (after a round that moved the labelling at large the pass runs whether or not it was rested: its last count is old)
   if (o.use_components && (active[77] || s->prev_moving) && comp_round) {
     b->counter_slot = 77;
