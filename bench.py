@@ -30,7 +30,7 @@ Extra objects on the JSON line:
                       `kernels` is filled by an instrumented pass after it.
   "roofline_limiter"  what actually bounds that kernel, from this run's device counters only (LDS bytes, pairs, cells, DP
                       steps); the explanation -- instruction issue of in-order waves at 4 waves per SIMD -- and the
-                      measurements behind it are in DESIGN.md 3.3 and profiles/README.md.
+                      measurements behind it are in HISTORY.md 3.3 and profiles/README.md.
   "cpu_baseline"      (rank 0, N=1) the reference's CPU path on a bounded sample -- see cpu_baseline().
   "cold_first_iteration_ms"  the first EM iteration of the warm-up (from argmax labels; child blocks allocated).
   "fit"               the whole fit under the reference's own stopping rules, run after the timed region (not part of
@@ -791,7 +791,7 @@ def main():
                                 "note": "device counters of this run only.  The expansion kernel is bound neither by HBM nor "
                                         "by the LDS pipe: an exact filter settles most (strip, label) pairs in ~500 vector "
                                         "and ~300 scalar instructions, and a SIMD issues at most ~0.4 of either per cycle "
-                                        "(tools/ubench/issue.hip); the measurements behind this are in DESIGN.md 3.3 and "
+                                        "(tools/ubench/issue.hip); the measurements behind this are in HISTORY.md 3.3, DESIGN.md 3.2 and "
                                         "profiles/README.md, not repeated in this line"}
     kernels = {k: {"ms": round(v[0], 3), "launches": int(v[1]), "busy_ms": round(busy.get(k, 0.0), 3),
                    "GBps": (round(v[2] / (busy[k] * 1e-3) / 1e9, 1) if busy.get(k, 0) > 0 and v[2] > 0 else None)}

@@ -175,7 +175,7 @@ typedef struct phmrf_solve_opts {
                           argmax_k logprob.  Only the START of the solve changes (8-neighbour grid blocks of >= 1,024
                           nodes that are not row tiles; otherwise ignored).  0 (default): off -- measured in round 5 on
                           the synthetic Hi-C workloads: the prolongated coarse labelling starts HIGHER than argmax + one
-                          ICM sweep and the solve is slower, so nothing in the fit or the bench uses it */
+                          ICM sweep and the solve is slower (HISTORY.md 3.1), so nothing in the fit or the bench uses it */
 } phmrf_solve_opts;
 
 typedef struct phmrf_solve_result {
@@ -249,7 +249,7 @@ PHMRF_API int phmrf_block_prepare_components(phmrf_block_t b);
 PHMRF_API int phmrf_mrf_strip_pass(phmrf_block_t b, double beta, int orient, int shift_r, int shift_c, int alpha,
                                    int64_t* changed);
 /* Every strip alpha-expansion of the labels named by the bits of label_mask on one cut, in ascending label order, in ONE
- * launch (strip_multi_kernel: a wave owns a strip, stages it once and runs the labels back to back; an exact filter
+ * launch (strip_cols_kernel: a wave owns a strip, stages it once and runs the labels back to back; an exact filter
  * settles most (strip, label) pairs without the DP).  Same result, label for label, as the phmrf_mrf_strip_pass calls
  * of those labels in that order.  Replaces the K swap-cycle inner loops of gco's swap()
  * (GCoptimization.cpp:1282-1394) inside phmrf_mrf_solve. */
@@ -322,7 +322,7 @@ PHMRF_API int phmrf_block_reset_timing(phmrf_block_t b);
  *   out[1] their strip cells (the nodes a unit re-decides: 5 x columns)
  *   out[2] grid cells staged (strip + fixed rim, 7 x (columns + 2): what a unit reads from HBM)
  *   out[3] DP steps walked (one 64-state step = one cell of one unit)   out[4] strip launches
- *   strip_multi_kernel (all labels of a strip in one wave) counts a (strip, label) pair in out[0] and, instead of
+ *   strip_cols_kernel (all labels of a strip in one wave) counts a (strip, label) pair in out[0] and, instead of
  *   out[1]:  out[5] the strip cells it swept (once per strip visit, whatever the number of labels),
  *            out[6] cells x labels examined (one label's unary term per cell)
  *   out[7] nodes whose fusion proposal was recomputed (the proposal kernels skip node tiles without a new change stamp)  */

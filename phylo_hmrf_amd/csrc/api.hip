@@ -1742,7 +1742,7 @@ int solve_round_launch(phmrf_block_t b) {
   // changed nothing in its last run is left out until the scale is switched on afresh (a round that moved the labelling at
   // large), a verification round or the forced last say runs all labels again.  A coarse round costs what its labels cost
   // -- a share of the coarsen pass, two child strip passes and an apply pass each --, and after the first coarse round of a
-  // cold or far-off solve a few labels per scale are still moving (measured: DESIGN.md 3.1).  Row tiles keep every label
+  // cold or far-off solve a few labels per scale are still moving (measured: HISTORY.md 3.1 item 6, round 5).  Row tiles keep every label
   // (their schedule runs on sums over the tiles; the per-label counts are local).
   const bool rest_coarse_labels = !(b->tile_top || b->tile_bot) && o.energy_tol_ppb > 0;
   if (s->coarse) {

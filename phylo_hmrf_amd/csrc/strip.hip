@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * PHMRF_STRIP_WPB, PHMRF_STRIP_WPE) void strip_k
           if (my_memo && lane == 0) *my_memo = (uint16_t)tick;
           continue;
         }
-        // ---- a one-hop flow certificate for those cells.  With every cell at "keep", a switch set S costs
+        // ---- a one-hop flow certificate for those cells (HISTORY.md 3.1 item 6 (v)).  With every cell at "keep", a switch set S costs
         //      sum_S D + cut(S).  Let every cell A with D_A < 0 ship f_AB <= lambda_AB to neighbours B with D_B > 0, each B
         //      taking in at most D_B in all.  If A can ship its whole deficit (sum_B f_AB >= -D_A) it is SETTLED, and a set S
         //      whose negative cells are all settled costs sum_S D + cut(S) >= -sum_{A in S, B not in S} f_AB + cut(S) >= 0 (what
@@ -2239,7 +2239,7 @@ static int peel_sweeps() {   // PHMRF_PEEL_SWEEPS=0 switches the filter off (tim
   return v;
 }
 static bool scan_enabled() {        // PHMRF_SCAN=1: strip_scan_kernel in front of every strip launch of a solve (a measured negative,
-  static const bool on = PHMRF_DEV_ENV("PHMRF_SCAN") != nullptr || PHMRF_DEV_ENV("PHMRF_SEED_MASKS") != nullptr;   // DESIGN.md 3.3 round 6)
+  static const bool on = PHMRF_DEV_ENV("PHMRF_SCAN") != nullptr || PHMRF_DEV_ENV("PHMRF_SEED_MASKS") != nullptr;   // DESIGN.md 3.2)
   return on;
 }
 static int mopup_grid() {           // PHMRF_MOPUP_GRID=n: workgroups of a strip launch in the rounds after a solve's first (0: one per slot)
@@ -2250,7 +2250,7 @@ static int mopup_grid() {           // PHMRF_MOPUP_GRID=n: workgroups of a strip
   }
   return v;
 }
-static bool seed_masks_enabled() {  // PHMRF_SEED_MASKS=1: the scan also uses the seed masks (a measured negative, DESIGN.md 3.3: kept
+static bool seed_masks_enabled() {  // PHMRF_SEED_MASKS=1: the scan also uses the seed masks (a measured negative, DESIGN.md 3.2: kept
   static const bool on = PHMRF_DEV_ENV("PHMRF_SEED_MASKS") != nullptr;   // for the A/B -- the labellings must not differ)
   return on;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The BENCHED regime (bench.py's default: 26 blocks, 14 in flight) under rocprofv3, two passes of the same command
-    python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-kernel-timing
+    python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-kernel-timing
 
   KT_DIR   rocprofv3 --kernel-trace                      (concurrent streams as benched: where each stream's time goes)
   PMC_DIR  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE
@@ -53,7 +53,7 @@ def main():
     kt_dir, pmc_dir, bench_json, out_path = sys.argv[1:5]
     per_iter = int(sys.argv[5]) if len(sys.argv) > 5 else 26
     first = int(sys.argv[6]) if len(sys.argv) > 6 else 6
-    out = {"command": "python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-kernel-timing"}
+    out = {"command": "python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-kernel-timing"}
     bench = None
     try:
         bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
@@ -67,7 +67,7 @@ def main():
     kt.sort(key=lambda r: int(r["Start_Timestamp"]))
     if kt:
         it = iteration_index(kt, per_iter)
-        steady = [(r, i) for r, i in zip(kt, it) if i >= first]
+        steady = [(r, i) for r, i in zip(kt, it) if first <= i < first + 4]      # (the 4 timed steps)
         iters = sorted({i for _, i in steady})
         n_it = max(len(iters), 1)
         t_lo = min(int(r["Start_Timestamp"]) for r, _ in steady)
@@ -124,7 +124,7 @@ def main():
         fam, tot = {}, {}
         iters = set()
         for r, i in zip(ds, it):
-            if i < first:
+            if i < first or i >= first + 4:
                 continue
             iters.add(i)
             k = family(short(r["Kernel_Name"]))
@@ -138,11 +138,11 @@ def main():
         n_it = max(len(iters), 1)
         res = {}
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
-            busy = v.get("SQ_BUSY_CYCLES", 0.0) / XCDS          # (summed over the XCDs' SQs)
+            busy = v.get("GRBM_GUI_ACTIVE", 0.0) / XCDS        # (the counter is summed over the 8 XCDs)
             res[k] = {"dispatches_per_iteration": round(v["dispatches"] / n_it, 1),
                       "SQ_INSTS_VALU_per_iteration": int(v.get("SQ_INSTS_VALU", 0) / n_it),
                       "SQ_WAVES_per_iteration": int(v.get("SQ_WAVES", 0) / n_it),
-                      "active_clocks_per_iteration (SQ_BUSY_CYCLES / 8)": int(busy / n_it),
+                      "active_clocks_per_iteration (GRBM_GUI_ACTIVE / 8)": int(busy / n_it),
                       "valu_pipe_busy_own (INSTS_VALU x 4 / (active clocks x 1024 SIMDs))":
                           round(v.get("SQ_INSTS_VALU", 0) * 4.0 / max(busy * SIMDS, 1), 4)}
         out["counters"] = {"steady_iterations": n_it, "per_family": res,

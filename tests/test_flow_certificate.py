@@ -1,4 +1,4 @@
-"""The one-hop flow certificate of the coarse child strips (strip_kernel's look), checked by brute
+"""The one-hop flow certificate of the coarse child strips (strip_kernel's look, HISTORY.md 3.1 item 6 (v)), checked by brute
 force on small problems (CPU, NumPy): whenever every negative cell of a switch set S is SETTLED by the rule the kernel uses,
 S costs at least 0 -- so a strip whose negative cells are all settled has nothing better than all-keep."""
 import itertools

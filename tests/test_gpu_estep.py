@@ -955,7 +955,7 @@ def test_strip_scan_and_seed_masks_leave_the_labellings_alone():
     test, OR-ed over a strip by the scan.  (c) is exact, too, but settles little -- the fusion pass and the other orientation's
     expansions run between the proposals' launch and the strip launch and leave a stamp in nearly every strip, which voids
     the strip's masks; and (b) costs what it saves, the floor of a mop-up launch being one wave's walk through its strip's
-    labels, not the look at the stamps -- so both are development options (DESIGN.md 3.3, round 6), off in the product."""
+    labels, not the look at the stamps -- so both are development options (DESIGN.md 3.2), off in the product."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,6 @@
 """CPU: `roofline.frac` of the bench line is the dominant kernel's own fraction of the HBM roofline, and it can be recomputed
-from the committed profile pair of ONE run (profiles/r5_bench_under_rocprof_serial.json = the JSON line of
-`rocprofv3 --kernel-trace --stats -- python3 bench.py --block-threads 1 ...`, profiles/r5_kernel_stats_serial.csv = that
+from the committed profile pair of ONE run (profiles/r6_bench_under_rocprof_serial.json = the JSON line of
+`rocprofv3 --kernel-trace --stats -- python3 bench.py --block-threads 1 ...`, profiles/r6_kernel_stats_serial.csv = that
 run's per-kernel summary): algorithmic bytes per launch (SURVEY.md 8d accounting x device-counted cells, from the line) over
 the kernel's average duration in the profiler's summary, against the same peak.  The two must agree within 10 %
 (the summary also holds the launches of the cold warm-up iteration and of the passes after the timed region, whose mix of
@@ -12,12 +12,12 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r5_bench_under_rocprof_serial.json")
-STATS = os.path.join(ROOT, "profiles", "r5_kernel_stats_serial.csv")
+LINE = os.path.join(ROOT, "profiles", "r6_bench_under_rocprof_serial.json")
+STATS = os.path.join(ROOT, "profiles", "r6_kernel_stats_serial.csv")
 
 
 def _load():
-    assert os.path.exists(LINE) and os.path.exists(STATS), "profiles/r5_bench_under_rocprof_serial.json / r5_kernel_stats_serial.csv missing"
+    assert os.path.exists(LINE) and os.path.exists(STATS), "profiles/r6_bench_under_rocprof_serial.json / r5_kernel_stats_serial.csv missing"
     d = json.loads(open(LINE).read().strip().splitlines()[-1])
     rows = list(csv.DictReader(open(STATS)))
     return d, rows
@@ -53,3 +53,28 @@ def test_frac_is_bytes_over_own_durations_and_its_parts_add_up():
     assert full["bytes"] / full["launches"] > mop["bytes"] / max(mop["launches"], 1)
     assert full["GBps"] > (mop["GBps"] or 0.0)
     assert d["build"]["source_hash"]
+
+
+def test_valu_on_the_line_follows_from_the_committed_counter_pass():
+    """Round 6: `roofline.valu.busy` -- the dominant kernel's share of the vector pipes' issue capacity -- is
+    SQ_INSTS_VALU x 4 clocks / (GRBM_GUI_ACTIVE / 8 XCDs x 1,024 SIMDs) over the kernel's dispatches in the committed
+    rocprofv3 --pmc pass (profiles/pmc_by_kernel.json, `valu` per kernel name), and `bound` names whichever of it and the HBM
+    fraction is the higher.  Recomputed here from the raw counters; the pass's own clock (active clocks / kernel duration) must
+    be a plausible MI355X clock, which checks the / 8."""
+    d, _ = _load()
+    r = d["roofline"]
+    pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_by_kernel.json")))
+    insts = clocks = ns = 0.0
+    for name, rec in pk["kernels"].items():
+        v = rec.get("valu")
+        if v and any(name.startswith(k) for k in r["kernel_names"]):
+            insts += v["sq_insts_valu"]
+            clocks += v["active_clocks"]
+            ns += v["duration_ns"]
+    assert clocks > 0, "no SQ_INSTS_VALU pass in profiles/pmc_by_kernel.json (profiles/run_pmc_by_kernel.sh)"
+    busy = insts * 4.0 / (clocks * 1024.0)
+    assert 0.2 < busy < 1.0, busy
+    assert 1.2 < clocks / ns < 3.0, clocks / ns                     # GHz
+    if pk["source_hash"] == d["build"]["source_hash"]:               # the line was written by the build the pass profiled
+        assert r["valu"]["busy"] is not None and abs(r["valu"]["busy"] - busy) <= 0.02 * busy, (r["valu"], busy)
+        assert r["bound"] == ("valu" if busy > r["frac"] else "hbm")

@@ -1,5 +1,5 @@
 """Development experiment (GPU box; the arithmetic is NumPy): how many child strips of a coarse alpha-expansion could a ONE-HOP
-FLOW certificate settle before the DP?    With every cell at "keep", a switch set S costs sum_S D + cut(S).
+FLOW certificate settle before the DP?  (HISTORY.md 3.1 item 6 (v).)  With every cell at "keep", a switch set S costs sum_S D + cut(S).
 If every cell with D < 0 can ship its deficit -D to neighbouring cells with D > 0 along the edges (at most lambda per edge, at
 most D_B into cell B in all), no switch set costs less than 0.  Split rule tested: a cell with surplus offers each of its
 negative neighbours min(lambda, D_B / number of negative neighbours).  Prints, per scale, the share of 5 x 63 strips that
