@@ -31,7 +31,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # bound names whichever of the two figures is the higher for the dominant kernel; achieved / peak / frac stay the HBM ones.
+    # (valu.busy comes from a committed counter pass of cfg3 with this build's source hash: on this small workload it is None
+    #  and says why, so the bound is the HBM one)
+    assert r["bound"] in ("hbm", "mfma", "valu") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "busy" in r["valu"] and "source" in r["valu"] and (r["valu"]["busy"] is not None or r["bound"] == "hbm")
     # frac is the KERNEL's fraction: bytes over the launches' own durations, full sweeps and mop-up launches apart
     full, mop = r["full_sweep"], r["mop_up"]
     assert r["own_durations_from"] and full["launches"] > 0 and full["bytes"] > 0 and full["own_ms"] > 0
@@ -51,6 +55,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for f in (d["fit"], d["fit_reference_start"]):
         assert f["iterations"] >= 1 and f["value"] > 0 and len(f["estep_ms"]) == f["iterations"]
     assert d["build"]["source_hash"]
+    # (round 6) the same iterations through the product's own loop, and every rank's own clocks
+    fs = d["fit_surface"]
+    assert fs["iterations_timed"] == 2 and fs["warmup"] == 1 and fs["ms_per_step"] > 0 and len(fs["ms_per_step_by_iteration"]) == 3
+    assert abs(fs["ratio_to_ms_per_step"] - fs["ms_per_step"] / d["ms_per_step"]) < 1e-3 and len(fs["cost1"]) == 3
+    pr = d["per_rank"]
+    assert len(pr["estep_ms"]) == 1 and abs(pr["estep_ms"][0] - d["estep_ms"]) < 1e-2 and pr["nodes"] == d["config"]["nodes_per_rank"]
     if r["kernel"] in ("strip", "fusion"):
         lim = d["roofline_limiter"]
         # device-counted work: (strip, label) pairs, cells swept once per strip visit, one unary entry per cell and label
