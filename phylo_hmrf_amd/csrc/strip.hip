@@ -761,16 +761,20 @@ constexpr int SLABW = (63 + 2) * SWC;        // floats
 constexpr int SLABL = ((63 + 2) * EH + 3) / 4 * 4;   // label bytes
 constexpr int CH = 18;                       // cells per table chunk: three groups of six DP steps
 constexpr int NBUF = 8;                      // flagged labels buffered before the wave turns to the DP
-// everything strip_cols_kernel keeps in LDS (one wave per workgroup): 9.9 KB
-struct ColsLds {
+// everything strip_cols_kernel keeps in LDS: 9.9 KB with one wave per workgroup (WV = 1: the full sweeps), 11 KB with WV = 4
+// waves that share one staged strip and split its labels (round 6: the launches of a solve's late rounds, strip_cols_kernel)
+template <int WV>
+struct ColsLdsT {
   alignas(16) float tabch[CH * 36];          // DP tables of one chunk (2.6 KB; 36 = TAB)
   alignas(16) float slabw[SLABW];            // the staged rectangle, never overwritten: forward weights ...
-  unsigned long long ubuf[NBUF][SH];         // U of the flagged labels, one word per strip row
-  int abuf[NBUF];                            // ... and which labels they are
+  unsigned long long ubuf[WV * NBUF][SH];    // U of the flagged labels, one word per strip row (NBUF entries per wave)
+  int abuf[WV * NBUF];                       // ... and which labels they are
   unsigned int wk[WORK_SLOTS];
-  int nbuf;
+  int nbuf[WV];                              // flagged labels per wave
+  unsigned long long left[WV];               // WV > 1: the labels a wave did not get to (its buffer was full)
   unsigned char slabl[SLABL];                // ... and label bytes of the staged rectangle
 };
+using ColsLds = ColsLdsT<1>;
 
 // ... and of fusion_cols_kernel: the same, plus the proposal byte of every staged cell
 struct FusLds {
@@ -991,7 +995,7 @@ __device__ __forceinline__ void slab_record(const float* slabw, const unsigned c
 #ifndef PHMRF_DP_INLINE
 #define PHMRF_DP_INLINE __noinline__
 #endif
-template <int ORIENT, bool FUSION>
+template <int ORIENT, bool FUSION, int WV = 1>
 __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds, int kb, int lane,
                                                    int rs0, int ca, int ncols, int ncell, int alpha, int tick_a, int64_t n, int D,
                                                    const int32_t* nbr_, const float* uT_, uint8_t* labels_, uint16_t* stamp_,
@@ -1001,7 +1005,7 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
     const global_ptr<uint8_t> labels = as_global(labels_);
     const global_ptr<uint16_t> stamp = as_global(stamp_);
     const global_ptr<uint16_t> mslot = as_global(mslot_);       // this move's memo entry (label alpha's, or the fusion pass's)
-    ColsLds* L = lds_object<ColsLds>(lds);
+    ColsLdsT<WV>* L = lds_object<ColsLdsT<WV>>(lds);
     const float* slabw = L->slabw;
     const unsigned char* slabl = L->slabl;
     const unsigned char* slabp = FUSION ? lds_object<FusLds>(lds)->slabp : L->slabl;
@@ -1181,19 +1185,20 @@ __device__ PHMRF_DP_INLINE unsigned int dp_flagged(StripGeom g, unsigned int lds
 #ifndef PHMRF_FILTER_INLINE
 #define PHMRF_FILTER_INLINE __forceinline__
 #endif
-template <int ORIENT>
+template <int ORIENT, int WV = 1>
 __device__ PHMRF_FILTER_INLINE unsigned long long filter_phase(StripGeom g, unsigned int lds, int lane, int rs0_, int ca_, int ncols_, int ncell_,
                                                              unsigned long long v0_, unsigned long long v1_, unsigned long long v2_,
                                                              unsigned long long v3_, unsigned long long v4_, unsigned long long todo_,
-                                                             int64_t n, const float* uT_, uint16_t* mrow_, int tick0_, int peel_max_) {
+                                                             int64_t n, const float* uT_, uint16_t* mrow_, int tick0_, int peel_max_,
+                                                             int wslot = 0) {
     const global_ptr<const float> uT = as_global(uT_);
     const global_ptr<uint16_t> mrow = as_global(mrow_);
-    ColsLds* L = lds_object<ColsLds>(lds);
+    ColsLdsT<WV>* L = lds_object<ColsLdsT<WV>>(lds);
     const float* slabw = L->slabw;
     const unsigned char* slabl = L->slabl;
-    unsigned long long (*ubuf)[SH] = L->ubuf;
-    int* abuf = L->abuf;
-    int* nbuf_out = &L->nbuf;
+    unsigned long long (*ubuf)[SH] = L->ubuf + (WV > 1 ? wslot * NBUF : 0);      // (this wave's share of the buffer)
+    int* abuf = L->abuf + (WV > 1 ? wslot * NBUF : 0);
+    int* nbuf_out = &L->nbuf[WV > 1 ? wslot : 0];
     unsigned int* wk = L->wk;
 #define PHMRF_UNI64(x) (((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)((x) >> 32)) << 32) | \
                         (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(x)))
@@ -1605,8 +1610,8 @@ __global__ __launch_bounds__(256) void strip_scan_kernel(StripGeom g, int K, uns
 #ifndef PHMRF_COLS_WPE
 #define PHMRF_COLS_WPE 4
 #endif
-template <int ORIENT>
-__global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeom g, int64_t n, int K, int D,
+template <int ORIENT, int WV = 1>
+__global__ __launch_bounds__(64 * WV, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeom g, int64_t n, int K, int D,
                                                                          const int32_t* __restrict__ nbr,
                                                                          const float4* __restrict__ fwd_w,
                                                                          const float* __restrict__ uT, uint8_t* __restrict__ labels,
@@ -1615,7 +1620,7 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
                                                                          uint16_t* __restrict__ stamp, uint16_t* __restrict__ memo,
                                                                          int tick0, unsigned long long* __restrict__ work, int peel_max,
                                                                          const unsigned long long* __restrict__ scan) {
-  __shared__ ColsLds lds_pool;
+  __shared__ ColsLdsT<WV> lds_pool;
   float* slabw = lds_pool.slabw;
   unsigned char* slabl = lds_pool.slabl;
   int* abuf = lds_pool.abuf;
@@ -1700,78 +1705,160 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
     todo_full = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo_full >> 32)) << 32) |
                 (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo_full);
     if (!todo || !(valid[0] | valid[1] | valid[2] | valid[3] | valid[4])) continue;
+    auto stage_strip = [&]() {
+      // ---- staging (as strip_kernel, step A): labels and forward weights of the strip's rectangle and rim -> LDS
+      constexpr int NEP = (ECELLS + 63) / 64;
+      int enode[NEP], eidx[NEP];
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {
+        int er, ec;
+        if (ORIENT == 0) {
+          int l2 = lane;
+          asm volatile("" : "+v"(l2));
+          er = q < EH ? q : l2;
+          ec = q < EH ? l2 : 64;
+          if (q >= EH && l2 >= EH) ec = 1 << 20;
+        } else {
+          int e = q * 64 + lane;
+          asm volatile("" : "+v"(e));
+          ec = e / EH;
+          er = e - ec * EH;
+        }
+        const bool have = ec < ncols + 2;
+        eidx[q] = have ? ec * EH + er : -1;
+        enode[q] = have ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
+      }
+      int elab[NEP];
+      float4 ef[NEP];
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {
+        const int node = enode[q];
+        elab[q] = 0;
+        ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node >= 0) {
+          elab[q] = labels[node];
+          ef[q] = fwd_w[node];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NEP; ++q) {
+        const int e = eidx[q];
+        if (e >= 0) {
+          const int ec = e / EH, er = e - ec * EH;
+          float* wr = slabw + ec * SWC + er * 4;
+          if (er < EH - 1) {
+            wr[0] = ef[q].x * beta;
+            wr[1] = ef[q].y * beta;
+            wr[2] = ef[q].z * beta;
+            wr[3] = ef[q].w * beta;
+          } else {
+            // the bottom rim row holds one edge the strip needs, and only in orientation 1: its cells' grid edge (+1, -1),
+            // which runs to strip row 4 of the next column; it lives in the column's 25th word
+            wr[0] = ef[q].y * beta;
+          }
+          slabl[e] = (unsigned char)(enode[q] >= 0 ? elab[q] : 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+#if !defined(PHMRF_PHASE_CLOCK) && !defined(PHMRF_FILTER_STATS)
+        atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
+        atomicAdd(&wk[4], (unsigned int)ncell);
+#endif
+      }
+    };
     bool staged = false;
+    if constexpr (WV > 1) {
+      // ---- WV waves on ONE strip (the launches of a solve's late rounds, where a handful of dirty strips is all there is and
+      //      a launch takes as long as one wave needs to walk one strip's labels in sequence).  Wave 0 stages the strip; every
+      //      wave runs the exact FILTER of every WV-th listed label on the staged labelling -- read-only work, so the verdicts
+      //      are those of the sequential order as long as nothing has moved --; then wave 0 alone runs the DPs of the flagged
+      //      labels in ascending order.  The first DP that moves a cell makes every later verdict stale: from there on wave 0
+      //      continues as the one-wave kernel does, filtering every later label again (the memo entries the other waves
+      //      wrote for those labels are overwritten by that second look: its stores come after theirs, fence + barrier).
+      //      Label for label the launch is the one-wave launch.
+      const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      if (wave == 0) stage_strip();
+      staged = true;
+      __syncthreads();
+      unsigned long long mine = 0ull;
+      {
+        unsigned long long t = todo;
+        int i = 0;
+        while (t) {
+          const int a = __ffsll((long long)t) - 1;
+          t &= t - 1ull;
+          if ((i++ % WV) == wave) mine |= 1ull << a;
+        }
+      }
+      unsigned long long left = 0ull;
+      if (mine) {
+        left = filter_phase<ORIENT, WV>(g, lds, lane, rs0, ca, ncols, ncell, valid[0], valid[1], valid[2], valid[3], valid[4], mine, n,
+                                        uT, mrow, tick0, peel_max, wave);
+        left = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(left >> 32)) << 32) |
+               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)left);
+      } else if (lane == 0) {
+        lds_pool.nbuf[wave] = 0;
+      }
+      if (lane == 0) lds_pool.left[wave] = left;
+      __threadfence();
+      __syncthreads();
+      unsigned long long rest = 0ull;
+      if (wave == 0) {
+        // labels nobody has looked at (a wave's buffer of flagged labels was full: rare) bound the merged pass from above
+        unsigned long long unl = 0ull;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) unl |= lds_pool.left[w];
+        unl = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unl >> 32)) << 32) |
+              (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)unl);
+        const int cut = unl ? __ffsll((long long)unl) - 1 : 64;
+        int head[WV], cnt[WV];
+#pragma unroll
+        for (int w = 0; w < WV; ++w) {
+          head[w] = 0;
+          cnt[w] = __builtin_amdgcn_readfirstlane(lds_pool.nbuf[w]);
+        }
+        rest = cut < 64 ? (todo & ~((1ull << cut) - 1ull)) : 0ull;
+        for (;;) {
+          int bw = -1, ba = 64;
+#pragma unroll
+          for (int w = 0; w < WV; ++w)
+            if (head[w] < cnt[w]) {
+              const int a = __builtin_amdgcn_readfirstlane(lds_pool.abuf[w * NBUF + head[w]]);
+              if (a < ba) {
+                ba = a;
+                bw = w;
+              }
+            }
+          if (bw < 0 || ba >= cut) break;
+          int kb = 0;
+#pragma unroll
+          for (int w = 0; w < WV; ++w)
+            if (w == bw) kb = w * NBUF + head[w]++;
+          const unsigned int my_changed = dp_flagged<ORIENT, false, WV>(g, lds, kb, lane, rs0, ca, ncols, ncell, ba, tick0 + ba, n, D, nbr, uT,
+                                                                        labels, stamp, mrow ? mrow + ba : nullptr, changed + ba);
+          if (my_changed) {
+            __threadfence();
+            rest = todo_full & ~((2ull << ba) - 1ull);
+            break;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      todo = rest;                             // (waves 1 .. WV - 1: nothing; wave 0: what is left for the sequential loop)
+    }
 
     while (todo) {
       if (!staged) {
-        // ---- staging (as strip_kernel, step A): labels and forward weights of the strip's rectangle and rim -> LDS
-        constexpr int NEP = (ECELLS + 63) / 64;
-        int enode[NEP], eidx[NEP];
-#pragma unroll
-        for (int q = 0; q < NEP; ++q) {
-          int er, ec;
-          if (ORIENT == 0) {
-            int l2 = lane;
-            asm volatile("" : "+v"(l2));
-            er = q < EH ? q : l2;
-            ec = q < EH ? l2 : 64;
-            if (q >= EH && l2 >= EH) ec = 1 << 20;
-          } else {
-            int e = q * 64 + lane;
-            asm volatile("" : "+v"(e));
-            ec = e / EH;
-            er = e - ec * EH;
-          }
-          const bool have = ec < ncols + 2;
-          eidx[q] = have ? ec * EH + er : -1;
-          enode[q] = have ? strip_node(g, rs0 - 1 + er, ca - 1 + ec) : -1;
-        }
-        int elab[NEP];
-        float4 ef[NEP];
-#pragma unroll
-        for (int q = 0; q < NEP; ++q) {
-          const int node = enode[q];
-          elab[q] = 0;
-          ef[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (node >= 0) {
-            elab[q] = labels[node];
-            ef[q] = fwd_w[node];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < NEP; ++q) {
-          const int e = eidx[q];
-          if (e >= 0) {
-            const int ec = e / EH, er = e - ec * EH;
-            float* wr = slabw + ec * SWC + er * 4;
-            if (er < EH - 1) {
-              wr[0] = ef[q].x * beta;
-              wr[1] = ef[q].y * beta;
-              wr[2] = ef[q].z * beta;
-              wr[3] = ef[q].w * beta;
-            } else {
-              // the bottom rim row holds one edge the strip needs, and only in orientation 1: its cells' grid edge (+1, -1),
-              // which runs to strip row 4 of the next column; it lives in the column's 25th word
-              wr[0] = ef[q].y * beta;
-            }
-            slabl[e] = (unsigned char)(enode[q] >= 0 ? elab[q] : 0);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-#if !defined(PHMRF_PHASE_CLOCK) && !defined(PHMRF_FILTER_STATS)
-          atomicAdd(&wk[2], (unsigned int)(EH * (ncols + 2)));
-          atomicAdd(&wk[4], (unsigned int)ncell);
-#endif
-        }
+        stage_strip();
         staged = true;
       }
 
       PH(2)
-      todo = filter_phase<ORIENT>(g, lds, lane, rs0, ca, ncols, ncell, valid[0], valid[1], valid[2], valid[3], valid[4], todo, n, uT,
-                                  mrow, tick0, peel_max);
+      todo = filter_phase<ORIENT, WV>(g, lds, lane, rs0, ca, ncols, ncell, valid[0], valid[1], valid[2], valid[3], valid[4], todo, n, uT,
+                                      mrow, tick0, peel_max, 0);
       todo = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(todo >> 32)) << 32) |
              (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)todo);
       PH(0)
@@ -1782,12 +1869,12 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
 #ifdef PHMRF_COLS_NO_DP            // development: the filter alone (timing / register experiments; the labelling is wrong)
       const int nbuf = 0;
 #else
-      const int nbuf = __builtin_amdgcn_readfirstlane(lds_pool.nbuf);
+      const int nbuf = __builtin_amdgcn_readfirstlane(lds_pool.nbuf[0]);
 #endif
       for (int kb = 0; kb < nbuf; ++kb) {
         const int alpha = __builtin_amdgcn_readfirstlane(abuf[kb]);
-        const unsigned int my_changed = dp_flagged<ORIENT, false>(g, lds, kb, lane, rs0, ca, ncols, ncell, alpha, tick0 + alpha, n, D, nbr,
-                                                                  uT, labels, stamp, mrow ? mrow + alpha : nullptr, changed + alpha);
+        const unsigned int my_changed = dp_flagged<ORIENT, false, WV>(g, lds, kb, lane, rs0, ca, ncols, ncell, alpha, tick0 + alpha, n, D, nbr,
+                                                                      uT, labels, stamp, mrow ? mrow + alpha : nullptr, changed + alpha);
         PH(4)
         if (my_changed) {
           // the labels of this strip have changed: everything later is filtered again on the new labelling (the slab's
@@ -1804,6 +1891,7 @@ __global__ __launch_bounds__(64, PHMRF_COLS_WPE) void strip_cols_kernel(StripGeo
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (WV > 1) __syncthreads();       // (the strip's LDS is free for the workgroup's next strip)
   }
 #ifdef PHMRF_PHASE_CLOCK
   // slots: 0 pairs + 4096 x general sweeps, 1 extraction, 2 ids/memo/staging, 3 single-site costs, 4 DP, 5 sweeps
@@ -2217,6 +2305,10 @@ inline int vec_of(int K) { return (K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 }  // namespace
 
+#ifdef PHMRF_DEV
+constexpr int PAR_DIRTY_DEFAULT = 0;      // launch_strip_multi (development builds): four waves per strip below this many (estimated) dirty strips; 0 = never
+#endif
+
 // Development knobs (read from the environment) exist only in builds with -DPHMRF_DEV (tools/variant.sh): the product
 // library has none that can change or break a labelling.
 #ifdef PHMRF_DEV
@@ -2253,6 +2345,14 @@ static int mopup_grid() {           // PHMRF_MOPUP_GRID=n: workgroups of a strip
 static bool seed_masks_enabled() {  // PHMRF_SEED_MASKS=1: the scan also uses the seed masks (a measured negative, DESIGN.md 3.2: kept
   static const bool on = PHMRF_DEV_ENV("PHMRF_SEED_MASKS") != nullptr;   // for the A/B -- the labellings must not differ)
   return on;
+}
+static int par_dirty_limit() {      // PHMRF_PAR_DIRTY=n: four waves per strip while the estimated dirty strips of a launch are <= n (0: never)
+  static int v = -2;
+  if (v == -2) {
+    const char* e = PHMRF_DEV_ENV("PHMRF_PAR_DIRTY");
+    v = e ? atoi(e) : PAR_DIRTY_DEFAULT;
+  }
+  return v;
 }
 #else
 static constexpr int strip_debug() { return 0; }
@@ -2436,13 +2536,33 @@ int launch_strip_multi(const phmrf_block* b, float beta, int orient, int shift_r
 #undef PHMRF_LAUNCH_SCAN
     PHMRF_HIP(hipGetLastError());
   }
-#define PHMRF_LAUNCH_MULTI(O_)                                                                                        \
-  hipLaunchKernelGGL((strip_cols_kernel<O_>), dim3(grid), dim3(TB), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
+  // (round 6, development builds only: a measured negative) FOUR WAVES PER STRIP in a solve's late rounds,
+  // PHMRF_PAR_DIRTY=n: when the previous round changed so few labels that the dirty strips (estimated from the round's change
+  // count) are <= n, four waves share the staged strip and split the labels' filters (strip_cols_kernel, WV = 4).  Same
+  // labelling, label for label -- and no faster: a four-wave workgroup takes a quarter of the GPU's strip slots.
+  bool four_waves = false;
+#ifdef PHMRF_DEV
+  if (use_memo && b->ss && b->ss->rounds > 0 && par_dirty_limit() > 0) {
+    const int64_t est_dirty = std::min<int64_t>((int64_t)nstrips, 2 * b->ss->last_changed);
+    four_waves = est_dirty <= par_dirty_limit();
+  }
+#endif
+#define PHMRF_LAUNCH_MULTI(O_, W_)                                                                                    \
+  hipLaunchKernelGGL((strip_cols_kernel<O_, W_>), dim3(grid), dim3(TB * W_), 0, b->stream, g, b->n, b->K, b->D, b->nbr, b->fwd_w, \
                      b->uT, b->labels, beta, label_mask, b->counters + 8, b->tick ? b->stamp : nullptr, mmemo,          \
                      b->tick, b->work_acc, peel_sweeps(),                                                             \
                      use_scan ? b->scan_out : static_cast<const unsigned long long*>(nullptr))
-  if (orient) PHMRF_LAUNCH_MULTI(1);
-  else PHMRF_LAUNCH_MULTI(0);
+#ifdef PHMRF_DEV
+  if (four_waves) {
+    if (orient) PHMRF_LAUNCH_MULTI(1, 4);
+    else PHMRF_LAUNCH_MULTI(0, 4);
+  } else
+#endif
+  {
+    (void)four_waves;
+    if (orient) PHMRF_LAUNCH_MULTI(1, 1);
+    else PHMRF_LAUNCH_MULTI(0, 1);
+  }
 #undef PHMRF_LAUNCH_MULTI
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;

@@ -962,14 +962,18 @@ def test_strip_scan_and_seed_masks_leave_the_labellings_alone():
     dev = os.path.join(root, "phylo_hmrf_amd", "libphmrf_dev.so")      # (the knobs exist in the -DPHMRF_DEV build only)
     assert os.path.exists(dev), "libphmrf_dev.so not built (make -C phylo_hmrf_amd/csrc)"
     runs = []
-    for extra in ({}, {"PHMRF_SCAN": "1", "PHMRF_LIB": dev}, {"PHMRF_SEED_MASKS": "1", "PHMRF_LIB": dev}):
+    # (d) round 6, development option: FOUR WAVES PER STRIP in a solve's late rounds (strip_cols_kernel<orient, 4>: the labels'
+    #     filters of a dirty strip on four waves, the rare DPs in label order on one; PHMRF_PAR_DIRTY=100000: every round after
+    #     a solve's first).  Exact as well, and no faster: the product keeps one wave per strip.
+    for extra in ({}, {"PHMRF_SCAN": "1", "PHMRF_LIB": dev}, {"PHMRF_SEED_MASKS": "1", "PHMRF_LIB": dev},
+                  {"PHMRF_PAR_DIRTY": "100000", "PHMRF_LIB": dev}):
         env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1", **extra)
         out = subprocess.run([sys.executable, "-c", SEED_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, out.stderr[-3000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
         runs.append(eval(line[len("RESULT"):]))
-    assert runs[0][0] == runs[1][0] == runs[2][0], runs
-    assert runs[0][1] == 0 and runs[1][1] == 0                       # no masks: nothing settled by them
+    assert runs[0][0] == runs[1][0] == runs[2][0] == runs[3][0], runs
+    assert runs[0][1] == 0 and runs[1][1] == 0 and runs[3][1] == 0   # no masks: nothing settled by them
     assert runs[0][3] == runs[1][3]                                  # the same (strip, label) pairs went through the filter
     settled, examined = runs[2][1], runs[2][3]
     # the same pairs, decided one way or the other (a label the masks settled is looked at again after a move on its strip)
