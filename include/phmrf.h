@@ -48,9 +48,9 @@ typedef struct phmrf_block* phmrf_block_t;
 /* ---- library ---------------------------------------------------------------------------------- */
 /* ABI version = major * 100 + minor.  110 (round 4): PHMRF_NUM_KERNEL_CLASSES is 10 and phmrf_block_get_timing takes the
  * capacity of the caller's arrays; phmrf_block_get_work writes 8 values; the resumable solve (phmrf_mrf_solve_begin ...
- * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  121: phmrf_block_prepare_components.  122 (round 6): phmrf_block_get_work_ex.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
+ * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  121: phmrf_block_prepare_components.  122 (round 6): phmrf_block_get_work_ex.  123: phmrf_mrf_graph_expansion.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
  * (phylo_hmrf_amd/_lib.py does). */
-#define PHMRF_VERSION 122
+#define PHMRF_VERSION 123
 PHMRF_API int phmrf_version(void);
 PHMRF_API const char* phmrf_last_error(void);
 PHMRF_API const char* phmrf_status_string(int status);
@@ -236,6 +236,12 @@ PHMRF_API int phmrf_block_tile_put_halo(phmrf_block_t b, const uint8_t* top_in, 
 PHMRF_API int phmrf_mrf_icm_sweep(phmrf_block_t b, double beta, int64_t* changed);
 PHMRF_API int phmrf_mrf_chain_sweep(phmrf_block_t b, double beta, int family, int64_t* changed);
 PHMRF_API int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed);
+/* ABI 123 (round 6): one alpha-expansion of the WHOLE graph -- every node keeps its label or takes alpha -- by an exact
+ * minimum s-t cut on the device (maxflow.hip: lock-free push-relabel with global relabelling, capacities quantised with the
+ * largest term at 2^24 as gco's finest quantisation).  The move gco's expansion() makes (GCoptimization.cpp:1120-1280) on a
+ * general graph (GCoptimization.h:551-597); phmrf_mrf_solve runs it for every label on blocks without grid geometry, where
+ * the strip moves do not exist.  Works on any block with a graph; *changed = labels that took alpha. */
+PHMRF_API int phmrf_mrf_graph_expansion(phmrf_block_t b, double beta, int alpha, int64_t* changed);
 /* Optional scheduling hint: queue, on the block's stream, the part of the next component pass that depends on the labels
  * alone (the connected components of equal label).  The EM driver calls it between two E-steps, where the GPU would
  * otherwise wait for the host's M-step (/root/reference/base.py:399: the reference's M-step follows its E-step the same

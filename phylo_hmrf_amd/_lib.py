@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PHMRF_LIB") or os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
-ABI_VERSION = 122             # include/phmrf.h PHMRF_VERSION: checked against the library in load()
+ABI_VERSION = 123             # include/phmrf.h PHMRF_VERSION: checked against the library in load()
 NUM_KERNEL_CLASSES = 10
 KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose", "coarse", "fusion")
 
@@ -88,6 +88,7 @@ SIGNATURES = {
     "phmrf_mrf_icm_sweep": [_vp, _d, _lp],
     "phmrf_mrf_chain_sweep": [_vp, _d, _i, _lp],
     "phmrf_mrf_component_pass": [_vp, _d, _lp],
+    "phmrf_mrf_graph_expansion": [_vp, _d, _i, _lp],
     "phmrf_block_prepare_components": [_vp],
     "phmrf_mrf_strip_pass": [_vp, _d, _i, _i, _i, _i, _lp],
     "phmrf_mrf_strip_multi_pass": [_vp, _d, _i, _i, _i, ctypes.c_uint64, _lp],

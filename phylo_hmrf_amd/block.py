@@ -214,6 +214,12 @@ class Block(object):
         check(self._L.phmrf_mrf_component_pass(self._h, float(beta), ctypes.byref(c)))
         return c.value
 
+    def graph_expansion(self, beta, alpha):
+        """one alpha-expansion of the whole graph by an exact minimum cut (general graphs; include/phmrf.h) -> labels changed"""
+        c = ctypes.c_int64(0)
+        check(self._L.phmrf_mrf_graph_expansion(self._h, float(beta), int(alpha), ctypes.byref(c)))
+        return c.value
+
     def strip_pass(self, beta, orient, shift_r, shift_c, alpha=-1):
         c = ctypes.c_int64(0)
         check(self._L.phmrf_mrf_strip_pass(self._h, float(beta), int(orient), int(shift_r), int(shift_c), int(alpha),

@@ -516,6 +516,15 @@ int phmrf_block_destroy(phmrf_block_t b) {
   dev_free(b->sgain);
   dev_free(b->seed);
   dev_free(b->scan_out);
+  dev_free(b->mf_rev);
+  dev_free(b->mf_theta);
+  dev_free(b->mf_cap);
+  dev_free(b->mf_tcap);
+  dev_free(b->mf_exc);
+  dev_free(b->mf_hgt);
+  dev_free(b->mf_flags);
+  if (b->mf_flags_host) (void)hipHostFree(b->mf_flags_host);
+  b->mf_flags_host = nullptr;
   for (int s = 0; s < 4; ++s) dev_free(b->saved[s]);
   dev_free(b->nbr);
   dev_free(b->wgt);
@@ -686,6 +695,12 @@ int phmrf_block_set_graph(phmrf_block_t b, int64_t E, const int64_t* edges, cons
   b->has_grid = false;
   for (auto& f : b->families) free_family(f);
   b->families.clear();
+  dev_free(b->mf_rev);                       // (the arcs' reverse slots and the flow's arrays belong to the old graph)
+  dev_free(b->mf_theta);
+  dev_free(b->mf_cap);
+  dev_free(b->mf_tcap);
+  dev_free(b->mf_exc);
+  dev_free(b->mf_hgt);
   return PHMRF_OK;
 }
 
@@ -1172,6 +1187,20 @@ int phmrf_mrf_component_pass(phmrf_block_t b, double beta, int64_t* changed) {
   return PHMRF_OK;
 }
 
+int phmrf_mrf_graph_expansion(phmrf_block_t b, double beta, int alpha, int64_t* changed) {
+  PHMRF_TRY(check_solvable(b));
+  PHMRF_CHECK(b->has_labels, PHMRF_ERR_STATE, "labels not set");
+  PHMRF_CHECK(alpha >= 0 && alpha < b->K, PHMRF_ERR_INVALID, "alpha must be in [0, K)");
+  PHMRF_CHECK(b->n >= 2, PHMRF_ERR_INVALID, "the graph has fewer than two nodes");
+  b->labels_are_slot = 0;
+  PHMRF_TRY(zero_counter(b));
+  PHMRF_TRY(launch_graph_expansion(b, (float)beta, alpha));
+  int64_t ch = 0;
+  PHMRF_TRY(read_counter(b, &ch));
+  if (changed) *changed = ch;
+  return PHMRF_OK;
+}
+
 static int strip_pass_nocount(phmrf_block_t b, float beta, int orient, int shift_r, int shift_c, int alpha, int geom = -1,
                               bool timed = true) {
   if (!b->uT_valid) {                       // (before the proposals: on a grid they are formed from the planes)
@@ -1538,6 +1567,9 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
   // move types and their change counters (slot in b->counters): chain families 72..75, ICM 76, components 77,
   // strip fusion 78/79, strip expansion of label a: 8 + a.
   s->expansions = s->strips && o.use_expansion;
+  // a graph without grid geometry: every label's alpha-expansion over the WHOLE graph by a minimum cut (maxflow.hip), the
+  // move gco's expansion() makes; the same change counters 8 + a
+  s->graph_expansions = !b->has_grid && o.use_expansion && b->nbr != nullptr && b->n >= 2;
   s->n_fam = s->chains ? (int)b->families.size() : 0;
   for (int f = 0; f < s->n_fam; ++f) s->slots.push_back(72 + f);
   s->slots.push_back(76);
@@ -1546,7 +1578,7 @@ int solve_begin(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, bool
     s->slots.push_back(78);
     s->slots.push_back(79);
   }
-  if (s->expansions)
+  if (s->expansions || s->graph_expansions)
     for (int a = 0; a < K; ++a) s->slots.push_back(8 + a);
   // coarse alpha-expansions: slots 80 (2 x 2 super-cells), 81 (4 x 4), 82 (8 x 8)
   s->coarse = s->strips && o.use_coarse && b->H >= 4 && b->W >= 4;
@@ -1685,6 +1717,18 @@ int solve_round_launch(phmrf_block_t b) {
     tic(b, KC_COMPONENT);
     PHMRF_TRY(launch_component_pass(b, bf));
     toc(b, KC_COMPONENT, 1);
+  }
+  if (s->graph_expansions) {
+    // (host-synchronous launches: a few small read-backs per expansion; general graphs are off the hot path)
+    for (int a = 0; a < K; ++a)
+      if (active[8 + a]) {
+        b->counter_slot = 8 + a;
+        ran[8 + a] = 1;
+        ++b->tick;
+        tic(b, KC_STRIP);
+        PHMRF_TRY(launch_graph_expansion(b, bf, a));
+        toc(b, KC_STRIP, 1);
+      }
   }
   if (s->strips) {
     const int geom = s->geom;

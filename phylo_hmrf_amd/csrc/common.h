@@ -123,6 +123,15 @@ struct phmrf_block {
   unsigned long long* coarse_lab = nullptr;       // device [3][64]: labels changed per coarse scale and label in the round (the schedule rests labels)
   unsigned long long* coarse_lab_host = nullptr;  //   ... its pinned host mirror
   char* coarse_arena = nullptr;             // ONE allocation behind the twelve child problems (labels, unary planes, weights, counters)
+  // alpha-expansion of a graph that is no grid by a minimum cut (maxflow.hip): reverse-arc slots and the flow's state
+  uint8_t* mf_rev = nullptr;                // device [n, D]: slot of arc (u -> v) in v's adjacency row
+  float* mf_theta = nullptr;                // device [n]: a node's switch cost
+  int32_t* mf_cap = nullptr;                // device [n, D]: residual capacities of the arcs
+  int32_t* mf_tcap = nullptr;               // device [n]: residual capacity of the arc to the sink
+  long long* mf_exc = nullptr;              // device [n]: excess
+  int32_t* mf_hgt = nullptr;                // device [n]: height / BFS level
+  int32_t* mf_flags = nullptr;              // device [4]
+  int32_t* mf_flags_host = nullptr;         //   ... pinned mirror
   int prop_tick = -1;                       // tick of the last proposal launch of this solve (-1: none)
   int seed_tick = -1;                       // ... of the last one that also wrote the seed masks: seed[i] is current while stamp[i] <= seed_tick
   int geom_phase = 0;                       // which of the three expansion cuts the next solve starts on (cycles across solves)
@@ -195,7 +204,7 @@ struct phmrf_solve_state {
   double eu0 = 0, ep0 = 0;
   int64_t total = 0;
   int rounds = 0, converged = 0;
-  bool chains = false, strips = false, expansions = false, coarse = false;
+  bool chains = false, strips = false, expansions = false, coarse = false, graph_expansions = false;
   int n_fam = 0;
   int64_t tol = 0;
   int64_t sched_n = 0;
@@ -278,6 +287,7 @@ int launch_coarse_apply(const phmrf_block* b, const phmrf_block* child, int s, i
 int launch_c2f_graph(const phmrf_block* b, phmrf_block* child, int Hc, int Wc, int s);     // c2f.hip
 int launch_c2f_logprob(const phmrf_block* b, phmrf_block* child, int Wc, int s);
 int launch_c2f_prolong(const phmrf_block* b, const phmrf_block* child, int Wc, int s);
+int launch_graph_expansion(phmrf_block* b, float beta, int alpha);                  // maxflow.hip: one alpha-expansion of a general graph
 int launch_unary_planes(phmrf_block* b);                                            // logprob -> uT
 int64_t strip_scan_slots(const phmrf_block* b);                                     // capacity of scan_out (strip_scan_kernel)
 // row tiles (tile.hip)

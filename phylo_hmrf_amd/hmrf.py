@@ -198,9 +198,10 @@ class phyloHMRF(_BaseGraph):
                 if not grid_ok:
                     import warnings
                     warnings.warn("region %d: the edge list / len_vec is not a contact-map grid block (utility.py:1871-"
-                                  "2053); it is labelled with general-graph moves only (ICM, component and path moves), for "
-                                  "which no strict energy parity with gco's swap is claimed (measured on k-NN graphs: "
-                                  "-9e-4 ... +1.3e-3 of gco through pygco, tests/test_gpu_estep.py)" % r, RuntimeWarning)
+                                  "2053); it is labelled with general-graph moves only (ICM, component and path moves, alpha-"
+                                  "expansion by minimum cut): host-synchronous and far slower per node than the grid "
+                                  "path; energy parity with gco's swap is tested on k-NN graphs (tests/test_gpu_estep.py)"
+                                  % r, RuntimeWarning)
                     self.general_graph_regions.append(r)
             self.blocks[r] = b
 

@@ -12,7 +12,8 @@ The reference passes no geometry, only the edge list -- but its edge lists are t
 block (utility.py:1871-2053: a full H x W block row-major, or the upper triangle of an N x N block row-major, 8- or
 4-neighbour), and the solver's chain / strip moves need that geometry.  `infer_grid` recovers (H, W, diagonal,
 num_neighbor) from the edge list; the library then checks every edge against it (phmrf_block_set_grid).  A graph that is
-not such a grid is solved with the general-graph moves only (ICM, component and path moves) and a RuntimeWarning says so
+not such a grid is solved with the general-graph moves only (ICM, component and path moves, alpha-expansion by a minimum
+cut on the device: maxflow.hip) and a RuntimeWarning says so
 (`strict_grid=True` raises instead).
 """
 import warnings
@@ -89,9 +90,9 @@ def cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=-1,
             b.set_grid(*grid)
         elif infer_grid(b, n, edges) is None:
             msg = ("cut_general_graph: the edge list is not the stencil of a contact-map block (utility.py:1871-2053); "
-                   "solving with general-graph moves only (ICM, component and path moves), without the strip moves the strict "
-                   "energy parity with gco's swap was established for (measured off the grid: -9e-4 ... +1.3e-3 of gco "
-                   "through pygco on k-NN graphs)")
+                   "solving with general-graph moves only (ICM, component and path moves, alpha-expansion by minimum cut): "
+                   "host-synchronous and slower per node than the grid path; energy parity with gco's swap off the grid is "
+                   "tested on k-NN graphs")
             if strict_grid:
                 raise ValueError(msg)
             warnings.warn(msg, RuntimeWarning, stacklevel=2)

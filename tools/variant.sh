@@ -9,7 +9,7 @@ make -s -j8 >/dev/null
 mkdir -p "$ROOT/variants" .obj/var
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -fno-honor-nans -mno-amdgpu-ieee -DPHMRF_DEV $DEFS -c -o .obj/var/$FILE.$NAME.o $FILE.hip
 OBJS=""
-for f in api kernels moves strip graph init coarse tile c2f; do
+for f in api kernels moves strip graph init coarse tile c2f maxflow; do
   if [ "$f" = "$FILE" ]; then OBJS="$OBJS .obj/var/$FILE.$NAME.o"; else OBJS="$OBJS .obj/dev/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/variants/libphmrf_$NAME.so" $OBJS
