@@ -1011,17 +1011,22 @@ static int energy_now(phmrf_block_t b, double beta, double* eu, double* ep) {
 // stamped (energy_delta_grid_kernel) -- a mop-up round touches a few per cent of the block.  Each evaluation leaves a
 // snapshot of the labels and its tick behind for the next.  (PHMRF_ENERGY_FULL=1: always the full pass;
 // PHMRF_ENERGY_CHECK=1: both, compared.)  The carried values are (unary, pair without beta).
+static const int ROUND_ENERGY_SLOT = 120;      // counters[120], [121]: the round's (unary, pair) energy sums (energy_round_launch)
 static int energy_round_launch(phmrf_block_t b, bool* incremental_out, bool* snapshot_out) {
   static const bool always_full = PHMRF_DEV_ENV("PHMRF_ENERGY_FULL") != nullptr;
   const bool grid = b->has_grid && b->fwd_w && b->uT && b->uT_valid && b->stamp && b->tick > 0 && b->n >= (1 << 18);
   const bool snapshot = grid && !always_full;
   const bool incremental = snapshot && energy_delta_available(b);
-  PHMRF_TRY(zero_accum(b, 4, 2));
+  // (round 6) the round's two energy sums live in the counter bank (slots 120, 121, as doubles -- or 2^-20 fixed-point integers
+  // in deterministic mode): the memset that opens the round has zeroed them and the ONE read-back of the bank that closes it
+  // carries them -- two fills / copies per round fewer than with the accumulator area
   tic(b, KC_ENERGY);
-  if (incremental) PHMRF_TRY(launch_energy_delta(b));
-  else PHMRF_TRY(launch_energy(b, 0.f));
+  double* const at = reinterpret_cast<double*>(b->counters + ROUND_ENERGY_SLOT);
+  if (incremental) PHMRF_TRY(launch_energy_delta(b, at));
+  else PHMRF_TRY(launch_energy(b, 0.f, at));
   toc(b, KC_ENERGY, 1);
-  PHMRF_HIP(hipMemcpyAsync(b->accum_host + 4, b->accum + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));   // (+ slot 6: pin violations)
+  if (b->tile_top || b->tile_bot)        // (the pin-violation count of a row tile: accum slot 6, tile.hip)
+    PHMRF_HIP(hipMemcpyAsync(b->accum_host + 6, b->accum + 6, sizeof(double), hipMemcpyDeviceToHost, b->stream));
   if (snapshot) {       // the snapshot for the next evaluation: every launch from here on carries a later tick
     if (!b->labels_eval) PHMRF_TRY(dev_alloc(&b->labels_eval, (size_t)b->n));
     PHMRF_HIP(hipMemcpyAsync(b->labels_eval, b->labels, (size_t)b->n, hipMemcpyDeviceToDevice, b->stream));
@@ -1039,12 +1044,14 @@ static int energy_round_collect(phmrf_block_t b, double beta, bool incremental, 
   double du, dp;
   if (b->deterministic) {             // 2^-20 fixed-point integers in the two slots (kernels.hip energy_flush)
     long long q[2];
-    std::memcpy(q, b->accum_host + 4, sizeof(q));
+    std::memcpy(q, b->counters_host + ROUND_ENERGY_SLOT, sizeof(q));
     du = (double)q[0] / 1048576.0;
     dp = (double)q[1] / 1048576.0;
   } else {
-    du = b->accum_host[4];
-    dp = b->accum_host[5];
+    double q[2];
+    std::memcpy(q, b->counters_host + ROUND_ENERGY_SLOT, sizeof(q));
+    du = q[0];
+    dp = q[1];
   }
   if (incremental) {
     *eu_carry += du;
@@ -1832,9 +1839,9 @@ int solve_round_launch(phmrf_block_t b) {
   }
   b->counter_slot = 0;
   if (b->timing) PHMRF_TRY(work_fetch_async(b));
-  PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                           b->stream));
   PHMRF_TRY(energy_round_launch(b, &s->incremental, &s->snapshot));
+  PHMRF_HIP(hipMemcpyAsync(b->counters_host, b->counters, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           b->stream));       // (the change counters AND the round's energy sums, slots 120 / 121)
   if (b->tile_top || b->tile_bot) PHMRF_TRY(tile_queue_boundary(b));      // the rows the neighbours need travel with the counters
   s->launched = true;
   s->collected = false;
@@ -1862,7 +1869,10 @@ int solve_round_collect(phmrf_block_t b, unsigned long long* counters, double* e
       PHMRF_CHECK(viol == 0, PHMRF_ERR_STATE, "internal: a pinned row of a tile has moved");
     }
   }
-  if (counters) std::memcpy(counters, b->counters_host, 128 * sizeof(unsigned long long));
+  if (counters) {
+    std::memcpy(counters, b->counters_host, 128 * sizeof(unsigned long long));
+    counters[ROUND_ENERGY_SLOT] = counters[ROUND_ENERGY_SLOT + 1] = 0ull;     // (the energy sums travel in `energy`, not as counters)
+  }
   if (energy) { energy[0] = s->eu_carry; energy[1] = s->ep_carry; }
   return PHMRF_OK;
 }

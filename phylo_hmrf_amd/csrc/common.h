@@ -265,7 +265,7 @@ int launch_choose_labels(const phmrf_block* b, const uint8_t* saved, const doubl
 bool energy_delta_available(const phmrf_block* b);
 bool energy_diff_available(const phmrf_block* b);
 int launch_energy_diff(const phmrf_block* b, const uint8_t* other);   // -> accum[4], [5] += E(labels) - E(other) (unary, pair)
-int launch_energy_delta(const phmrf_block* b);        // -> accum[..] += the change since labels_eval / eval_tick
+int launch_energy_delta(const phmrf_block* b, double* accum_at = nullptr);   // -> accum[4], [5] (or accum_at[0], [1]) += the change since labels_eval / eval_tick
 int launch_posterior_stats(const phmrf_block* b, float beta, int estimate_type, bool write_posteriors);
 int launch_chain_colour(const phmrf_block* b, float beta, int family, int colour, int phase);
 int launch_component_pass(phmrf_block* b, float beta);

@@ -961,13 +961,14 @@ bool energy_delta_available(const phmrf_block* b) {
          b->eval_tick >= 0;
 }
 
-int launch_energy_delta(const phmrf_block* b) {
+int launch_energy_delta(const phmrf_block* b, double* accum_at) {
+  double* const acc = accum_at ? accum_at - ACC_ENERGY : b->accum;
   const int gx = (b->W + 63) / 64;
   int gy = (b->H + 3) / 4;
   const int cap = 2048 / gx + 1;
   if (gy > cap) gy = cap;
   hipLaunchKernelGGL(energy_delta_grid_kernel, dim3(gx, gy), dim3(256), 0, b->stream, b->uT, b->n, b->H, b->W, b->diagonal,
-                     b->fwd_w, b->labels, b->labels_eval, b->stamp, b->eval_tick, b->accum, b->deterministic ? 1 : 0);
+                     b->fwd_w, b->labels, b->labels_eval, b->stamp, b->eval_tick, acc, b->deterministic ? 1 : 0);
   PHMRF_HIP(hipGetLastError());
   return PHMRF_OK;
 }
