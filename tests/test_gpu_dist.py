@@ -229,6 +229,10 @@ def test_bench_two_ranks_on_one_gpu_shards_the_blocks(tmp_path):
     assert max(d2["config"]["nodes_per_rank"]) < 0.52 * (n0 + n1)
     assert d1["config"]["nodes_per_rank"] == [n0 + n1]
     assert d2["value"] > 0 and d2["ms_per_step"] > 0
+    # (round 6) every rank's own clocks travel on the line: which rank is slow, and in what
+    pr = d2["per_rank"]
+    assert len(pr["estep_ms"]) == 2 and all(x > 0 for x in pr["estep_ms"]) and pr["nodes"] == d2["config"]["nodes_per_rank"]
+    assert pr["units"] == [3, 3] and all(x > 0 for x in pr["exchange_us"]) and d2["fit_surface"] is None and d1["fit_surface"]
     # (one block solved as two tiles: a different local optimum of the same energy in the very first iteration already;
     #  chaotic afterwards, see the fit tests)
     np.testing.assert_allclose(d2["cost1"], d1["cost1"], rtol=6e-2, atol=5e-3)
@@ -253,6 +257,7 @@ def test_bench_four_ranks_on_one_gpu_two_split_blocks_on_disjoint_rank_pairs(tmp
     assert sorted(d["config"]["units_per_rank"]) == [1, 1, 1, 2] and sum(d["config"]["nodes_per_rank"]) == n0 + n1
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["fit"]["iterations"] >= 6
     assert all(np.isfinite(c) for c in d["cost1"])
+    assert len(d["per_rank"]["estep_ms"]) == 4 and sum(d["per_rank"]["nodes"]) == n0 + n1
 
 
 def test_cli_under_torchrun_two_ranks_one_block_in_two_tiles(tmp_path):
