@@ -94,7 +94,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prepare", action="store_true",
                     help="A/B: do not queue the next E-step's connected components behind the M-step (phmrf_block_prepare_components)")
-    ap.add_argument("--block-threads", type=int, default=14,
+    ap.add_argument("--block-threads", type=int, default=14,   # 0: ONE host thread, all blocks in lockstep rounds (phmrf_mrf_solve_group)
                     help="host threads driving blocks concurrently, each block on its own HIP stream (1 = sequential)")
     ap.add_argument("--mstep-workers", type=int, default=0,
                     help="processes fitting the states in the M-step (0 = min(K, cores); 1 = in this process, no fork: "
@@ -298,7 +298,7 @@ def main():
     # small blocks fill the GPU next to the large ones.  ctypes drops the GIL for the duration of a library call.
     # The row tiles of split blocks run their lockstep rounds on THIS thread meanwhile (tiles.Conductor).
     from phylo_hmrf_amd.concurrent import BlockRunner
-    runner = BlockRunner(a.block_threads, local_rank)
+    runner = BlockRunner(max(a.block_threads, 1), local_rank)      # (--block-threads 0: the lockstep group solve, estep_lockstep)
     order = sorted(range(len(blocks)), key=lambda i: -blocks[i].n)
 
     block_trace = [] if os.environ.get("PHMRF_BLOCK_TRACE") else None      # development: (step start, block, n, t0, t1)
@@ -325,6 +325,23 @@ def main():
     def tile_finish(tl):
         tl.b.posterior_stats_dev(a.beta, 3, stats_dev[len(blocks) + local_tiles.index(tl)].data_ptr())
 
+    def estep_lockstep():
+        """--block-threads 0: ONE host thread drives every whole block -- emission and warm start queued on the blocks' streams,
+        then all solves in lockstep rounds (phmrf_mrf_solve_group), then the statistics: the same library work per block as
+        estep_block, the same overlap on the GPU, no thread pool"""
+        for i in order:
+            b = blocks[i]
+            b.emission(state["means"], state["covars"])
+            if state["warm_start"] == "best":
+                b.warm_start(a.beta, SLOT_LOCAL, report=False)
+            else:
+                b.restore_labels(SLOT_LOCAL)
+        Block.solve_group([blocks[i] for i in order], a.beta, **solver)
+        for i in order:
+            blocks[i].posterior_stats_dev(a.beta, 3, stats_dev[i].data_ptr())
+        for i in order:
+            blocks[i].sync()
+
     def estep_all(sequential=False):
         if block_trace is not None:
             del block_trace[:]
@@ -332,6 +349,9 @@ def main():
         if sequential:
             for i in order:
                 estep_block(i)
+            pending = None
+        elif a.block_threads == 0:
+            estep_lockstep()
             pending = None
         else:
             pending = runner.start(estep_block, order)
@@ -727,7 +747,7 @@ def main():
         # The kernel's fraction: algorithmic bytes / the launches' OWN durations / peak.  With one block in flight at a time
         # (--block-threads 1: the profiled serial runs) the timed region's own event times are that; otherwise the isolated
         # pass right after the timed region supplies them (same EM trajectory, one block at a time).
-        serial = runner.n_threads == 1 and not conductor.groups
+        serial = a.block_threads == 1 and not conductor.groups
         if serial:
             own_all, own_full, own_mop = own_split(agg_dom, agg_dom_first, dom_name)
             own_from = "the timed region (--block-threads 1: one stream in flight, an event pair times the kernel alone)"
@@ -840,7 +860,7 @@ def main():
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
             "value_estep_only": n_norm * a.steps / float(np.sum(t_e_timed)),
-            "setup_s": setup_s, "block_threads": runner.n_threads, "components_prepared_behind_mstep": bool(blocks and not a.no_prepare),
+            "setup_s": setup_s, "block_threads": a.block_threads, "components_prepared_behind_mstep": bool(blocks and not a.no_prepare),
             "kernels": kernels, "kernels_from": kernels_from,
             "kernels_steps": inst_steps or a.steps, "roofline": roofline,
             "roofline_limiter": roofline_limiter,

@@ -48,9 +48,9 @@ typedef struct phmrf_block* phmrf_block_t;
 /* ---- library ---------------------------------------------------------------------------------- */
 /* ABI version = major * 100 + minor.  110 (round 4): PHMRF_NUM_KERNEL_CLASSES is 10 and phmrf_block_get_timing takes the
  * capacity of the caller's arrays; phmrf_block_get_work writes 8 values; the resumable solve (phmrf_mrf_solve_begin ...
- * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  121: phmrf_block_prepare_components.  122 (round 6): phmrf_block_get_work_ex.  123: phmrf_mrf_graph_expansion.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
+ * _end) and the row-tile entry points are new.  120 (round 5): phmrf_block_get_work_first, phmrf_block_get_timing_first; phmrf_solve_opts.coarse_start.  121: phmrf_block_prepare_components.  122 (round 6): phmrf_block_get_work_ex.  123: phmrf_mrf_graph_expansion.  124: phmrf_mrf_solve_group.  A binding checks phmrf_version() == PHMRF_VERSION when it loads the library
  * (phylo_hmrf_amd/_lib.py does). */
-#define PHMRF_VERSION 123
+#define PHMRF_VERSION 124
 PHMRF_API int phmrf_version(void);
 PHMRF_API const char* phmrf_last_error(void);
 PHMRF_API const char* phmrf_status_string(int status);
@@ -194,6 +194,11 @@ typedef struct phmrf_solve_result {
 /* Minimise E_float by energy-non-increasing moves from the current labels; labels stay on the device
  * (phmrf_block_get_labels to fetch).  opts NULL = defaults, res may be NULL. */
 PHMRF_API int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res);
+/* ABI 124 (round 6): the same solve of SEVERAL independent blocks in lockstep rounds from the calling thread -- every undecided
+ * block's round is queued on its own stream, then the rounds are collected and decided in the same order: the blocks' kernels
+ * overlap on the GPU as they do with one host thread per block (the reference: one process per block, base.py:357-362),
+ * without the threads.  Block for block the labelling phmrf_mrf_solve gives.  List the largest blocks first. */
+PHMRF_API int phmrf_mrf_solve_group(phmrf_block_t* blocks, int n_blocks, double beta, const phmrf_solve_opts* opts);
 /* The same solve in pieces (phmrf_mrf_solve is exactly begin; {launch; collect; decide} while *status == 0; end):
  *   begin    resets the solve's state (stamps, memos, schedule); want_init_energy: also evaluate the starting energy
  *   launch   queues one round's kernels and the read-back of its change counters and energy on the block's stream

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PHMRF_LIB") or os.path.join(_HERE, "libphmrf.so")
 
 OK = 0
-ABI_VERSION = 123             # include/phmrf.h PHMRF_VERSION: checked against the library in load()
+ABI_VERSION = 124             # include/phmrf.h PHMRF_VERSION: checked against the library in load()
 NUM_KERNEL_CLASSES = 10
 KERNEL_CLASSES = ("emission", "icm", "chain", "component", "energy", "posterior_stats", "strip", "propose", "coarse", "fusion")
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     "phmrf_emission_pack": [_i, _i, _dp, _dp, _fp],
     "phmrf_emission_dev": [_vp, _i64, _i, _i, _vp, _vp, _vp],
     "phmrf_mrf_solve": [_vp, _d, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveResult)],
+    "phmrf_mrf_solve_group": [ctypes.POINTER(ctypes.c_void_p), _i, _d, ctypes.POINTER(SolveOpts)],
     "phmrf_mrf_solve_begin": [_vp, _d, ctypes.POINTER(SolveOpts), _i],
     "phmrf_mrf_solve_round_launch": [_vp],
     "phmrf_mrf_solve_round_collect": [_vp, ctypes.POINTER(ctypes.c_uint64), _dp],

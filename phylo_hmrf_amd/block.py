@@ -135,6 +135,18 @@ class Block(object):
                       int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb), int(coarse_start))
         check(self._L.phmrf_mrf_solve(self._h, float(beta), ctypes.byref(o), None))
 
+    @staticmethod
+    def solve_group(blocks, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
+                    use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True, coarse_start=0):
+        """solve_fast of several independent blocks in lockstep rounds from THIS thread (phmrf_mrf_solve_group): their kernels
+        overlap on the GPU as with one host thread per block, without the threads.  List the largest blocks first."""
+        if not blocks:
+            return
+        o = SolveOpts(int(max_rounds), int(use_chains), int(use_components), int(init_mode), int(use_strips),
+                      int(use_expansion), int(min_changed), int(use_coarse), int(energy_tol_ppb), int(coarse_start))
+        arr = (ctypes.c_void_p * len(blocks))(*[b._h for b in blocks])
+        check(blocks[0]._L.phmrf_mrf_solve_group(arr, len(blocks), float(beta), ctypes.byref(o)))
+
     # -- the solve in pieces (lockstep rounds of the row tiles of one block: tiles.py) ----------------
     def solve_begin(self, beta, want_init_energy=False, max_rounds=64, use_chains=True, use_components=True, init_mode=0,
                     use_strips=True, use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True, coarse_start=0):

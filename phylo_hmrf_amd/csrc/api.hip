@@ -2123,6 +2123,59 @@ int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, 
 }
 
 
+// Several blocks solved in LOCKSTEP ROUNDS from one host thread (round 6): every undecided block's round is queued on its own
+// stream, then the rounds are collected and decided in the same order -- the blocks' kernels overlap on the GPU as they do
+// when a host thread per block drives them, without the threads.  Each block's state machine is the one phmrf_mrf_solve
+// runs: block for block the same labelling (bit-identical under PHMRF_DETERMINISTIC=1).
+int phmrf_mrf_solve_group(phmrf_block_t* blocks, int n_blocks, double beta, const phmrf_solve_opts* opts) {
+  PHMRF_CHECK(blocks && n_blocks >= 0, PHMRF_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < n_blocks; ++i) PHMRF_CHECK(blocks[i], PHMRF_ERR_INVALID, "block is NULL");
+  struct Scope {                               // an error inside the loop still ends every solve
+    phmrf_block_t* bl;
+    int n;
+    ~Scope() {
+      for (int i = 0; i < n; ++i)
+        if (bl[i]->ss) solve_scope_exit(bl[i]);
+    }
+  } scope{blocks, 0};
+  for (int i = 0; i < n_blocks; ++i) {
+    PHMRF_TRY(solve_begin(blocks[i], beta, opts, false));
+    scope.n = i + 1;
+  }
+  std::vector<int> status(n_blocks, 0);
+  std::vector<char> launched(n_blocks, 0);
+  unsigned long long counters[128];
+  double energy[2];
+  for (;;) {
+    int n_launched = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+      launched[i] = 0;
+      phmrf_block* b = blocks[i];
+      if (status[i] != 0) continue;
+      if (b->ss->rounds >= b->ss->o.max_rounds || b->tick >= 60000) {
+        status[i] = 2;
+        continue;
+      }
+      PHMRF_TRY(solve_round_launch(b));
+      launched[i] = 1;
+      ++n_launched;
+    }
+    if (n_launched == 0) break;
+    for (int i = 0; i < n_blocks; ++i) {
+      if (!launched[i]) continue;
+      PHMRF_TRY(solve_round_collect(blocks[i], counters, energy));
+      PHMRF_TRY(solve_round_decide(blocks[i], counters, energy, &status[i]));
+    }
+  }
+  int st = PHMRF_OK;
+  for (int i = 0; i < n_blocks; ++i) {
+    const int s1 = solve_end(blocks[i], nullptr);
+    if (s1 != PHMRF_OK) st = s1;
+  }
+  scope.n = 0;
+  return st;
+}
+
 // ---- row tiles (tile.hip) -----------------------------------------------------------------------
 static int64_t row_first(const phmrf_block* b, int i) {      // first node of grid row i (i == H: n)
   return b->diagonal ? (int64_t)i * b->W - ((int64_t)i * (i - 1)) / 2 : (int64_t)i * b->W;

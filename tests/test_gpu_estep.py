@@ -1017,6 +1017,63 @@ def test_strip_scan_and_seed_masks_leave_the_labellings_alone():
     assert settled > 0 and runs[0][3] <= settled + examined <= 1.05 * runs[0][3], runs
 
 
+GROUP_SCRIPT = r"""
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, os.environ["PHMRF_ROOT"])
+import torch
+from phylo_hmrf_amd import Block, synthetic
+from phylo_hmrf_amd.tree import PhyloTree
+K, S = 12, 4
+tree = PhyloTree(synthetic.tree_for(S)); rng = np.random.default_rng(4)
+P = synthetic.sample_ou_params(rng, tree, K); mu, cv = tree.mean_cov(P); cv = cv + 1e-3 * np.eye(S)
+P2 = np.clip(P * (1 + 0.15 * rng.standard_normal(P.shape)), 1e-3, 50); mu2, cv2 = tree.mean_cov(P2); cv2 = cv2 + 1e-3 * np.eye(S)
+P3 = np.clip(P2 * (1 + 0.05 * rng.standard_normal(P.shape)), 1e-3, 50); mu3, cv3 = tree.mean_cov(P3); cv3 = cv3 + 1e-3 * np.eye(S)
+dev = torch.device("cuda", 0)
+shapes = [(500, 500, True), (300, 420, False), (260, 260, True)]
+opts = dict(energy_tol_ppb=1000)
+out = []
+for mode in ("one by one", "group"):
+    blocks = []                          # (fresh blocks per mode: a block's solves cycle through the three strip cuts)
+    for i, (H, W, diag) in enumerate(shapes):
+        X = synthetic.device_observations(torch, dev, 10 + i, H, W, diag, K, mu, cv); torch.cuda.synchronize()
+        n = H * (H + 1) // 2 if diag else H * W
+        b = Block(n, S, K); b.set_observations_dev(X.data_ptr()); b.sync(); b.build_grid_graph(H, W, diag, 8, 0.5)
+        blocks.append(b)
+    for b in blocks:
+        b.emission(mu2, cv2)
+    if mode == "group":
+        Block.solve_group(blocks, 1.0, init_mode=1, **opts)                  # cold
+    else:
+        for b in blocks: b.solve_fast(1.0, init_mode=1, **opts)
+    for b in blocks:
+        b.emission(mu3, cv3)
+    if mode == "group":
+        Block.solve_group(blocks, 1.0, **opts)                               # warm
+    else:
+        for b in blocks: b.solve_fast(1.0, **opts)
+    out.append([hashlib.sha1(b.get_labels().tobytes()).hexdigest() for b in blocks])
+    for b in blocks:
+        b.close()
+print("RESULT", out)
+"""
+
+
+def test_group_solve_in_lockstep_rounds_gives_the_per_block_labellings():
+    """phmrf_mrf_solve_group (round 6): three independent blocks -- two triangular, one rectangular -- solved in lockstep rounds
+    from one host thread, cold and then warm, give block for block the labels of solving them one after the other
+    (PHMRF_DETERMINISTIC=1: bit for bit): the group call only interleaves the blocks' own state machines."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PHMRF_ROOT=root, PHMRF_DETERMINISTIC="1")
+    out = subprocess.run([sys.executable, "-c", GROUP_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
+    runs = eval(line[len("RESULT"):])
+    assert runs[0] == runs[1] and len(set(runs[0])) == 3, runs
+
+
 PREP_SCRIPT = r"""
 import os, sys, hashlib
 import numpy as np
