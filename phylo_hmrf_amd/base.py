@@ -101,6 +101,11 @@ class _BaseGraph(object):
         """-> [(stats dict, cost numerators[4], owned nodes)] of the row tiles this rank holds (none by default)"""
         return []
 
+    def _estep_lockstep(self, regions):
+        """hook: the E-step of all `regions` driven from the calling thread in lockstep rounds -> {region: (stats, costs)},
+        or None when the model runs its regions on the runner's threads (the default)"""
+        return None
+
     # ---- checkpoint / resume -----------------------------------------------------------------------
     CHECKPOINT_FORMAT = 1
 
@@ -234,9 +239,13 @@ class _BaseGraph(object):
             # E-step of the regions this rank owns; un-normalised cost sums travel with the statistics
             local = np.zeros(K * (1 + S + S * S) + 5)
             by_size = sorted(self.my_regions, key=lambda r: -int(len_vec[r][0]))          # largest block first
-            pending = self.runner.start(self._estep_region, by_size)                      # concurrent streams
-            tiled = self._estep_tiles()         # row tiles of split blocks: lockstep rounds, on this thread meanwhile
-            done = dict(zip(by_size, pending.results()))
+            done = self._estep_lockstep(by_size)         # (block_threads=0: every whole block from THIS thread; else None)
+            if done is None:
+                pending = self.runner.start(self._estep_region, by_size)                  # concurrent streams
+                tiled = self._estep_tiles()     # row tiles of split blocks: lockstep rounds, on this thread meanwhile
+                done = dict(zip(by_size, pending.results()))
+            else:
+                tiled = self._estep_tiles()
             for region_id in self.my_regions:                                             # fixed summation order
                 st, costs = done[region_id]
                 local[:-5] += pack_stats(st)

@@ -168,7 +168,9 @@ class phyloHMRF(_BaseGraph):
                 torch.cuda.set_device(device)
         # independent blocks run concurrently, each on its own stream (the reference: one process per block, base.py:357)
         from .concurrent import BlockRunner
-        self.runner = BlockRunner(min(int(block_threads), max(1, len(self.my_regions))), device)
+        # block_threads=0: no thread pool -- this thread drives every whole block in lockstep rounds (phmrf_mrf_solve_group)
+        self.lockstep = int(block_threads) == 0
+        self.runner = BlockRunner(min(max(int(block_threads), 1), max(1, len(self.my_regions))), device)
 
         # device-resident blocks (the reference's _edge_weight_undirected_vec, :567-598, happens here once)
         factory = block_factory or Block
@@ -444,6 +446,25 @@ class phyloHMRF(_BaseGraph):
         b.solve_fast(self.beta, **self.solver_opts)
         stats, costs, _ = b.posterior_stats(self.beta, self.estimate_type)
         return stats, costs
+
+    def _estep_lockstep(self, regions):
+        """block_threads=0: emission and warm start of every whole block queued on its stream, all solves in lockstep rounds
+        from this thread (Block.solve_group: block for block the labels of the per-block solves), then the statistics"""
+        if not self.lockstep:
+            return None
+        blocks = [self._whole_block(r, "its E-step") for r in regions]
+        for b in blocks:
+            b.emission(self.means_, self._covars_)
+            if self.warm_start == "best":
+                b.warm_start(self.beta, SLOT_LOCAL, report=False)
+            else:
+                b.restore_labels(SLOT_LOCAL)
+        Block.solve_group(blocks, self.beta, **self.solver_opts)
+        out = {}
+        for r, b in zip(regions, blocks):
+            stats, costs, _ = b.posterior_stats(self.beta, self.estimate_type)
+            out[r] = (stats, costs)
+        return out
 
     def _prepare_next_estep(self):
         """While the host fits the K states (the reference's M-step follows its E-step the same way, base.py:399) the GPU has

@@ -307,3 +307,32 @@ def test_fit_surface_at_the_chr1_block_size():
         assert len(it_ms) == 5 and np.all(it_ms[2:] < 250.0), it_ms
     finally:
         m.close()
+
+
+def test_fit_with_the_blocks_in_lockstep_from_one_thread_equals_the_threaded_fit(monkeypatch):
+    """block_threads=0 (round 6): the E-step of every whole block driven from the calling thread in lockstep rounds
+    (phmrf_mrf_solve_group) -- same start, same M-step draws, deterministic solver: the fit's costs equal the threaded fit's to
+    1e-9 and its labels exactly, iteration by iteration (the group call interleaves the blocks' own state machines)."""
+    monkeypatch.setenv("PHMRF_DETERMINISTIC", "1")
+    import phylo_hmrf as cli
+    from phylo_hmrf_amd.hmrf import phyloHMRF
+    Xa, lva, ea, tree = cli.synthetic_cache(70, 4, 4, 8, 21)
+    Xb, lvb, eb, _ = cli.synthetic_cache(50, 4, 4, 8, 22)
+    X = np.vstack([Xa, Xb])
+    na, nb = Xa.shape[0], Xb.shape[0]
+    len_vec = [lva[0], [nb, na, na + nb, 50, 50, 0, 0, 1, 1, 2]]
+    edges = [ea[0], eb[0]]
+
+    def fit(threads):
+        m = phyloHMRF(n_components=4, run_id=0, n_samples=na + nb, n_features=4, observation=X, edge_list=tree, len_vec=len_vec,
+                      type_id=1, branch_list=[1.0] * 7, edge_list_1=edges, cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0,
+                      initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, estimate_type=3, random_state=5, quiet=True,
+                      mstep_workers=1, block_threads=threads, init_method="sklearn")
+        try:
+            return m.fit_accumulate_test(X, len_vec, 0.0, "t", 4)
+        finally:
+            m.close()
+
+    a, b = fit(2), fit(0)
+    np.testing.assert_allclose(a[5], b[5], rtol=1e-9)
+    assert np.array_equal(a[6], b[6])
