@@ -631,6 +631,10 @@ def main():
         return {"warm_start": warm_start, "iterations": iters, "stopped_by": stop, "wall_s": round(fit_wall, 4),
                 "value": n_norm * iters / fit_wall, "unit": "node-iterations/s over the whole fit (cold first iteration included)",
                 "estep_ms": [round(x, 2) for x in e_ms], "mstep_ms_mean": round(float(np.mean(m_ms)), 3) if m_ms else None,
+                # the iterations past the fifth (what `value`'s timed window holds under --warmup 5), E-step + mean M-step:
+                # the steady cost of an EM iteration under THIS start rule, beside `ms_per_step`
+                "steady_ms_per_iteration": (round(float(np.mean(e_ms[5:])) + (float(np.mean(m_ms)) if m_ms else 0.0), 3)
+                                            if iters > 5 else None),
                 "cost1": c1, "rules": "threshold 0.001, m_iter 60 (phylo_hmrf.py:1555,1561); base.py:416-435"}
 
     # `fit`: with the start of an E-step's labelling this run was asked for (--warm-start; default "best");

@@ -54,6 +54,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["fit"]["warm_start"] == "best" and d["fit_reference_start"]["warm_start"] == "local"
     for f in (d["fit"], d["fit_reference_start"]):
         assert f["iterations"] >= 1 and f["value"] > 0 and len(f["estep_ms"]) == f["iterations"]
+        assert (f["steady_ms_per_iteration"] is None) == (f["iterations"] <= 5)      # the steady cost under each start rule
     assert d["build"]["source_hash"]
     # (round 6) the same iterations through the product's own loop, and every rank's own clocks
     fs = d["fit_surface"]
