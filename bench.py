@@ -92,6 +92,11 @@ def parse():
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ab-env", default="",
+                    help="development (libphmrf_dev.so via PHMRF_LIB): NAME=A,B -- after everything else, --ab-steps more EM "
+                         "iterations whose E-step runs TWICE from the same labellings and parameters, once with the environment "
+                         "variable NAME set to A and once to B (order alternating); both times and cost1 go to `ab` on the line")
+    ap.add_argument("--ab-steps", type=int, default=20)
     ap.add_argument("--no-prepare", action="store_true",
                     help="A/B: do not queue the next E-step's connected components behind the M-step (phmrf_block_prepare_components)")
     ap.add_argument("--block-threads", type=int, default=14,   # 0: ONE host thread, all blocks in lockstep rounds (phmrf_mrf_solve_group)
@@ -719,6 +724,48 @@ def main():
         finally:
             m.close()
 
+    # ---- development: the same E-steps under two settings of a knob of the development library (not part of `value`) --------
+    ab = None
+    if a.ab_env and unit_blocks and not conductor.groups:
+        name, vals = a.ab_env.split("=", 1)
+        va, vb = vals.split(",")
+        SLOT_AB = 1
+        for b in unit_blocks:
+            b.enable_timing(False)
+        ms = {va: [], vb: []}
+        c1 = {va: [], vb: []}
+        for it in range(a.ab_steps):
+            for b in unit_blocks:
+                b.save_labels(SLOT_AB)                 # the labelling the previous E-step left
+            tot = None
+            for v in ((va, vb) if it % 2 == 0 else (vb, va)):
+                os.environ[name] = v
+                for b in unit_blocks:
+                    b.restore_labels(SLOT_AB)
+                    if not a.no_prepare and solver["use_components"]:
+                        b.prepare_components()
+                barrier()
+                ta = time.time()
+                tot = estep_all()
+                barrier()
+                ms[v].append((time.time() - ta) * 1e3)
+                c1[v].append(float(tot[n_stats + 3] / n_norm))
+            # the EM goes on from the second run's result (the order alternates)
+            stats = unpack_stats(tot[:n_stats], K, S)
+            cost1 = tot[n_stats + 3] / n_norm
+            if cost1 < state["min_cost"]:
+                state["min_cost"] = cost1
+                for b in unit_blocks:
+                    b.save_labels(SLOT_LOCAL)
+            mstep_all(stats, rng)
+        ab = {"env": name, "values": [va, vb], "steps": a.ab_steps,
+              "estep_ms_mean": {v: round(float(np.mean(ms[v])), 3) for v in ms},
+              "estep_ms_median": {v: round(float(np.median(ms[v])), 3) for v in ms},
+              "estep_ms": {v: [round(x, 1) for x in ms[v]] for v in ms},
+              "cost1_mean": {v: round(float(np.mean(c1[v])), 7) for v in c1},
+              "cost1_diff_mean (B - A)": float(np.mean(np.array(c1[vb]) - np.array(c1[va]))),
+              "cost1": {v: [round(x, 6) for x in c1[v]] for v in c1}}
+
     fit_surface = None
     if not a.no_through_fit and world == 1 and not emulating and a.scaling == "strong":
         fit_surface = through_fit()
@@ -861,6 +908,7 @@ def main():
             "fit_surface": fit_surface,
             "tile_rounds": tile_rounds,
             "per_rank": per_rank,
+            **({"ab": ab} if ab else {}),
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
             "value_estep_only": n_norm * a.steps / float(np.sum(t_e_timed)),
