@@ -88,3 +88,18 @@ def test_bench_rccl_path_single_rank():
 def test_bench_weak_scaling_mode_replicates_the_workload():
     d = _run(["--no-cpu-baseline", "--scaling", "weak"])
     assert d["scaling"] == "weak" and d["config"]["units_per_rank"] == [2]
+
+
+def test_bench_ab_env_runs_every_estep_under_both_values_from_the_same_labellings():
+    """--ab-env (development library): both runs of an E-step start from the same labellings and parameters, so with a knob
+    that leaves the labellings alone (the strip scan) they end within a solve's own spread of each other -- a block's
+    expansion cut advances from one solve to the next (b->geom_phase), which is why the order of the two runs alternates --
+    where two EM iterations apart differ in cost1 by percents."""
+    dev = os.path.join(ROOT, "phylo_hmrf_amd", "libphmrf_dev.so")
+    d = _run(["--no-cpu-baseline", "--no-fit", "--no-through-fit", "--no-kernel-timing", "--ab-env", "PHMRF_SCAN=0,1", "--ab-steps", "3"],
+             env={"PHMRF_LIB": dev})
+    ab = d["ab"]
+    assert ab["env"] == "PHMRF_SCAN" and ab["values"] == ["0", "1"] and ab["steps"] == 3
+    assert len(ab["estep_ms"]["0"]) == 3 and len(ab["estep_ms"]["1"]) == 3 and min(ab["estep_ms"]["0"] + ab["estep_ms"]["1"]) > 0
+    for x, y in zip(ab["cost1"]["0"], ab["cost1"]["1"]):
+        assert abs(x - y) <= 1e-3 * abs(x), (x, y)
