@@ -395,7 +395,7 @@ def strip_fusion(g, unary, labels, prop, beta, H, W, diagonal, orient, shift_r, 
 
 
 def peel(g, unary, labels, beta, H, W, diagonal, orient, shift_r, shift_c, alpha, max_sweeps=None):
-    """The exact filter in front of the strip alpha-expansions (model of strip_multi_kernel's sweeps).
+    """The exact filter in front of the strip alpha-expansions (model of strip_cols_kernel's sweeps).
 
     s_i = cost of switching node i alone to alpha;  disc_ij = beta w_ij (2 - [l_i != l_j]) = what an edge inside a
     switching set saves against the single-site sums.  For an optimal switching set C* of a strip:

@@ -9,8 +9,9 @@ FETCH_DIR / WRITE_DIR hold the outputs of
 """
 import csv, glob, json, os, sys
 
-CLASSES = {"strip": ["strip_multi_kernel", "strip_kernel"], "chain": ["chain_kernel"], "icm": ["icm_kernel"], "posterior_stats": ["posterior_kernel"],
-           "energy": ["energy_kernel"], "propose": ["propose_kernel", "alpha_mask_kernel", "strip_scan_kernel", "unary_planes_kernel"],
+CLASSES = {"strip": ["strip_cols_kernel", "strip_kernel"], "fusion": ["fusion_cols_kernel"], "chain": ["chain_kernel"], "icm": ["icm_kernel"], "posterior_stats": ["posterior_kernel"],
+           "energy": ["energy_kernel", "energy_grid_kernel", "energy_delta_grid_kernel", "energy_diff_grid_kernel"],
+           "propose": ["propose_kernel", "propose_grid_kernel", "strip_scan_kernel", "unary_planes_kernel"],
            "coarse": ["coarsen_kernel", "coarse_apply_kernel"],
            "emission": ["emission_kernel"],
            "component": ["cc_init_kernel", "cc_union_kernel", "cc_flatten_kernel", "comp_table_kernel", "comp_decide_kernel",

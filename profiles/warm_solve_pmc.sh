@@ -14,7 +14,7 @@ for set in "$@"; do
   python3 -c "
 import json
 d=json.load(open('$O/${TAG}_pmc$i.json')).get('warm_solve_sq',{})
-for k in ('strip_multi_kernel','strip_kernel'):
+for k in ('strip_cols_kernel','fusion_cols_kernel','strip_kernel'):
     if k in d: print(k, {a:(v if '/' in a or 'per' in a else int(v)) for a,v in d[k].items()})
 "
   rm -rf $O/wp_$i

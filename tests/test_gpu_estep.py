@@ -112,7 +112,7 @@ def _integer_problem(seed, H, W, K, diagonal):
 @pytest.mark.parametrize("H,W,K,diagonal", [(23, 70, 4, False), (41, 41, 6, True), (6, 200, 3, False), (130, 7, 5, False),
                                             (64, 129, 20, False), (3, 3, 2, True), (30, 66, 64, False), (35, 35, 30, True)])
 def test_strip_multi_pass_matches_the_single_label_passes(H, W, K, diagonal):
-    """strip_multi_kernel (every label of a cut in one launch, behind the exact filter) = the strip alpha-expansions of
+    """strip_cols_kernel (every label of a cut in one launch, behind the exact filter) = the strip alpha-expansions of
     the move model applied label after label, label for label -- the filter loses no move and breaks no tie differently."""
     n, eid, w, lp, init = _integer_problem(6, H, W, K, diagonal)
     g = M.Graph(n, eid, w)

@@ -1,5 +1,5 @@
 """CPU: the exact filter in front of the strip alpha-expansions (oracle/mrf_moves.peel, the model of
-strip_multi_kernel's sweeps) against the exact strip DP (oracle/mrf_moves.strip_fusion): on seeded problems with
+strip_cols_kernel's sweeps) against the exact strip DP (oracle/mrf_moves.strip_fusion): on seeded problems with
 integer and with real-valued costs, every node the DP switches lies in the filter's set U and every strip the DP
 changes has a seed -- the filter never loses a move."""
 import numpy as np
