@@ -332,8 +332,8 @@ def main():
 
     def estep_lockstep():
         """--block-threads 0: ONE host thread drives every whole block -- emission and warm start queued on the blocks' streams,
-        then all solves in lockstep rounds (phmrf_mrf_solve_group), then the statistics: the same library work per block as
-        estep_block, the same overlap on the GPU, no thread pool"""
+        then all solves round by round as the rounds end (phmrf_mrf_solve_group), then the statistics: the same library work per
+        block as estep_block, the same overlap on the GPU, no thread pool"""
         for i in order:
             b = blocks[i]
             b.emission(state["means"], state["covars"])
@@ -356,8 +356,12 @@ def main():
                 estep_block(i)
             pending = None
         elif a.block_threads == 0:
-            estep_lockstep()
-            pending = None
+            # one thread for all whole blocks: this one, unless the rank holds row tiles too (their rounds run here meanwhile)
+            if conductor.groups and blocks:
+                pending = runner.start_one(estep_lockstep)
+            else:
+                estep_lockstep()
+                pending = None
         else:
             pending = runner.start(estep_block, order)
         if conductor.groups:

@@ -194,10 +194,11 @@ typedef struct phmrf_solve_result {
 /* Minimise E_float by energy-non-increasing moves from the current labels; labels stay on the device
  * (phmrf_block_get_labels to fetch).  opts NULL = defaults, res may be NULL. */
 PHMRF_API int phmrf_mrf_solve(phmrf_block_t b, double beta, const phmrf_solve_opts* opts, phmrf_solve_result* res);
-/* ABI 124 (round 6): the same solve of SEVERAL independent blocks in lockstep rounds from the calling thread -- every undecided
- * block's round is queued on its own stream, then the rounds are collected and decided in the same order: the blocks' kernels
- * overlap on the GPU as they do with one host thread per block (the reference: one process per block, base.py:357-362),
- * without the threads.  Block for block the labelling phmrf_mrf_solve gives.  List the largest blocks first. */
+/* ABI 124 (round 6): the same solve of SEVERAL independent blocks from the calling thread alone -- a round of every block is
+ * queued on the block's own stream; the thread then looks at the streams in turn and, as a block's round drains, collects it,
+ * decides it and queues that block's next round at once: the blocks' kernels overlap on the GPU as they do with one host thread
+ * per block (the reference: one process per block, base.py:357-362), without the threads.  Block for block the labelling
+ * phmrf_mrf_solve gives.  List the largest blocks first. */
 PHMRF_API int phmrf_mrf_solve_group(phmrf_block_t* blocks, int n_blocks, double beta, const phmrf_solve_opts* opts);
 /* The same solve in pieces (phmrf_mrf_solve is exactly begin; {launch; collect; decide} while *status == 0; end):
  *   begin    resets the solve's state (stamps, memos, schedule); want_init_energy: also evaluate the starting energy

@@ -239,13 +239,20 @@ class _BaseGraph(object):
             # E-step of the regions this rank owns; un-normalised cost sums travel with the statistics
             local = np.zeros(K * (1 + S + S * S) + 5)
             by_size = sorted(self.my_regions, key=lambda r: -int(len_vec[r][0]))          # largest block first
-            done = self._estep_lockstep(by_size)         # (block_threads=0: every whole block from THIS thread; else None)
-            if done is None:
+            if getattr(self, "lockstep", False):
+                # block_threads=0: every whole block from ONE thread (Block.solve_group) -- this one, unless the rank also holds
+                # row tiles: their lockstep rounds run here then, and the whole blocks on one helper thread meanwhile
+                if by_size and getattr(self, "tile_groups", None):
+                    pending = self.runner.start_one(lambda: self._estep_lockstep(by_size))
+                    tiled = self._estep_tiles()
+                    done = pending.results()[0]
+                else:
+                    done = self._estep_lockstep(by_size)
+                    tiled = self._estep_tiles()
+            else:
                 pending = self.runner.start(self._estep_region, by_size)                  # concurrent streams
                 tiled = self._estep_tiles()     # row tiles of split blocks: lockstep rounds, on this thread meanwhile
                 done = dict(zip(by_size, pending.results()))
-            else:
-                tiled = self._estep_tiles()
             for region_id in self.my_regions:                                             # fixed summation order
                 st, costs = done[region_id]
                 local[:-5] += pack_stats(st)

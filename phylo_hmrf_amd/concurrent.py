@@ -14,6 +14,7 @@ class BlockRunner(object):
         self.n_threads = max(1, int(n_threads))
         self.device = None if device is None else int(device)
         self._pool = None
+        self._aux = None
         if self.n_threads > 1:
             self._pool = ThreadPoolExecutor(max_workers=self.n_threads, initializer=self._init_thread)
 
@@ -37,10 +38,21 @@ class BlockRunner(object):
         futures = [self._pool.submit(fn, it) for it in items]
         return _Deferred(lambda: [f.result() for f in futures])
 
+    def start_one(self, fn):
+        """fn() on ONE helper thread of its own (created at the first call), returning at once; .results() -> [fn()].
+        For a caller that drives all whole blocks from one thread (block_threads=0) and has row tiles to run meanwhile."""
+        if self._aux is None:
+            self._aux = ThreadPoolExecutor(max_workers=1, initializer=self._init_thread)
+        future = self._aux.submit(fn)
+        return _Deferred(lambda: [future.result()])
+
     def close(self):
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
+        if self._aux is not None:
+            self._aux.shutdown(wait=True)
+            self._aux = None
 
 
 class _Deferred(object):

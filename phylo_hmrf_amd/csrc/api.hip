@@ -8,6 +8,7 @@
 #include <limits>
 #include <numeric>
 #include <random>
+#include <thread>
 
 #include "common.h"
 
@@ -2143,29 +2144,46 @@ int phmrf_mrf_solve_group(phmrf_block_t* blocks, int n_blocks, double beta, cons
     scope.n = i + 1;
   }
   std::vector<int> status(n_blocks, 0);
-  std::vector<char> launched(n_blocks, 0);
+  std::vector<char> in_flight(n_blocks, 0);
   unsigned long long counters[128];
   double energy[2];
-  for (;;) {
-    int n_launched = 0;
-    for (int i = 0; i < n_blocks; ++i) {
-      launched[i] = 0;
-      phmrf_block* b = blocks[i];
-      if (status[i] != 0) continue;
-      if (b->ss->rounds >= b->ss->o.max_rounds || b->tick >= 60000) {
-        status[i] = 2;
-        continue;
-      }
-      PHMRF_TRY(solve_round_launch(b));
-      launched[i] = 1;
-      ++n_launched;
+  // queue a block's next round, unless it is decided or out of rounds
+  auto launch = [&](int i) -> int {
+    phmrf_block* b = blocks[i];
+    if (status[i] != 0) return PHMRF_OK;
+    if (b->ss->rounds >= b->ss->o.max_rounds || b->tick >= 60000) {
+      status[i] = 2;
+      return PHMRF_OK;
     }
-    if (n_launched == 0) break;
+    PHMRF_TRY(solve_round_launch(b));
+    in_flight[i] = 1;
+    return PHMRF_OK;
+  };
+  int n_in_flight = 0;
+  for (int i = 0; i < n_blocks; ++i) {
+    PHMRF_TRY(launch(i));
+    n_in_flight += in_flight[i];
+  }
+  // (round 6) the rounds are taken as they END: this thread looks at the streams in turn (hipStreamQuery), and a block whose
+  // round has drained is collected, decided and given its next round at once -- no block waits for another's round.  (The
+  // first form queued a round of every block, then collected them all in order: 69 - 71 ms per E-step of the whole-genome
+  // workload where fourteen threads take 60 - 63.)
+  while (n_in_flight > 0) {
+    bool progressed = false;
     for (int i = 0; i < n_blocks; ++i) {
-      if (!launched[i]) continue;
+      if (!in_flight[i]) continue;
+      const hipError_t q = hipStreamQuery(blocks[i]->stream);
+      if (q == hipErrorNotReady) continue;
+      PHMRF_HIP(q);
       PHMRF_TRY(solve_round_collect(blocks[i], counters, energy));
       PHMRF_TRY(solve_round_decide(blocks[i], counters, energy, &status[i]));
+      in_flight[i] = 0;
+      --n_in_flight;
+      PHMRF_TRY(launch(i));
+      n_in_flight += in_flight[i];
+      progressed = true;
     }
+    if (!progressed) std::this_thread::yield();
   }
   int st = PHMRF_OK;
   for (int i = 0; i < n_blocks; ++i) {

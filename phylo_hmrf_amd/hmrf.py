@@ -448,8 +448,9 @@ class phyloHMRF(_BaseGraph):
         return stats, costs
 
     def _estep_lockstep(self, regions):
-        """block_threads=0: emission and warm start of every whole block queued on its stream, all solves in lockstep rounds
-        from this thread (Block.solve_group: block for block the labels of the per-block solves), then the statistics"""
+        """block_threads=0: emission and warm start of every whole block queued on its stream, all solves from this thread,
+        round by round as the rounds end (Block.solve_group: block for block the labels of the per-block solves), then the
+        statistics"""
         if not self.lockstep:
             return None
         blocks = [self._whole_block(r, "its E-step") for r in regions]

@@ -323,11 +323,11 @@ def test_fit_with_the_blocks_in_lockstep_from_one_thread_equals_the_threaded_fit
     len_vec = [lva[0], [nb, na, na + nb, 50, 50, 0, 0, 1, 1, 2]]
     edges = [ea[0], eb[0]]
 
-    def fit(threads):
+    def fit(threads, **kw):
         m = phyloHMRF(n_components=4, run_id=0, n_samples=na + nb, n_features=4, observation=X, edge_list=tree, len_vec=len_vec,
                       type_id=1, branch_list=[1.0] * 7, edge_list_1=edges, cons_param=1.0, beta=1.0, beta1=0.5, initial_mode=0,
                       initial_weight=0.3, initial_weight1=0.1, initial_magnitude=1.0, estimate_type=3, random_state=5, quiet=True,
-                      mstep_workers=1, block_threads=threads, init_method="sklearn")
+                      mstep_workers=1, block_threads=threads, init_method="sklearn", **kw)
         try:
             return m.fit_accumulate_test(X, len_vec, 0.0, "t", 4)
         finally:
@@ -336,3 +336,8 @@ def test_fit_with_the_blocks_in_lockstep_from_one_thread_equals_the_threaded_fit
     a, b = fit(2), fit(0)
     np.testing.assert_allclose(a[5], b[5], rtol=1e-9)
     assert np.array_equal(a[6], b[6])
+    # with the first block cut into two row tiles: the tiles' lockstep rounds run on the calling thread, the whole block's
+    # group solve on ONE helper thread meanwhile (base.py) -- the fit of the same tiles with the blocks on the runner's threads
+    c, d = fit(2, tile_parts={0: 2}), fit(0, tile_parts={0: 2})
+    np.testing.assert_allclose(c[5], d[5], rtol=1e-9)
+    assert np.array_equal(c[6], d[6])
