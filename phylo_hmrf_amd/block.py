@@ -138,7 +138,7 @@ class Block(object):
     @staticmethod
     def solve_group(blocks, beta, max_rounds=64, use_chains=True, use_components=True, init_mode=0, use_strips=True,
                     use_expansion=True, min_changed=0, energy_tol_ppb=0, use_coarse=True, coarse_start=0):
-        """solve_fast of several independent blocks in lockstep rounds from THIS thread (phmrf_mrf_solve_group): their kernels
+        """solve_fast of several independent blocks from THIS thread, round by round as the rounds end (phmrf_mrf_solve_group): their kernels
         overlap on the GPU as with one host thread per block, without the threads.  List the largest blocks first."""
         if not blocks:
             return

@@ -168,7 +168,7 @@ class phyloHMRF(_BaseGraph):
                 torch.cuda.set_device(device)
         # independent blocks run concurrently, each on its own stream (the reference: one process per block, base.py:357)
         from .concurrent import BlockRunner
-        # block_threads=0: no thread pool -- this thread drives every whole block in lockstep rounds (phmrf_mrf_solve_group)
+        # block_threads=0: no thread pool -- this thread drives every whole block, round by round as the rounds end (phmrf_mrf_solve_group)
         self.lockstep = int(block_threads) == 0
         self.runner = BlockRunner(min(max(int(block_threads), 1), max(1, len(self.my_regions))), device)
 
