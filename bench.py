@@ -847,6 +847,10 @@ def main():
                             "orientations over the whole block), mop_up = the later rounds' (strips whose inputs changed: bound by "
                             "one wave's label loop, few bytes).  traffic = PMC FETCH_SIZE x 2 + WRITE_SIZE per launch of the named "
                             "kernels from the committed rocprofv3 passes, only if taken with this build (traffic_source)"}
+        # (round 6) the whole E-step beside the dominant kernel: what the committed passes of THIS build say about every
+        # kernel of the warm path together -- vector issue capacity (profiles/r6_regime.json: 14 blocks in flight) and HBM
+        # bytes (profiles/pmc_by_kernel.json) over this run's measured E-step time
+        roofline["whole_estep"] = whole_estep_figures(a.workload, float(np.mean(t_e_timed)) if len(t_e_timed) else None)
         if dom_name in ("strip", "fusion"):
             # what the strip kernels move through LDS (device counters): a DP step reads 64 lanes x 8 B and its cell's
             # table (128 B) was written once; staging writes 17 B per staged cell and reads 9 x 5 B back per strip cell
@@ -978,6 +982,47 @@ def pmc_traffic(workload, kernel_names):
     if tot_l == 0:
         return None, "kernels %s not in profiles/pmc_by_kernel.json" % (kernel_names,)
     return int(tot_b / tot_l), "profiles/pmc_by_kernel.json: %s (git %s)" % (d.get("command"), d.get("git_rev"))
+
+
+WARM_PATH_KERNELS = ("strip_cols", "fusion_cols", "propose_grid", "emission", "posterior", "comp_", "cc_", "energy", "choose",
+                     "unary")
+
+
+def whole_estep_figures(workload, estep_s):
+    """-> {"valu_busy", "hbm_frac": [lower, upper], ...} of the whole E-step, from the committed counter passes of this build
+    (None values + the reason when they are another build's or another workload's)"""
+    out = {"valu_busy": None, "hbm_frac": None}
+    try:
+        reg = json.load(open(os.path.join(ROOT, "profiles", "r6_regime.json")))
+        if (reg.get("build") or {}).get("source_hash") == source_hash() and workload == "cfg3":
+            v = reg["estep_valu_pipe_busy_as_benched"]
+            out["valu_busy"] = v["value"]
+            out["valu_source"] = ("profiles/r6_regime.json: SQ_INSTS_VALU per EM iteration (counter pass of the benched command) x 4 / "
+                                  "(E-step of its kernel-trace pass, %.1f ms, x %.1f GHz x 1024 SIMDs)" % (v["estep_ms"], v["assumed_GHz"]))
+        else:
+            out["valu_source"] = "profiles/r6_regime.json is another build's or another workload's"
+    except Exception as e:          # noqa
+        out["valu_source"] = "no profiles/r6_regime.json (%s)" % type(e).__name__
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_by_kernel.json")))
+        if d.get("source_hash") == source_hash() and d.get("workload") == workload and estep_s:
+            its = 7.0                                     # the pass runs --steps 2 --warmup 5 (its cold first iteration included)
+            raw = wr = 0.0
+            for name, rec in d.get("kernels", {}).items():
+                if any(name.startswith(k) for k in WARM_PATH_KERNELS):
+                    raw += rec.get("fetch_bytes_raw", 0.0)
+                    wr += rec.get("write_bytes", 0.0)
+            lo, hi = (raw + wr) / its, (2.0 * raw + wr) / its
+            out["hbm_bytes_per_iteration"] = [int(lo), int(hi)]
+            out["hbm_frac"] = [round(lo / estep_s / (HBM_PEAK_GBS * 1e9), 4), round(hi / estep_s / (HBM_PEAK_GBS * 1e9), 4)]
+            out["hbm_source"] = ("profiles/pmc_by_kernel.json: FETCH_SIZE (raw .. x 2, the guide's gfx950 correction as an upper bound) + "
+                                 "WRITE_SIZE of the warm path's kernels over the pass's 7 EM iterations, per iteration / this run's "
+                                 "E-step (%.1f ms) / %.0f GB/s" % (estep_s * 1e3, HBM_PEAK_GBS))
+        else:
+            out["hbm_source"] = "profiles/pmc_by_kernel.json is another build's or another workload's"
+    except Exception as e:          # noqa
+        out["hbm_source"] = "no profiles/pmc_by_kernel.json (%s)" % type(e).__name__
+    return out
 
 
 def pmc_valu(workload, kernel_names):

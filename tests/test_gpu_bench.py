@@ -49,6 +49,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k["busy_ms"] <= k["ms"] + 1e-3 and k["busy_ms"] <= d["ms_per_step"] * d["steps"] + 1e-3
     # every figure in the roofline object is measured in this run or says where it comes from
     assert "traffic_source" in r and (r["traffic"] is None or r["traffic"] > 0)
+    # (round 6) the whole E-step's figures are the committed cfg3 passes' or absent with the reason -- never another workload's
+    we = r["whole_estep"]
+    assert we["valu_busy"] is None and we["hbm_frac"] is None and we["valu_source"] and we["hbm_source"]
     # the start of an E-step's labelling is on the line where the driver keeps it, and the whole fit is there under both rules
     assert "warm_start=best" in d["config"]["workload"]
     assert d["fit"]["warm_start"] == "best" and d["fit_reference_start"]["warm_start"] == "local"

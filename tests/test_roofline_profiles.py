@@ -8,6 +8,7 @@ full sweeps and mop-up launches differs a little from the timed region's)."""
 import csv
 import json
 import os
+import sys
 
 import pytest
 
@@ -78,3 +79,23 @@ def test_valu_on_the_line_follows_from_the_committed_counter_pass():
     if pk["source_hash"] == d["build"]["source_hash"]:               # the line was written by the build the pass profiled
         assert r["valu"]["busy"] is not None and abs(r["valu"]["busy"] - busy) <= 0.02 * busy, (r["valu"], busy)
         assert r["bound"] == ("valu" if busy > r["frac"] else "hbm")
+
+
+def test_whole_estep_figures_follow_from_the_committed_passes():
+    """Round 6: `roofline.whole_estep` -- the vector pipes' and the HBM's share over the WHOLE E-step -- is arithmetic on the two
+    committed counter files of this build: SQ_INSTS_VALU per iteration of profiles/r6_regime.json, FETCH_SIZE / WRITE_SIZE of
+    the warm path's kernels in profiles/pmc_by_kernel.json.  While both are this build's the figures must be there and say
+    what DESIGN.md says: neither resource is saturated (vector pipes 0.5 - 0.7, HBM 0.25 - 0.65 of peak)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_by_kernel.json")))
+    reg = json.load(open(os.path.join(ROOT, "profiles", "r6_regime.json")))
+    w = bench.whole_estep_figures("cfg3", 1e-3 * reg["bench_under_kernel_trace"]["estep_ms"])
+    if pk["source_hash"] == bench.source_hash():
+        lo, hi = w["hbm_frac"]
+        assert 0.25 < lo < hi < 0.65 and hi < 2.0 * lo + 1e-9, w
+        assert w["hbm_bytes_per_iteration"][0] > 88.8e6 * 300          # >= 300 B per node and EM iteration
+    if reg["build"]["source_hash"] == bench.source_hash():
+        assert 0.5 < w["valu_busy"] < 0.7, w
+    other = bench.whole_estep_figures("small", 1e-3)
+    assert other["valu_busy"] is None and other["hbm_frac"] is None and "another" in other["hbm_source"]
