@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--beta1", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ab-env", default="",
-                    help="development (libphmrf_dev.so via PHMRF_LIB): NAME=A,B -- after everything else, --ab-steps more EM "
+                    help="development (libphmrf_dev.so via PHMRF_LIB; or a solver option such as energy_tol_ppb): NAME=A,B -- after everything else, --ab-steps more EM "
                          "iterations whose E-step runs TWICE from the same labellings and parameters, once with the environment "
                          "variable NAME set to A and once to B (order alternating); both times and cost1 go to `ab` on the line")
     ap.add_argument("--ab-steps", type=int, default=20)
@@ -109,9 +109,13 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=652,
                     help="side N of the diagonal block used for the CPU baseline (652: the size of config 1's chr21 block)")
     ap.add_argument("--no-expansion", action="store_true")
-    ap.add_argument("--energy-tol-ppb", type=int, default=1000,
+    ap.add_argument("--energy-tol-ppb", type=int, default=10000,
                     help="stop the label solver when a round lowers the energy by less than this many ppb (0 = exact "
-                         "fixed point); energy parity with gco at this setting: tests/test_gpu_estep.py")
+                         "fixed point).  10000 = 1e-5 |E|: the level at which two solves of the same inputs differ (1.4e-5 per "
+                         "E-step, profiles/r6_late_round_economies.txt); rounds 3-5 benched 1000, which the line still "
+                         "carries as `at_tol_1000ppb`; energy parity with gco at 0, 1000 and 10000: tests/test_gpu_estep.py")
+    ap.add_argument("--no-old-tolerance", action="store_true",
+                    help="skip the second window at the stopping tolerance of rounds 3-5 (`at_tol_1000ppb`)")
     return ap.parse_args()
 
 
@@ -582,6 +586,45 @@ def main():
                         "GBps": (round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[2] > 0 else None)}
                     for k, v in agg_i.items()}
 
+    # ---- the same warm-up + timed EM iterations REPLAYED from the bench's start (same parameters, first labelling and M-step
+    #      draws) at the stopping tolerance of rounds 3 - 5 (1e-6 |E|; not part of `value`): the number that continues
+    #      BENCH_r03 .. r05 beside the one at this round's default tolerance.  (Later iterations of the same EM are calmer: a
+    #      window that merely FOLLOWED the timed region would flatter whichever setting it ran.)
+    at_old_tol = None
+    if not a.no_old_tolerance and a.energy_tol_ppb != 1000 and unit_blocks:
+        for b in unit_blocks:                        # (the same event timers as in the timed region)
+            b.enable_timing(not a.no_kernel_timing, classes=[dominant] if dominant else None)
+            b.reset_timing()
+            b.restore_labels(SLOT_INIT)
+            b.save_labels(SLOT_LOCAL)
+        keep = solver["energy_tol_ppb"]
+        solver["energy_tol_ppb"] = 1000
+        state.update(min_cost=1e30, params=params_cur.copy(), means=means, covars=covars, warm_start=a.warm_start)
+        rng.bit_generator.state = rng_state_at_start
+        for _ in range(a.warmup):
+            em_step()
+        n_e, n_m = len(t_e), len(t_m)
+        u_old = untimed[0]
+        barrier()
+        t_old = time.time()
+        for _ in range(a.steps):
+            em_step()
+        barrier()
+        el_old = time.time() - t_old - (untimed[0] - u_old)
+        solver["energy_tol_ppb"] = keep
+        if use_dist:
+            t = torch.tensor([el_old], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_old = float(t.item())
+        at_old_tol = {"energy_tol_ppb": 1000, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el_old / a.steps * 1e3,
+                      "value": n_norm * a.steps / el_old, "estep_ms": float(np.mean(t_e[n_e:]) * 1e3),
+                      "mstep_ms": float(np.mean(t_m[n_m:]) * 1e3),
+                      "estep_ms_by_step": [round(x * 1e3, 1) for x in t_e[n_e:]],
+                      "note": "the warm-up + timed EM iterations replayed from the bench's start (same parameters, first labelling and "
+                              "M-step draws; the EM is chaotic: another draw of the same iterations) with the label solver's stopping "
+                              "tolerance at 1e-6 |E| as benched in rounds 3 - 5; `value` is measured at config.mrf_solver.energy_tol_ppb"}
+        del t_e[n_e - a.warmup:], t_m[n_m - a.warmup:]
+
     # ---- the WHOLE FIT (not part of `value`): the same workload from the same start under the reference's own stopping
     #      rules -- threshold 0.001 and at most 60 iterations (phylo_hmrf.py:1555, :1561), the relative-change tests after
     #      iteration 5 and the 50-iterations-past-the-minimum test (base.py:428-435), no M-step after the last E-step --
@@ -738,12 +781,16 @@ def main():
             b.enable_timing(False)
         ms = {va: [], vb: []}
         c1 = {va: [], vb: []}
+        solver_before = dict(solver)
         for it in range(a.ab_steps):
             for b in unit_blocks:
                 b.save_labels(SLOT_AB)                 # the labelling the previous E-step left
             tot = None
             for v in ((va, vb) if it % 2 == 0 else (vb, va)):
-                os.environ[name] = v
+                if name in solver:                     # a solver option (energy_tol_ppb, max_rounds, ...) instead of a knob
+                    solver[name] = type(solver[name])(int(v))
+                else:
+                    os.environ[name] = v
                 for b in unit_blocks:
                     b.restore_labels(SLOT_AB)
                     if not a.no_prepare and solver["use_components"]:
@@ -762,6 +809,7 @@ def main():
                 for b in unit_blocks:
                     b.save_labels(SLOT_LOCAL)
             mstep_all(stats, rng)
+        solver.update(solver_before)
         ab = {"env": name, "values": [va, vb], "steps": a.ab_steps,
               "estep_ms_mean": {v: round(float(np.mean(ms[v])), 3) for v in ms},
               "estep_ms_median": {v: round(float(np.median(ms[v])), 3) for v in ms},
@@ -917,6 +965,7 @@ def main():
             "tile_rounds": tile_rounds,
             "per_rank": per_rank,
             **({"ab": ab} if ab else {}),
+            "at_tol_1000ppb": at_old_tol,
             "cost1": [round(c, 6) for c in cost1_log[-min(len(cost1_log), 8):]],     # the last iterations' cost1 (base.py:410)
             "build": {"source_hash": source_hash()},
             "value_estep_only": n_norm * a.steps / float(np.sum(t_e_timed)),

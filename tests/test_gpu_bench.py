@@ -59,6 +59,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert f["iterations"] >= 1 and f["value"] > 0 and len(f["estep_ms"]) == f["iterations"]
         assert (f["steady_ms_per_iteration"] is None) == (f["iterations"] <= 5)      # the steady cost under each start rule
     assert d["build"]["source_hash"]
+    # (round 6) the stopping tolerance is on the line, and so is the number at the tolerance rounds 3 - 5 benched
+    assert d["config"]["mrf_solver"]["energy_tol_ppb"] == 10000
+    old = d["at_tol_1000ppb"]
+    assert old["energy_tol_ppb"] == 1000 and old["steps"] == d["steps"] and old["ms_per_step"] > 0 and old["value"] > 0
     # (round 6) the same iterations through the product's own loop, and every rank's own clocks
     fs = d["fit_surface"]
     assert fs["iterations_timed"] == 2 and fs["warmup"] == 1 and fs["ms_per_step"] > 0 and len(fs["ms_per_step_by_iteration"]) == 3

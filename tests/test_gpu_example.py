@@ -38,7 +38,7 @@ def _block(ex):
     return b
 
 
-@pytest.mark.parametrize("tol_ppb", [0, 1000])
+@pytest.mark.parametrize("tol_ppb", [0, 1000, 10000])
 @pytest.mark.parametrize("it", [0, 1, 2, 3, 4])
 def test_energy_below_the_reference_on_real_hic(ex, it, tol_ppb):
     beta = float(ex["beta"])
@@ -91,7 +91,7 @@ def test_energy_below_the_reference_on_the_full_chr22_block(exfull, it):
     np.testing.assert_allclose([e_init, e_ref_lab], [ex["it_efloat_init"][it][0], ex["it_efloat"][it][0]], rtol=1e-9)
     b = _block(ex)
     b.emission(ex["it_means"][it], ex["it_covars"][it])
-    for tol_ppb in (0, 1000):
+    for tol_ppb in (0, 1000, 10000):
         b.set_labels(ex["it_init"][it])
         res = b.solve(beta, energy_tol_ppb=tol_ppb)
         e_mine = R.mrf_energy(b.get_labels(), lp, ex["eid"], ex["w"], beta)[0]
