@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The BENCHED regime (bench.py's default: 26 blocks, 14 in flight) under rocprofv3, two passes of the same command
-    python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-kernel-timing
+    python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-old-tolerance --no-kernel-timing
 
   KT_DIR   rocprofv3 --kernel-trace                      (concurrent streams as benched: where each stream's time goes)
   PMC_DIR  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE
@@ -53,7 +53,7 @@ def main():
     kt_dir, pmc_dir, bench_json, out_path = sys.argv[1:5]
     per_iter = int(sys.argv[5]) if len(sys.argv) > 5 else 26
     first = int(sys.argv[6]) if len(sys.argv) > 6 else 6
-    out = {"command": "python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-kernel-timing"}
+    out = {"command": "python3 bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-old-tolerance --no-kernel-timing"}
     bench = None
     try:
         bench = json.loads(open(bench_json).read().strip().splitlines()[-1])

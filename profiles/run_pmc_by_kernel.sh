@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 export PHMRF_GIT_REV=${1:-unknown}
 O=gpurun_out
-CMD="python3 bench.py --steps 2 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --block-threads 1 --mstep-workers 1"
+CMD="python3 bench.py --steps 2 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-old-tolerance --block-threads 1 --mstep-workers 1"
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pk_fetch -- $CMD > $O/pk_fetch.out 2> $O/pk_fetch.err || echo "FETCH pass failed"
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pk_write -- $CMD > $O/pk_write.out 2> $O/pk_write.err || echo "WRITE pass failed"
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/pk_valu -- $CMD > $O/pk_valu.out 2> $O/pk_valu.err || echo "VALU pass failed"

@@ -37,7 +37,7 @@ if [ "$PART" = "a" ]; then
   summ r6_bench r6_bench_steps20_warmup5 r6_bench_steps20_warmup5_b r6_bench_steps20_warmup5_c
 fi
 if [ "$PART" = "b" ]; then
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r6_stats -- python3 bench.py --no-cpu-baseline --no-fit --no-through-fit > $O/r6_bench_under_rocprof.json 2> $O/r6_rocprof.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r6_stats -- python3 bench.py --no-cpu-baseline --no-fit --no-through-fit --no-old-tolerance > $O/r6_bench_under_rocprof.json 2> $O/r6_rocprof.err
   find $O/r6_stats -name "*kernel_stats.csv" -exec cp {} $O/r6_kernel_stats.csv \;
   rm -rf $O/r6_stats
   bash profiles/run_profiles_r6_serial.sh

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out; mkdir -p $O
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r6_stats -- python3 bench.py --no-cpu-baseline --no-fit --no-through-fit --block-threads 1 --mstep-workers 1 --steps 8 --warmup 2 > $O/r6_bench_under_rocprof_serial.json 2> $O/r6_rocprof_serial.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r6_stats -- python3 bench.py --no-cpu-baseline --no-fit --no-through-fit --no-old-tolerance --block-threads 1 --mstep-workers 1 --steps 8 --warmup 2 > $O/r6_bench_under_rocprof_serial.json 2> $O/r6_rocprof_serial.err
 find $O/r6_stats -name "*kernel_stats.csv" -exec cp {} $O/r6_kernel_stats_serial.csv \;
 rm -rf $O/r6_stats
 python3 - <<'PY'

@@ -9,7 +9,7 @@ python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fit --no-through-f
 python3 -c "
 import json;d=json.loads(open('$O/${TAG}_base.json').read().strip().splitlines()[-1]);r=d['roofline']
 print('base: ms/step %.2f estep %.2f mstep %.2f cold %.0f | frac %.4f full %s mop %s'%(d['ms_per_step'],d['estep_ms'],d['mstep_ms'],d['cold_first_iteration_ms'],r['frac'],r['full_sweep']['own_ms'],r['mop_up']['own_ms']))"
-CMD="bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-kernel-timing"
+CMD="bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-fit --no-through-fit --no-old-tolerance --no-kernel-timing"
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_kt -- python3 $CMD > $O/${TAG}_regime_bench.json 2> $O/${TAG}_kt.err || exit 1
 echo "kernel trace done"
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc -- python3 $CMD > $O/${TAG}_regime_bench_pmc.json 2> $O/${TAG}_pmc.err || exit 1
