@@ -103,13 +103,14 @@ def test_energy_below_the_reference_on_the_full_chr22_block(exfull, it):
     b.close()
 
 
+@pytest.mark.parametrize("FIT_TOL_PPB,tile_gap", [(1000, 5e-4), (10000, 1e-3)])     # (the fit's tolerance: 1e-5 since round 6, 1e-6 before)
 @pytest.mark.parametrize("parts", [1, 2, 3])
-def test_warm_start_policy_and_row_tiles_stay_below_the_reference_at_every_iteration(exfull, parts):
+def test_warm_start_policy_and_row_tiles_stay_below_the_reference_at_every_iteration(exfull, parts, FIT_TOL_PPB, tile_gap):
     """The fit's own E-step sequence on the full chr22 block: five EM iterations of the reference's parameters, each
     labelling started from the reference's labels_local of that iteration OR from this build's previous result, whichever
     has the lower energy (Block.warm_start, the fit's default), at the fit's stopping tolerance -- as one block (parts = 1)
     and cut into 2 and 3 row tiles solved in lockstep rounds (tiles.py).  Every iteration's labelling is strictly at or
-    below the reference's (gco swap through pygco, same float64 energy function); the tiled solves end at most 1e-3 above
+    below the reference's (gco swap through pygco, same float64 energy function); the tiled solves end at most 5e-4 (1e-3 at 1e-5) above
     the unsplit one (two local minima of one energy on a 233,586-node block in a run whose energy falls from 536,000 to 92,000
     in four iterations: measured +4e-5, +2.8e-4, -4.2e-4, -2.1e-3 -- the reference's own results are 0.2 % to 166 % above
     either; at 2,001,000 nodes tiled and unsplit agree to 1e-5, tests/test_gpu_tiles.py)."""
@@ -146,7 +147,7 @@ def test_warm_start_policy_and_row_tiles_stay_below_the_reference_at_every_itera
         ec, es, took = whole.warm_start(beta, SLOT_LOCAL)
         e_start = min(ec, es)
         np.testing.assert_allclose(es, R.mrf_energy(init, lp, ex["eid"], ex["w"], beta)[0], rtol=1e-6)
-        whole.solve_fast(beta, energy_tol_ppb=1000)
+        whole.solve_fast(beta, energy_tol_ppb=FIT_TOL_PPB)
         e_whole = R.mrf_energy(whole.get_labels(), lp, ex["eid"], ex["w"], beta)[0]
         assert e_whole <= e_ref_lab and e_whole <= e_start * (1 + 1e-9), (it, e_whole, e_ref_lab, e_start)
         if grp is None:
@@ -156,7 +157,7 @@ def test_warm_start_policy_and_row_tiles_stay_below_the_reference_at_every_itera
             tl.b.set_labels(init[tl.global_slice()])
             tl.b.save_labels(SLOT_LOCAL)
             tl.b.set_labels(cur)
-        cond.solve(beta, dict(energy_tol_ppb=1000), prepare=lambda tl: tl.b.emission(ex["it_means"][it], ex["it_covars"][it]),
+        cond.solve(beta, dict(energy_tol_ppb=FIT_TOL_PPB), prepare=lambda tl: tl.b.emission(ex["it_means"][it], ex["it_covars"][it]),
                    warm_slot=SLOT_LOCAL)
         lab = np.zeros(n, dtype=np.int64)
         for tl in grp.local.values():
@@ -166,7 +167,7 @@ def test_warm_start_policy_and_row_tiles_stay_below_the_reference_at_every_itera
               % (it, parts, e_ref_lab, e_whole, e_tiled, (e_tiled - e_whole) / abs(e_whole)))
         assert e_tiled <= e_ref_lab, (it, e_tiled, e_ref_lab)          # strictly at or below the reference
         # (measured over the five iterations: +4e-5 ... -2.1e-3 with 2 and 3 tiles; worst +2.8e-4)
-        assert e_tiled <= e_whole + 5e-4 * abs(e_whole), (it, e_tiled, e_whole)
+        assert e_tiled <= e_whole + tile_gap * abs(e_whole), (it, e_tiled, e_whole)
     whole.close()
     if grp is not None:
         for tl in grp.local.values():
