@@ -78,6 +78,9 @@ def parse_args(argv=None):
     parser.add_option("--warm_start", default="best", help="start of an E-step's labelling: 'local' = labels_local, the labels of "
                       "the iteration with the lowest cost so far, as the reference does (phylo_hmrf.py:479); 'best' (default) = "
                       "that or the previous E-step's labels, whichever has the lower energy under the new parameters")
+    parser.add_option("--energy_tol_ppb", default="10000", help="the label solver of an E-step stops when a whole round lowers the "
+                      "energy by less than this many parts per billion of it (default 10000 = 1e-5, the level at which two solves of "
+                      "the same inputs differ; 1000 until round 6; 0 = to the exact fixed point, ~25x the E-step time)")
     parser.add_option("--checkpoint", default="", help="write an .npz checkpoint of the fit here after every "
                       "--checkpoint_every-th EM iteration (parameters, cost bookkeeping, labellings, random generator)")
     parser.add_option("--checkpoint_every", default="1", help="EM iterations between checkpoints")
@@ -178,7 +181,7 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
         initial_mode, initial_weight, initial_weight1, initial_magnitude, position1, position2, filter_sigma, beta,
         beta1, num_neighbor, filter_mode, conv_threshold, estimate_type, simu_version, annotation, reload_mode,
         diagonal_type, m_iter, resolution, quantile, ref_species, output_path, synthetic="0", seed="", quiet="0",
-        init_method="minibatch", warm_start="best", checkpoint="", checkpoint_every="1", resume=""):
+        init_method="minibatch", warm_start="best", checkpoint="", checkpoint_every="1", resume="", energy_tol_ppb="10000"):
     run_id = int(run_id1)
     n_components1 = int(num_states)
     cons_param = float(cons_param)
@@ -264,7 +267,8 @@ def run(num_states, chromvec, root_path, multiple, species_name, sort_states, ru
                           initial_weight1=initial_weight1, initial_magnitude=initial_magnitude, learning_rate=0.001,
                           estimate_type=estimate_type, max_iter=100, n_iter=5000, tol=1e-7, num_neighbor=num_neighbor,
                           random_state=seed, quiet=bool(int(quiet)), init_method=init_method, warm_start=warm_start,
-                          checkpoint_path=checkpoint or None, checkpoint_every=int(checkpoint_every), resume_from=resume or None)
+                          checkpoint_path=checkpoint or None, checkpoint_every=int(checkpoint_every), resume_from=resume or None,
+                          solver_opts=dict(energy_tol_ppb=int(energy_tol_ppb)))
         print("fitting...")
         lambda_0 = cons_param
         filename = "%s/estimate_ou_%d_%.2f_%d_%s" % (output_path, run_id, lambda_0, n_components1, annotation)
@@ -297,4 +301,5 @@ if __name__ == "__main__":
         opts.num_neighbor, opts.filter_mode, opts.threshold, opts.estimate_type, opts.simu_version, opts.annotation,
         opts.reload, opts.dtype, opts.miter, opts.resolution, opts.quantile, opts.ref_species, opts.output,
         synthetic=opts.synthetic, seed=opts.seed, quiet=opts.quiet, init_method=opts.init, warm_start=opts.warm_start,
-        checkpoint=opts.checkpoint, checkpoint_every=opts.checkpoint_every, resume=opts.resume)
+        checkpoint=opts.checkpoint, checkpoint_every=opts.checkpoint_every, resume=opts.resume,
+        energy_tol_ppb=opts.energy_tol_ppb)
