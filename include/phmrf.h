@@ -167,7 +167,9 @@ typedef struct phmrf_solve_opts {
                           as, at the round's average gain per changed label, all rested types together were worth at most
                           a quarter of the tolerance -- a heuristic about labels, not a bound on the energy a stop
                           leaves behind (what the stops do leave is measured against gco in the parity tests).
-                          0: run to the exact fixed point                                                          */
+                          0: run to the exact fixed point.  The host side's default is 10000 (1e-5: the level at which two
+                          solves of the same inputs differ; 1e-6 costs 8 % more E-step time for 5e-6 of energy, the exact
+                          fixed point 25 x for 1.7e-4: profiles/r6_late_round_economies.txt)                          */
   int coarse_start;    /* 1: a cold start (init_mode 1) of a grid block begins COARSE-TO-FINE: the labelling problem of its
                           4 x 4 super-cells (unary terms and crossing pair weights summed: an ordinary Potts problem on a
                           grid of n / 16 nodes) is solved by this same solver -- recursively while it is large --, its
