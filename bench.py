@@ -782,6 +782,7 @@ def main():
         ms = {va: [], vb: []}
         c1 = {va: [], vb: []}
         solver_before = dict(solver)
+        threads_before = a.block_threads
         for it in range(a.ab_steps):
             for b in unit_blocks:
                 b.save_labels(SLOT_AB)                 # the labelling the previous E-step left
@@ -789,6 +790,8 @@ def main():
             for v in ((va, vb) if it % 2 == 0 else (vb, va)):
                 if name in solver:                     # a solver option (energy_tol_ppb, max_rounds, ...) instead of a knob
                     solver[name] = type(solver[name])(int(v))
+                elif name == "block_threads":          # 0: all whole blocks from this thread (group solve); else the runner's threads
+                    a.block_threads = int(v)
                 else:
                     os.environ[name] = v
                 for b in unit_blocks:
@@ -810,6 +813,7 @@ def main():
                     b.save_labels(SLOT_LOCAL)
             mstep_all(stats, rng)
         solver.update(solver_before)
+        a.block_threads = threads_before
         ab = {"env": name, "values": [va, vb], "steps": a.ab_steps,
               "estep_ms_mean": {v: round(float(np.mean(ms[v])), 3) for v in ms},
               "estep_ms_median": {v: round(float(np.median(ms[v])), 3) for v in ms},
